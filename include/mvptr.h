@@ -1,0 +1,249 @@
+/*
+ * mvptr.h — C ABI of libmvptr_hip.so, the MI355X (gfx950) implementation of MVPTR's
+ * cross-modal BERT encoder hot path.
+ *
+ * The reference has no FFI: its "operator interface" for this path is a sequence of PyTorch
+ * ops inside oscar/modeling/modeling_vlbert.py and
+ * transformers/pytorch_transformers/modeling_bert.py.  Each entry point below names the
+ * reference op sequence (file:line, relative to the reference tree) it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated; tensors are row-major;
+ *   - `bf16` buffers are raw uint16 bfloat16; statistics, losses and weight gradients are f32;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     without synchronising the device; no call allocates device memory;
+ *   - return 0 on success, a negative mvptr_status otherwise; mvptr_last_error() returns a
+ *     thread-local description of the last failure on the calling thread;
+ *   - the library keeps no mutable global state (re-entrant, one process per GPU or several
+ *     host threads on several devices).
+ */
+#ifndef MVPTR_H
+#define MVPTR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MVPTR_OK = 0,
+  MVPTR_BAD_SHAPE = -1,
+  MVPTR_BAD_ALIGN = -2,
+  MVPTR_WORKSPACE_TOO_SMALL = -3,
+  MVPTR_UNSUPPORTED_ARCH = -4,
+  MVPTR_HIP_ERROR = -5,
+  MVPTR_BAD_ARG = -6
+} mvptr_status;
+
+/* mvptr_query `what` codes */
+enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
+
+#define MVPTR_ABI_VERSION 1
+
+/* GEMM epilogues (see mvptr_gemm_nt) */
+typedef enum {
+  MVPTR_EPI_BIAS = 0,        /* out0(bf16) = acc + bias                                  */
+  MVPTR_EPI_BIAS_GELU = 1,   /* out0(bf16) = u = acc + bias ; out1(bf16) = gelu_erf(u)    */
+  MVPTR_EPI_BIAS_RESID = 2,  /* out0(bf16) = dropout(acc + bias) + aux(bf16)              */
+  MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * gelu_erf'(aux) ; colsum -> vec_out f32 */
+  MVPTR_EPI_ADD = 4,         /* out0(bf16) = acc + aux(bf16)  (aux may be NULL)           */
+  MVPTR_EPI_F32 = 5,         /* out0(f32)  = acc + bias                                   */
+  MVPTR_EPI_BIAS_TANH = 6    /* out0(bf16) = tanh(acc + bias)                             */
+} mvptr_epilogue;
+
+/* Dropout descriptor: keep-mask bit for element index i is
+ *   h = mvptr_hash32((uint32)(i >> 1) ^ seed_lo) ; h2 = mvptr_hash32(h + seed_hi + (uint32)(i >> 33))
+ *   (mvptr_hash32 = the 'lowbias32' integer mixer: x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16)
+ *   u16 = (i & 1) ? (h2 >> 16) : (h2 & 0xffff) ; keep = u16 >= thresh16
+ * with thresh16 = round(p * 65536) and kept values scaled by 65536/(65536-thresh16).
+ * p == 0 (thresh16 == 0) disables dropout.  The element index is op-specific and documented
+ * per call.  mvptr_dropout_mask() materialises the same mask for tests. */
+typedef struct {
+  uint32_t seed_lo;
+  uint32_t seed_hi;
+  uint32_t thresh16; /* 0 => no dropout */
+  uint32_t pad_;
+} mvptr_dropout;
+
+int mvptr_query(int what, int64_t* out);
+const char* mvptr_last_error(void);
+
+/* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue; A,B bf16, f32 accumulate (MFMA 16x16x32).
+ * Replaces nn.Linear forward (y = x W^T + b): modeling_bert.py:348 (BertSelfOutput.dense),
+ * :395 (BertIntermediate.dense + gelu :142-148), :408 (BertOutput.dense), Q/K/V projections
+ * modeling_vlbert.py:71-73, and the data-gradient of the same layers (dX = dY * W, with
+ * B = W^T as stored by mvptr_cast_pack).
+ * lda/ldb/ldc/ld_aux in elements; K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned.
+ * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual / pre-activation) or NULL.
+ * vec_out: f32[N] column sums (EPI_GELU_BWD), accumulated with atomics, or NULL.
+ * drop: dropout on (acc + bias) for EPI_BIAS_RESID, element index = m * N + n. */
+int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                  int epilogue, const float* bias, const void* aux, int64_t ld_aux, void* out0,
+                  void* out1, int64_t ldc, float* vec_out, const mvptr_dropout* drop,
+                  void* stream);
+
+/* dW[N,K] (+)= A[M,N]^T * B[M,K] ; A = dY (bf16), B = X (bf16), dW f32 (MFMA 32x32x16,
+ * transposed LDS reads, split over M with f32 atomics when accumulate != 0 or splits > 1).
+ * Replaces the weight gradient of nn.Linear computed by autograd (addmm backward) for every
+ * Linear cited above.  The caller zeroes dW when it wants a fresh gradient.
+ * lda % 8 == 0, ldb % 8 == 0 (rows padded so that partial 16-byte chunks at the N/K edge stay
+ * inside the row). */
+int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                  float* dW, int64_t ldw, void* stream);
+
+/* Column sums: out[n] += sum_m X[m,n] (X bf16 [M, ldx]); bias gradients. */
+int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream);
+
+/* Self-attention core, one workgroup per (batch, head), whole sequence resident in LDS.
+ * Replaces modeling_vlbert.py:75-100 (transpose_for_scores, QK^T/sqrt(d) + mask, softmax,
+ * dropout, PV, merge heads).  qkv: bf16 [B*L, 3*H] (Q | K | V, head-major inside each),
+ * mask_add: f32 [B, L] additive mask (0 / -10000) broadcast over heads and queries,
+ * ctx: bf16 [B*L, H], lse: f32 [B, heads, L] (row log-sum-exp, saved for backward; may be
+ * NULL in inference).  head_dim must be 64, L <= 256.
+ * drop: dropout on the probabilities, element index = ((b*heads + h)*L + q)*L + key. */
+int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse, int B,
+                        int L, int heads, const mvptr_dropout* drop, void* stream);
+
+/* Backward of the above: dqkv bf16 [B*L, 3*H] from dctx bf16 [B*L, H].  P is recomputed from
+ * qkv and lse; delta = rowsum(dctx*ctx) is computed in-kernel. */
+int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
+                        const void* dctx, const float* lse, void* dqkv, int B, int L, int heads,
+                        const mvptr_dropout* drop, void* stream);
+
+/* y = LayerNorm(z) * gamma + beta (TF style, eps inside sqrt), optional dropout on y.
+ * Replaces BertLayerNorm.forward modeling_bert.py:242-246 (+ nn.Dropout where the reference
+ * applies it right after, e.g. BertEmbeddings :275-276, img embedding modeling_vlbert.py:499-503).
+ * z: bf16 [M, H]; y: bf16, row r is written to out row  (r / rows_per_group) * group_stride +
+ * row_offset + (r % rows_per_group)  (lets the caller write straight into a concatenated
+ * sequence buffer; rows_per_group = M, group_stride = 0, row_offset = 0 for the identity).
+ * mean/rstd: f32 [M] saved statistics (may be NULL).  H % 8 == 0, H <= 1024.
+ * drop element index = r * H + c. */
+int mvptr_layernorm_fwd(const void* z, const float* gamma, const float* beta, float eps,
+                        void* y, float* mean, float* rstd, int M, int H, int rows_per_group,
+                        int group_stride, int row_offset, const mvptr_dropout* drop,
+                        void* stream);
+
+/* Backward of LayerNorm (+ the dropout that followed the producing dense layer).
+ * dy: bf16, read with the same row remap as y above; z/mean/rstd as saved by forward.
+ * y_drop: dropout that was applied to y in forward (or NULL).
+ * dz: bf16 [M,H] gradient wrt z.  dd: bf16 [M,H] = dz with `dense_drop` applied (gradient wrt
+ * the dense output that was dropped out before the residual add; element index m*H+c);
+ * dd may be NULL when dense_drop is NULL/disabled (then dd == dz).
+ * dgamma/dbeta/dbias: f32 [H], accumulated with atomics (dbias = colsum(dd), may be NULL). */
+int mvptr_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
+                        const float* gamma, void* dz, void* dd, float* dgamma, float* dbeta,
+                        float* dbias, int M, int H, int rows_per_group, int group_stride,
+                        int row_offset, const mvptr_dropout* y_drop,
+                        const mvptr_dropout* dense_drop, void* stream);
+
+/* Embedding gather + add: z[r, :] = word[ids[r]] + pos[pos_ids[r]] + type[type_ids[r]] (bf16 out).
+ * Replaces BertEmbeddings.forward modeling_bert.py:268-273 (LayerNorm + dropout follow through
+ * mvptr_layernorm_fwd).  Tables are f32 master weights; ids are int64. */
+int mvptr_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                    const float* word, const float* pos, const float* type, void* z, int rows,
+                    int H, int64_t vocab, int64_t npos, int64_t ntype, void* stream);
+
+/* Backward: scatter-add dz (bf16 [rows,H]) into the three f32 gradient tables (atomics).
+ * Replaces embedding_dense_backward of the three nn.Embedding tables. */
+int mvptr_embed_bwd(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                    const void* dz, float* dword, float* dpos, float* dtype, int rows, int H,
+                    void* stream);
+
+/* f32 -> bf16 cast with optional K padding and optional transposed copy.
+ * src f32 [rows, cols] (row stride ld_src) -> dst bf16 [rows, ld_dst] (cols..ld_dst zero filled)
+ * and, if dst_t != NULL, dst_t bf16 [cols, ld_dst_t] = src^T written at column offset col_off_t.
+ * Used for (a) bf16 working copies of the f32 master weights, packed (Q|K|V rows) and
+ * transposed for the data-gradient GEMMs, (b) the 2054-d region features
+ * (modeling_vlbert.py:498 input) cast to bf16 with K padded to a multiple of 8. */
+int mvptr_cast_pack(const float* src, int64_t ld_src, int rows, int cols, void* dst,
+                    int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int col_off_t, void* stream);
+
+/* bf16 -> f32 strided copy (grad hand-back / outputs) */
+int mvptr_cast_f32(const void* src, int64_t ld_src, int rows, int cols, float* dst,
+                   int64_t ld_dst, void* stream);
+
+/* Cross-entropy over f32 logits [M, ld] with int64 labels (-1 = ignore):
+ * loss_row[m] = lse - logit[label] (0 when ignored), lse_row[m] saved.
+ * Replaces CrossEntropyLoss(ignore_index=-1) modeling_vlbert.py:1228-1251 on the MLM /
+ * masked-concept logits.  bwd writes dlogits bf16 [M, ld_d] = (softmax - onehot) * scale[0]
+ * where scale is a device f32 scalar (upstream gradient / number of valid rows). */
+int mvptr_ce_fwd(const float* logits, int64_t ld, const int64_t* labels, float* loss_row,
+                 float* lse_row, int M, int V, void* stream);
+int mvptr_ce_bwd(const float* logits, int64_t ld, const int64_t* labels, const float* lse_row,
+                 const float* scale, void* dlogits, int64_t ld_d, int M, int V, int Vpad,
+                 void* stream);
+
+/* Materialise the dropout keep-mask (1/0 bytes) for n elements — test support. */
+int mvptr_dropout_mask(const mvptr_dropout* drop, int64_t n, uint8_t* keep, void* stream);
+
+/* One BERT encoder layer, forward and backward, composed from the kernels above.
+ * Replaces CaptionBertLayer.forward modeling_vlbert.py:191-199 (attention :63-103,
+ * BertSelfOutput modeling_bert.py:348-352, BertIntermediate :394-397, BertOutput :407-411)
+ * and its autograd backward. */
+typedef struct {
+  int B, L, H, heads, I;
+  float eps;
+  int training;        /* save activations for backward                       */
+  uint32_t p_hidden16; /* dropout threshold (p*65536) for dense outputs        */
+  uint32_t p_attn16;   /* dropout threshold for attention probabilities        */
+  uint64_t seed;       /* per-layer-call seed                                  */
+} mvptr_layer_desc;
+
+typedef struct {
+  const void* w_qkv;   /* bf16 [3H, H]  (query|key|value rows)                 */
+  const void* w_qkv_t; /* bf16 [H, 3H]  transposed copy for dgrad              */
+  const float* b_qkv;  /* f32 [3H]                                             */
+  const void* w_o;     /* bf16 [H, H]   attention.output.dense                 */
+  const void* w_o_t;   /* bf16 [H, H]                                          */
+  const float* b_o;
+  const float* ln1_g;  /* attention.output.LayerNorm                           */
+  const float* ln1_b;
+  const void* w_i;     /* bf16 [I, H]   intermediate.dense                     */
+  const void* w_i_t;   /* bf16 [H, I]                                          */
+  const float* b_i;
+  const void* w_out;   /* bf16 [H, I]   output.dense                           */
+  const void* w_out_t; /* bf16 [I, H]                                          */
+  const float* b_out;
+  const float* ln2_g;  /* output.LayerNorm                                     */
+  const float* ln2_b;
+} mvptr_layer_weights;
+
+/* f32 gradient buffers (accumulated into; caller zeroes) */
+typedef struct {
+  float* w_qkv; /* [3H, H] */
+  float* b_qkv;
+  float* w_o;
+  float* b_o;
+  float* ln1_g;
+  float* ln1_b;
+  float* w_i;
+  float* b_i;
+  float* w_out;
+  float* b_out;
+  float* ln2_g;
+  float* ln2_b;
+} mvptr_layer_grads;
+
+/* bytes of the per-layer activation stash (training) and of the scratch workspace */
+int64_t mvptr_layer_saved_bytes(const mvptr_layer_desc* d);
+int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d);
+
+/* x: bf16 [B*L, H] -> y: bf16 [B*L, H].  saved: activation stash of mvptr_layer_saved_bytes()
+ * bytes (kept for backward when training, reusable scratch otherwise); ws is unused by forward. */
+int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                            const void* x, const float* mask_add, void* y, void* saved,
+                            void* ws, int64_t ws_bytes, void* stream);
+
+/* dy: bf16 [B*L,H] -> dx: bf16 [B*L,H]; weight grads accumulated into g.
+ * x is the layer input given to forward (the previous layer's y). */
+int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                            const void* x, const float* mask_add, const void* saved,
+                            const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
+                            int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVPTR_H */

@@ -1,0 +1,402 @@
+// attention.hip — joint text+region self-attention core, forward and backward.
+//
+// Replaces oscar/modeling/modeling_vlbert.py:75-100 (CaptionBertSelfAttention.forward after
+// the Q/K/V projections: transpose_for_scores, QK^T / sqrt(64) + additive mask, softmax,
+// dropout, P·V, head merge) and its autograd backward.
+//
+// CDNA4 design: the sequences on this path are short (<= 70 tokens + <= 50 regions; <= 256
+// supported), so one 256-thread workgroup owns one (batch, head) and keeps the whole Q, K, V
+// (and dO in backward) [L,64] bf16 tiles in LDS (buffer_load ... lds, 128-B rows, one XOR
+// swizzle that is conflict free for both ds_read_b128 row reads and ds_read_b64_tr_b16
+// transposed reads).  All products are v_mfma_f32_32x32x16_bf16.  Scores are computed
+// transposed (S^T = K·Q^T) so a lane owns one query column: the softmax reductions are
+// in-register plus one lane^32 exchange, and the probability accumulator feeds the next MFMA
+// (O^T = V^T·P^T) directly as its B operand with no LDS round trip.  Nothing of size L x L
+// ever reaches HBM; backward recomputes P from Q, K and the saved row log-sum-exp:
+//   pass A (key on lane):   dV^T += dO^T·P,  dK^T += Q^T·dS      (waves own key blocks)
+//   pass B (query on lane): dQ^T += K^T·dS^T                     (waves own query blocks)
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const __bf16* qkv;
+  const float* mask;
+  __bf16* ctx;        // fwd: out ; bwd: forward output (for delta)
+  const __bf16* dctx; // bwd
+  float* lse;         // fwd: out (may be null) ; bwd: in
+  __bf16* dqkv;       // bwd out
+  int B, L, heads, Lp;
+  DropDev drop;
+};
+
+// swizzle of the 8 16-byte chunks of a 128-B tile row
+__device__ __forceinline__ int swz128(int row) {
+  return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+}
+__device__ __forceinline__ uint32_t tile_off(int row, int chunk) {
+  return (uint32_t)(row * 128 + ((chunk ^ swz128(row)) << 4));
+}
+
+// stage an [L,64] bf16 head slice (row stride ld elements) into an Lp-row LDS tile
+__device__ __forceinline__ void stage_tile(char* tile, const __bf16* src, int64_t ld, int L, int Lp,
+                                           int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (uint32_t)(((int64_t)(L - 1) * ld + 64) * 2));
+  const int ninstr = Lp >> 3;  // 8 rows per wave instruction
+  for (int i = wave; i < ninstr; i += 4) {
+    const int row = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz128(row);
+    const uint32_t off = (uint32_t)(row * ld * 2 + c * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + i * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, chunk));
+}
+
+// transposed fragment: element j <- tile[row0 + 8*(j>>2) + (j&3)][col] for this lane's column
+// (col = 32*db + 16*cb + (lane&15)); row0 already includes the lane half's +4*hh.
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int db, int lane) {
+  const int i16 = lane & 15, cb = (lane >> 4) & 1;
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int ch = db * 4 + cb * 2 + (pp >> 1);
+  const uint32_t o0 = tile_off(row0 + q, ch) + 8 * (pp & 1);
+  const uint32_t o1 = tile_off(row0 + 8 + q, ch) + 8 * (pp & 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + o0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + o1));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = f2bf(x[8 * s + j]);
+  return r;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// row index held in accumulator register r by lane half hh (32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// ------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x;
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int L = p.L, Lp = p.Lp, H = p.heads * 64;
+  const int64_t ldq = 3 * (int64_t)H;
+  char* tQ = smem;
+  char* tK = tQ + Lp * 128;
+  char* tV = tK + Lp * 128;
+  float* maskv = reinterpret_cast<float*>(tV + Lp * 128);
+
+  const __bf16* base = p.qkv + (int64_t)b * L * ldq + hd * 64;
+  stage_tile(tQ, base, ldq, L, Lp, wave, lane);
+  stage_tile(tK, base + H, ldq, L, Lp, wave, lane);
+  stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
+  for (int i = tid; i < Lp; i += 256) maskv[i] = (i < L) ? p.mask[(int64_t)b * L + i] : -INFINITY;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int nb = Lp >> 5;
+  for (int qb = wave; qb < nb; qb += 4) {
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_frag(tQ, 32 * qb + l31, 2 * ks + hh);
+    // pass 1: running max / sum of this lane's query column
+    float m_run = -1e30f, l_run = 0.f;
+    for (int kb = 0; kb < nb; ++kb) {
+      f32x16 st = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], st, 0, 0, 0);
+      float bm = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = st[r] * 0.125f + maskv[32 * kb + acc_row(r, hh)];
+        bm = fmaxf(bm, st[r]);
+      }
+      const float m_new = fmaxf(m_run, bm);
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc += __expf(st[r] - m_new);
+      l_run = l_run * __expf(m_run - m_new) + acc;
+      m_run = m_new;
+    }
+    {
+      const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
+      const float mm = fmaxf(m_run, m_o);
+      l_run = l_run * __expf(m_run - mm) + l_o * __expf(m_o - mm);
+      m_run = mm;
+    }
+    const float lse = m_run + __logf(l_run);
+    const int q = 32 * qb + l31;
+    if (p.lse != nullptr && hh == 0 && q < L) p.lse[(int64_t)bh * L + q] = lse;
+
+    // pass 2: P^T = exp(S^T - lse) (dropout), O^T += V^T · P^T
+    f32x16 o[2] = {zero16(), zero16()};
+    for (int kb = 0; kb < nb; ++kb) {
+      f32x16 st = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], st, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kb + acc_row(r, hh);
+        float pv = __expf(st[r] * 0.125f + maskv[key] - lse);
+        if (p.drop.thresh16 != 0)
+          pv = drop_apply(p.drop, ((uint64_t)bh * L + q) * (uint64_t)L + key, pv);
+        st[r] = pv;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = pack8(st, s);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tV, 32 * kb + 16 * s + 4 * hh, db, lane), pb, o[db], 0, 0, 0);
+      }
+    }
+    if (q < L) {
+      __bf16* dst = p.ctx + ((int64_t)b * L + q) * H + hd * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          bf16x4 v = {f2bf(o[db][4 * t4]), f2bf(o[db][4 * t4 + 1]), f2bf(o[db][4 * t4 + 2]), f2bf(o[db][4 * t4 + 3])};
+          *reinterpret_cast<bf16x4*>(dst + 32 * db + 8 * t4 + 4 * hh) = v;
+        }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x;
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int L = p.L, Lp = p.Lp, H = p.heads * 64;
+  const int64_t ldq = 3 * (int64_t)H;
+  char* tQ = smem;
+  char* tK = tQ + Lp * 128;
+  char* tV = tK + Lp * 128;
+  char* tD = tV + Lp * 128;  // dO
+  float* maskv = reinterpret_cast<float*>(tD + Lp * 128);
+  float* lsev = maskv + Lp;
+  float* deltav = lsev + Lp;
+
+  const __bf16* base = p.qkv + (int64_t)b * L * ldq + hd * 64;
+  const __bf16* dob = p.dctx + (int64_t)b * L * H + hd * 64;
+  const __bf16* ob = p.ctx + (int64_t)b * L * H + hd * 64;
+  stage_tile(tQ, base, ldq, L, Lp, wave, lane);
+  stage_tile(tK, base + H, ldq, L, Lp, wave, lane);
+  stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
+  stage_tile(tD, dob, H, L, Lp, wave, lane);
+  for (int i = tid; i < Lp; i += 256) {
+    float mk = -INFINITY, ls = 0.f, dl = 0.f;
+    if (i < L) {
+      mk = p.mask[(int64_t)b * L + i];
+      ls = p.lse[(int64_t)bh * L + i];
+      const bf16x8* a = reinterpret_cast<const bf16x8*>(dob + (int64_t)i * H);
+      const bf16x8* c = reinterpret_cast<const bf16x8*>(ob + (int64_t)i * H);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16x8 x = a[j], y = c[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
+      }
+    }
+    maskv[i] = mk;
+    lsev[i] = ls;
+    deltav[i] = dl;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int nb = Lp >> 5;
+  __bf16* dq_base = p.dqkv + (int64_t)b * L * ldq + hd * 64;
+
+  // ---------------- pass A: waves own key blocks; key on lane, query in registers
+  for (int kb = wave; kb < nb; kb += 4) {
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = row_frag(tK, 32 * kb + l31, 2 * ks + hh);
+      vf[ks] = row_frag(tV, 32 * kb + l31, 2 * ks + hh);
+    }
+    const int key = 32 * kb + l31;
+    const float mk = maskv[key];
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    for (int qb = 0; qb < nb; ++qb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, 32 * qb + l31, 2 * ks + hh), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tD, 32 * qb + l31, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = 32 * qb + acc_row(r, hh);
+        const float pr = __expf(s[r] * 0.125f + mk - lsev[q]);
+        float pd = pr, dpp = dp[r];
+        if (p.drop.thresh16 != 0) {
+          const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
+          pd = keep ? pr * p.drop.scale : 0.f;
+          dpp = keep ? dpp * p.drop.scale : 0.f;
+        }
+        s[r] = pd;                         // dropped-out probabilities (for dV)
+        dp[r] = pr * (dpp - deltav[q]);    // dS
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
+        const int row0 = 32 * qb + 16 * st + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tD, row0, db, lane), pb, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tQ, row0, db, lane), dsb, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (key < L) {
+      __bf16* dK = dq_base + (int64_t)key * ldq + H;
+      __bf16* dV = dq_base + (int64_t)key * ldq + 2 * H;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int d = 32 * db + 8 * t4 + 4 * hh;
+          bf16x4 a = {f2bf(dk[db][4 * t4] * 0.125f), f2bf(dk[db][4 * t4 + 1] * 0.125f),
+                      f2bf(dk[db][4 * t4 + 2] * 0.125f), f2bf(dk[db][4 * t4 + 3] * 0.125f)};
+          bf16x4 c = {f2bf(dv[db][4 * t4]), f2bf(dv[db][4 * t4 + 1]), f2bf(dv[db][4 * t4 + 2]), f2bf(dv[db][4 * t4 + 3])};
+          *reinterpret_cast<bf16x4*>(dK + d) = a;
+          *reinterpret_cast<bf16x4*>(dV + d) = c;
+        }
+    }
+  }
+
+  // ---------------- pass B: waves own query blocks; query on lane, key in registers
+  for (int qb = wave; qb < nb; qb += 4) {
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = row_frag(tQ, 32 * qb + l31, 2 * ks + hh);
+      dof[ks] = row_frag(tD, 32 * qb + l31, 2 * ks + hh);
+    }
+    const int q = 32 * qb + l31;
+    const float ls = lsev[q], dl = deltav[q];
+    f32x16 dq[2] = {zero16(), zero16()};
+    for (int kb = 0; kb < nb; ++kb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, 32 * kb + l31, 2 * ks + hh), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kb + acc_row(r, hh);
+        const float pr = __expf(s[r] * 0.125f + maskv[key] - ls);
+        float dpp = dp[r];
+        if (p.drop.thresh16 != 0) {
+          const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
+          dpp = keep ? dpp * p.drop.scale : 0.f;
+        }
+        s[r] = pr * (dpp - dl);  // dS^T
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 dsb = pack8(s, st);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tK, 32 * kb + 16 * st + 4 * hh, db, lane), dsb, dq[db], 0, 0, 0);
+      }
+    }
+    if (q < L) {
+      __bf16* dQ = dq_base + (int64_t)q * ldq;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          bf16x4 a = {f2bf(dq[db][4 * t4] * 0.125f), f2bf(dq[db][4 * t4 + 1] * 0.125f),
+                      f2bf(dq[db][4 * t4 + 2] * 0.125f), f2bf(dq[db][4 * t4 + 3] * 0.125f)};
+          *reinterpret_cast<bf16x4*>(dQ + 32 * db + 8 * t4 + 4 * hh) = a;
+        }
+    }
+  }
+}
+
+int check_common(const char* who, const void* qkv, int B, int L, int heads) {
+  if (B <= 0 || L <= 0 || heads <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: B, L, heads must be > 0", who);
+  if (L > 256) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: L=%d > 256 not supported", who, L);
+  if ((uintptr_t)qkv & 15) MVPTR_FAIL(MVPTR_BAD_ALIGN, "%s: qkv must be 16-byte aligned", who);
+  return MVPTR_OK;
+}
+
+}  // namespace
+
+extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse,
+                                   int B, int L, int heads, const mvptr_dropout* drop,
+                                   void* stream) {
+  int rc = check_common("attention_fwd", qkv, B, L, heads);
+  if (rc) return rc;
+  if (!mask_add || !ctx) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask/ctx");
+  AttnArgs a{};
+  a.qkv = (const __bf16*)qkv;
+  a.mask = mask_add;
+  a.ctx = (__bf16*)ctx;
+  a.lse = lse;
+  a.B = B;
+  a.L = L;
+  a.heads = heads;
+  a.Lp = (L + 31) & ~31;
+  a.drop = make_dropdev(drop);
+  const size_t lds = (size_t)a.Lp * 128 * 3 + (size_t)a.Lp * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_fwd: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  MVPTR_CHECK_LAUNCH("attention_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
+                                   const void* dctx, const float* lse, void* dqkv, int B, int L,
+                                   int heads, const mvptr_dropout* drop, void* stream) {
+  int rc = check_common("attention_bwd", qkv, B, L, heads);
+  if (rc) return rc;
+  if (!mask_add || !ctx || !dctx || !lse || !dqkv) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL argument");
+  if (((uintptr_t)dctx & 15) || ((uintptr_t)ctx & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "attention_bwd: ctx/dctx must be 16-byte aligned");
+  AttnArgs a{};
+  a.qkv = (const __bf16*)qkv;
+  a.mask = mask_add;
+  a.ctx = (__bf16*)const_cast<void*>(ctx);
+  a.dctx = (const __bf16*)dctx;
+  a.lse = const_cast<float*>(lse);
+  a.dqkv = (__bf16*)dqkv;
+  a.B = B;
+  a.L = L;
+  a.heads = heads;
+  a.Lp = (L + 31) & ~31;
+  a.drop = make_dropdev(drop);
+  const size_t lds = (size_t)a.Lp * 128 * 4 + (size_t)a.Lp * 12;
+  hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_bwd: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  MVPTR_CHECK_LAUNCH("attention_bwd");
+  return MVPTR_OK;
+}

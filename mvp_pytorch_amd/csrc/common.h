@@ -1,0 +1,110 @@
+// common.h — shared device/host helpers for libmvptr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mvptr.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define MVPTR_OOB 0x80000000u  // buffer voffset that is always out of range -> loads return 0
+
+// ---------------------------------------------------------------------------------------------
+// host-side error plumbing
+void mvptr_set_error(const char* fmt, ...);
+#define MVPTR_FAIL(code, ...)      \
+  do {                             \
+    mvptr_set_error(__VA_ARGS__);  \
+    return (code);                 \
+  } while (0)
+#define MVPTR_CHECK_LAUNCH(name)                                              \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess)                                                    \
+      MVPTR_FAIL(MVPTR_HIP_ERROR, "%s: %s", name, hipGetErrorString(e__));    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ uint32_t mvptr_hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// 16 random bits for element index i (see mvptr.h, mvptr_dropout)
+__device__ __forceinline__ uint32_t mvptr_rand16(uint64_t i, uint32_t seed_lo, uint32_t seed_hi) {
+  uint32_t h = mvptr_hash32((uint32_t)(i >> 1) ^ seed_lo);
+  h = mvptr_hash32(h + seed_hi + (uint32_t)(i >> 33));
+  return (i & 1) ? (h >> 16) : (h & 0xffffu);
+}
+struct DropDev {
+  uint32_t seed_lo, seed_hi, thresh16;
+  float scale;  // 65536/(65536-thresh16)
+};
+static inline DropDev make_dropdev(const mvptr_dropout* d) {
+  DropDev r;
+  if (d == nullptr || d->thresh16 == 0) {
+    r.seed_lo = r.seed_hi = r.thresh16 = 0;
+    r.scale = 1.f;
+  } else {
+    r.seed_lo = d->seed_lo;
+    r.seed_hi = d->seed_hi;
+    r.thresh16 = d->thresh16;
+    r.scale = 65536.f / (65536.f - (float)d->thresh16);
+  }
+  return r;
+}
+__device__ __forceinline__ float drop_apply(const DropDev& d, uint64_t idx, float v) {
+  if (d.thresh16 == 0) return v;
+  return (mvptr_rand16(idx, d.seed_lo, d.seed_hi) >= d.thresh16) ? v * d.scale : 0.f;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// buffer resource over [base, base+bytes): out-of-range lanes read 0 / drop stores
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// bijective XCD-aware remap of a 1-D block id (8 XCDs, blocks dealt round-robin):
+// blocks that share an XCD get a contiguous range of logical tile ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,218 @@
+// gemm_tn.hip — dW[N,K] += A[M,N]^T * B[M,K]  (A = dY, B = X; bf16 in, f32 out).
+//
+// Replaces the weight gradient autograd computes for every nn.Linear on the path
+// (addmm backward of modeling_bert.py:348,395,408 and modeling_vlbert.py:71-73 layers).
+//
+// CDNA4 design: the reduction index (token row m) is the ROW of both row-major operands, so
+// the MFMA fragments are fetched with the gfx950 transposed LDS read ds_read_b64_tr_b16 from
+// row-major 64x128 tiles (256-B rows, XOR swizzle that is conflict free for these reads).
+// 128(n) x 128(k) output tile per 256-thread workgroup, 4 waves as 2x2, each 64x64 = 2x2
+// v_mfma_f32_32x32x16_bf16; tiles staged with buffer_load ... lds, double buffered.
+// M is split across blockIdx.y; partial sums are added with f32 atomics whose wave
+// instruction covers two 128-B row segments (one 32x32 accumulator register).
+#include "common.h"
+
+namespace {
+
+constexpr int TN_ = 128, TK_ = 128, TM_ = 64;
+constexpr int TILE_B = TM_ * 256;  // 16 KiB
+
+struct GemmTnArgs {
+  const __bf16* A;
+  const __bf16* B;
+  int64_t lda, ldb;
+  int M, N, K;
+  float* dW;
+  int64_t ldw;
+  int tiles_n, tiles_k;
+  int rows_per_split;
+};
+
+__device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, uint32_t off_lo, uint32_t off_hi) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + off_lo));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + off_hi));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_B];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = p.tiles_n * p.tiles_k;
+  const int t = xcd_remap(blockIdx.x, nt);
+  const int tn = t / p.tiles_k;
+  const int tk = t - tn * p.tiles_k;
+  const int n0 = tn * TN_, k0 = tk * TK_;
+  const int m_begin = blockIdx.y * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int rows = m_end - m_begin;
+  if (rows <= 0) return;
+  const int ncols = min(TN_, p.N - n0);
+  const int kcols = min(TK_, p.K - k0);
+  // partial 16-byte chunks at the N/K edge read the row padding (lda/ldb are multiples of 8)
+  const int ncols8 = (int)min((int64_t)((ncols + 7) & ~7), p.lda - n0);
+  const int kcols8 = (int)min((int64_t)((kcols + 7) & ~7), p.ldb - k0);
+
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(
+      p.A + (int64_t)m_begin * p.lda + n0, (uint32_t)(((int64_t)(rows - 1) * p.lda + ncols8) * 2));
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(
+      p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
+
+  // staging: instruction i of this wave fills LDS rows (i*4+wave)*4 .. +4 (1 KiB)
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ swz256(row);
+    offA[i] = (ch * 8 < ncols) ? (uint32_t)(row * p.lda * 2 + ch * 16) : MVPTR_OOB;
+    offB[i] = (ch * 8 < kcols) ? (uint32_t)(row * p.ldb * 2 + ch * 16) : MVPTR_OOB;
+  }
+  auto stage = [&](int buf, int mrow0) {
+    char* la = lds + buf * 2 * TILE_B;
+    char* lb = la + TILE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)(mrow0 * p.lda * 2);
+      const uint32_t vb = (offB[i] == MVPTR_OOB) ? MVPTR_OOB : offB[i] + (uint32_t)(mrow0 * p.ldb * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 4 + wave) * 1024), 16, va, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 4 + wave) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+
+  const int wn = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int h = g >> 1, cb = g & 1;
+  const int q = i16 >> 2, pp = i16 & 3;
+  // transposed-read byte offsets: [substep s][block b][lo/hi]
+  uint32_t ta[4][2][2], tb[4][2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const int row = 16 * s + 8 * h + 4 * hl + q;
+        const int cha = wn * 8 + b * 4 + 2 * cb + (pp >> 1);
+        const int chb = wk * 8 + b * 4 + 2 * cb + (pp >> 1);
+        ta[s][b][hl] = row * 256 + ((cha ^ swz256(row)) << 4) + 8 * (pp & 1);
+        tb[s][b][hl] = row * 256 + ((chb ^ swz256(row)) << 4) + 8 * (pp & 1);
+      }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (rows + TM_ - 1) / TM_;
+  stage(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nsteps) stage((st + 1) & 1, (st + 1) * TM_);
+    const char* la = lds + (st & 1) * 2 * TILE_B;
+    const char* lb = la + TILE_B;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        af[b] = tr_frag(la, ta[s][b][0], ta[s][b][1]);
+        bfr[b] = tr_frag(lb, tb[s][b][0], tb[s][b][1]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+    }
+  }
+
+  const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int k = k0 + wk * 64 + kb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (n < p.N && k < p.K) atomicAdd(p.dW + (int64_t)n * p.ldw + k, acc[nb][kb][r]);
+      }
+    }
+}
+
+__global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float* out,
+                              int rows_per_block) {
+  // block handles a 64-column strip x rows_per_block rows; 256 threads = 4 row lanes x 64 cols
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + (threadIdx.x >> 6); r < r1; r += 4) s += bf2f(X[(int64_t)r * ldx + c]);
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < N) {
+    s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    atomicAdd(out + c, s);
+  }
+}
+
+}  // namespace
+
+extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,
+                             int K, float* dW, int64_t ldw, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: M,N,K must be > 0");
+  if ((lda & 7) || (ldb & 7))
+    MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: lda, ldb must be multiples of 8");
+  if (lda < N || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: lda/ldb smaller than N/K");
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+    MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: A and B must be 16-byte aligned");
+  GemmTnArgs a;
+  a.A = (const __bf16*)A;
+  a.B = (const __bf16*)B;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.dW = dW;
+  a.ldw = ldw;
+  a.tiles_n = (N + TN_ - 1) / TN_;
+  a.tiles_k = (K + TK_ - 1) / TK_;
+  const int tiles = a.tiles_n * a.tiles_k;
+  int splits = (512 + tiles - 1) / tiles;
+  const int max_splits = (M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (M + splits - 1) / splits;
+  rps = (rps + TM_ - 1) / TM_ * TM_;
+  // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)
+  const int64_t ldmax = lda > ldb ? lda : ldb;
+  while ((int64_t)rps * ldmax * 2 >= (int64_t)0x7fffffff && rps > TM_) rps = (rps / 2 + TM_ - 1) / TM_ * TM_;
+  splits = (M + rps - 1) / rps;
+  a.rows_per_split = rps;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+  MVPTR_CHECK_LAUNCH("gemm_tn");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream) {
+  if (M <= 0 || N <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "colsum: M,N must be > 0");
+  const int rpb = 256;
+  dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, ldx,
+                     M, N, out, rpb);
+  MVPTR_CHECK_LAUNCH("colsum");
+  return MVPTR_OK;
+}

@@ -1,0 +1,163 @@
+// layer.hip — one BERT encoder layer (forward / backward) composed from the kernels of this
+// library on a single HIP stream.
+//
+// Replaces CaptionBertLayer.forward oscar/modeling/modeling_vlbert.py:191-199 =
+//   CaptionBertSelfAttention :63-103 -> BertSelfOutput modeling_bert.py:348-352 ->
+//   BertIntermediate :394-397 -> BertOutput :407-411, and the autograd backward of that chain.
+#include "common.h"
+
+namespace {
+
+inline int64_t al256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Stash {
+  char *qkv, *ctx, *z1, *x1, *u, *a, *z2;
+  float *lse, *mean1, *rstd1, *mean2, *rstd2;
+  int64_t total;
+};
+
+Stash carve(const mvptr_layer_desc* d, void* base) {
+  const int64_t M = (int64_t)d->B * d->L, H = d->H, I = d->I;
+  char* p = (char*)base;
+  int64_t off = 0;
+  Stash s;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += al256(bytes);
+    return r;
+  };
+  s.qkv = take(M * 3 * H * 2);
+  s.ctx = take(M * H * 2);
+  s.z1 = take(M * H * 2);
+  s.x1 = take(M * H * 2);
+  s.u = take(M * I * 2);
+  s.a = take(M * I * 2);
+  s.z2 = take(M * H * 2);
+  s.lse = (float*)take((int64_t)d->B * d->heads * d->L * 4);
+  s.mean1 = (float*)take(M * 4);
+  s.rstd1 = (float*)take(M * 4);
+  s.mean2 = (float*)take(M * 4);
+  s.rstd2 = (float*)take(M * 4);
+  s.total = off;
+  return s;
+}
+
+mvptr_dropout site_drop(const mvptr_layer_desc* d, int site, uint32_t thresh) {
+  mvptr_dropout r;
+  r.seed_lo = (uint32_t)(d->seed & 0xffffffffu) ^ (0x9E3779B9u * (uint32_t)(site + 1));
+  r.seed_hi = (uint32_t)(d->seed >> 32) + 0x85EBCA6Bu * (uint32_t)(site + 1);
+  r.thresh16 = d->training ? thresh : 0;
+  r.pad_ = 0;
+  return r;
+}
+
+int check_desc(const char* who, const mvptr_layer_desc* d) {
+  if (!d) MVPTR_FAIL(MVPTR_BAD_ARG, "%s: desc is NULL", who);
+  if (d->B <= 0 || d->L <= 0 || d->H <= 0 || d->heads <= 0 || d->I <= 0)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: non-positive dimension", who);
+  if (d->H != d->heads * 64) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: head_dim must be 64 (H=%d heads=%d)", who, d->H, d->heads);
+  if ((d->H & 7) || (d->I & 7) || d->H > 1024) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: H,I must be multiples of 8, H <= 1024", who);
+  if (d->L > 256) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: L=%d > 256", who, d->L);
+  return MVPTR_OK;
+}
+
+#define RUN(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+}  // namespace
+
+extern "C" int64_t mvptr_layer_saved_bytes(const mvptr_layer_desc* d) {
+  if (check_desc("layer_saved_bytes", d)) return -1;
+  return carve(d, nullptr).total;
+}
+
+extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
+  if (check_desc("layer_workspace_bytes", d)) return -1;
+  const int64_t M = (int64_t)d->B * d->L, H = d->H;
+  const int64_t W = d->I > 3 * H ? d->I : 3 * H;
+  return 3 * al256(M * H * 2) + al256(M * W * 2);
+}
+
+extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                       const void* x, const float* mask_add, void* y, void* saved,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+  (void)ws;
+  (void)ws_bytes;
+  RUN(check_desc("encoder_layer_fwd", d));
+  if (!w || !x || !mask_add || !y || !saved) MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_fwd: NULL argument");
+  const int M = d->B * d->L, H = d->H, I = d->I;
+  Stash s = carve(d, saved);
+  const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
+  const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
+  const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
+  RUN(mvptr_gemm_nt(x, H, w->w_qkv, H, M, 3 * H, H, MVPTR_EPI_BIAS, w->b_qkv, nullptr, 0, s.qkv,
+                    nullptr, 3 * H, nullptr, nullptr, stream));
+  RUN(mvptr_attention_fwd(s.qkv, mask_add, s.ctx, s.lse, d->B, d->L, d->heads, &dr_attn, stream));
+  RUN(mvptr_gemm_nt(s.ctx, H, w->w_o, H, M, H, H, MVPTR_EPI_BIAS_RESID, w->b_o, x, H, s.z1, nullptr,
+                    H, nullptr, &dr_o, stream));
+  RUN(mvptr_layernorm_fwd(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
+                          nullptr, stream));
+  RUN(mvptr_gemm_nt(s.x1, H, w->w_i, H, M, I, H, MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
+                    nullptr, nullptr, stream));
+  RUN(mvptr_gemm_nt(s.a, I, w->w_out, I, M, H, I, MVPTR_EPI_BIAS_RESID, w->b_out, s.x1, H, s.z2,
+                    nullptr, H, nullptr, &dr_out, stream));
+  RUN(mvptr_layernorm_fwd(s.z2, w->ln2_g, w->ln2_b, d->eps, y, s.mean2, s.rstd2, M, H, M, 0, 0,
+                          nullptr, stream));
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                       const void* x, const float* mask_add, const void* saved,
+                                       const void* dy, void* dx, const mvptr_layer_grads* g,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+  RUN(check_desc("encoder_layer_bwd", d));
+  if (!w || !x || !mask_add || !saved || !dy || !dx || !g || !ws)
+    MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd: NULL argument");
+  if (ws_bytes < mvptr_layer_workspace_bytes(d))
+    MVPTR_FAIL(MVPTR_WORKSPACE_TOO_SMALL, "encoder_layer_bwd: workspace %ld < %ld", (long)ws_bytes,
+               (long)mvptr_layer_workspace_bytes(d));
+  const int M = d->B * d->L, H = d->H, I = d->I;
+  Stash s = carve(d, const_cast<void*>(saved));
+  char* p = (char*)ws;
+  char* bufA = p;
+  char* bufB = bufA + al256((int64_t)M * H * 2);
+  char* bufC = bufB + al256((int64_t)M * H * 2);
+  char* bufU = bufC + al256((int64_t)M * H * 2);
+  const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
+  const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
+  const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
+  const bool hdrop = dr_o.thresh16 != 0;
+
+  // output.LayerNorm / output.dense
+  RUN(mvptr_layernorm_bwd(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
+                          g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
+                          hdrop ? &dr_out : nullptr, stream));
+  const char* d2 = hdrop ? bufB : bufA;
+  if (g->w_out) RUN(mvptr_gemm_tn(d2, H, s.a, I, M, H, I, g->w_out, I, stream));
+  RUN(mvptr_gemm_nt(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
+                    I, g->b_i, nullptr, stream));
+  // intermediate.dense
+  if (g->w_i) RUN(mvptr_gemm_tn(bufU, I, s.x1, H, M, I, H, g->w_i, H, stream));
+  RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
+                    nullptr, nullptr, stream));
+  // attention.output.LayerNorm / dense
+  RUN(mvptr_layernorm_bwd(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufA, hdrop ? bufB : nullptr,
+                          g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
+                          hdrop ? &dr_o : nullptr, stream));
+  const char* d1 = hdrop ? bufB : bufA;
+  if (g->w_o) RUN(mvptr_gemm_tn(d1, H, s.ctx, H, M, H, H, g->w_o, H, stream));
+  RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
+                    nullptr, nullptr, stream));
+  // attention core
+  RUN(mvptr_attention_bwd(s.qkv, mask_add, s.ctx, bufC, s.lse, bufU, d->B, d->L, d->heads, &dr_attn,
+                          stream));
+  // Q/K/V projections
+  if (g->b_qkv) RUN(mvptr_colsum(bufU, 3 * H, M, 3 * H, g->b_qkv, stream));
+  if (g->w_qkv) RUN(mvptr_gemm_tn(bufU, 3 * H, x, H, M, 3 * H, H, g->w_qkv, H, stream));
+  RUN(mvptr_gemm_nt(bufU, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufA, H, dx,
+                    nullptr, H, nullptr, nullptr, stream));
+  return MVPTR_OK;
+}

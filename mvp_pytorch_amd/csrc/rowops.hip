@@ -1,0 +1,497 @@
+// rowops.hip — HBM-bound row kernels of the encoder path: LayerNorm fwd/bwd (+dropout),
+// embedding gather / scatter, f32<->bf16 cast+pack(+transpose), cross-entropy fwd/bwd.
+//
+// Reference op sequences replaced (file:line relative to the reference tree):
+//   BertLayerNorm.forward            transformers/pytorch_transformers/modeling_bert.py:242-246
+//   BertEmbeddings.forward           modeling_bert.py:262-277
+//   CrossEntropyLoss(ignore_index=-1) oscar/modeling/modeling_vlbert.py:1228-1251
+//   nn.Dropout after LayerNorm / dense modeling_bert.py:276,350,409; modeling_vlbert.py:503
+// All are memory-bound: one 64-lane wave per row, 16-byte vector accesses, f32 statistics.
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+constexpr int LN_MAXC = 2;  // 16-byte chunks per lane -> H <= 64*8*2 = 1024
+
+__device__ __forceinline__ int remap_row(int r, int rpg, int gstride, int roff) {
+  return (r / rpg) * gstride + roff + (r % rpg);
+}
+
+// ------------------------------------------------------------------------------ LayerNorm fwd
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const float* gamma,
+                                                      const float* beta, float eps, __bf16* y,
+                                                      float* mean, float* rstd, int M, int H,
+                                                      int rpg, int gstride, int roff, DropDev drop) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const int nch = H >> 3;
+  float v[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(z + (int64_t)r * H + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[c][e] = bf2f(x[e]);
+        s += v[c][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c)
+    if (lane + 64 * c < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[c][e] - mu;
+        q += d * d;
+      }
+  const float var = wave_sum(q) / (float)H;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean) mean[r] = mu;
+    if (rstd) rstd[r] = rs;
+  }
+  const int64_t orow = remap_row(r, rpg, gstride, roff);
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = ch * 8 + e;
+        float t = (v[c][e] - mu) * rs * gamma[col] + beta[col];
+        t = drop_apply(drop, (uint64_t)r * (uint64_t)H + col, t);
+        o[e] = f2bf(t);
+      }
+      *reinterpret_cast<bf16x8*>(y + orow * H + ch * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm bwd
+// grid-stride over rows; per-lane column partial sums are reduced across the 4 waves through
+// LDS and added with one atomic per column per block.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __bf16* z,
+                                                       const float* mean, const float* rstd,
+                                                       const float* gamma, __bf16* dz, __bf16* dd,
+                                                       float* dgamma, float* dbeta, float* dbias,
+                                                       int M, int H, int rpg, int gstride, int roff,
+                                                       DropDev ydrop, DropDev ddrop) {
+  __shared__ float red[3][3][1024];  // waves 1..3 publish, wave 0 sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float ag[LN_MAXC][8], ab[LN_MAXC][8], abias[LN_MAXC][8], gm[LN_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ag[c][e] = ab[c][e] = abias[c][e] = 0.f;
+      const int col = (lane + 64 * c) * 8 + e;
+      gm[c][e] = (col < H) ? gamma[col] : 0.f;
+    }
+  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    const float mu = mean[r], rs = rstd[r];
+    const int64_t irow = remap_row(r, rpg, gstride, roff);
+    float xh[LN_MAXC][8], g[LN_MAXC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dy + irow * H + ch * 8);
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(z + (int64_t)r * H + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float d = bf2f(a[e]);
+          d = drop_apply(ydrop, (uint64_t)r * (uint64_t)H + ch * 8 + e, d);
+          xh[c][e] = (bf2f(x[e]) - mu) * rs;
+          g[c][e] = d * gm[c][e];
+          s1 += g[c][e];
+          s2 += g[c][e] * xh[c][e];
+          ag[c][e] += d * xh[c][e];
+          ab[c][e] += d;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[c][e] = g[c][e] = 0.f;
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)H;
+    const float c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        bf16x8 o, od;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = rs * (g[c][e] - c1 - xh[c][e] * c2);
+          o[e] = f2bf(t);
+          const float td = drop_apply(ddrop, (uint64_t)r * (uint64_t)H + ch * 8 + e, t);
+          od[e] = f2bf(td);
+          abias[c][e] += td;
+        }
+        *reinterpret_cast<bf16x8*>(dz + (int64_t)r * H + ch * 8) = o;
+        if (dd != nullptr) *reinterpret_cast<bf16x8*>(dd + (int64_t)r * H + ch * 8) = od;
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = (lane + 64 * c) * 8 + e;
+        red[0][wave - 1][col] = ag[c][e];
+        red[1][wave - 1][col] = ab[c][e];
+        red[2][wave - 1][col] = abias[c][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = (lane + 64 * c) * 8 + e;
+        if (col < H) {
+          const float a = ag[c][e] + red[0][0][col] + red[0][1][col] + red[0][2][col];
+          const float b = ab[c][e] + red[1][0][col] + red[1][1][col] + red[1][2][col];
+          const float d = abias[c][e] + red[2][0][col] + red[2][1][col] + red[2][2][col];
+          if (dgamma) atomicAdd(dgamma + col, a);
+          if (dbeta) atomicAdd(dbeta + col, b);
+          if (dbias) atomicAdd(dbias + col, d);
+        }
+      }
+  }
+}
+
+// --------------------------------------------------------------------------------- embeddings
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, const int64_t* pids,
+                                                         const int64_t* tids, const float* word,
+                                                         const float* pos, const float* type,
+                                                         __bf16* z, int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* w = word + ids[r] * (int64_t)H;
+  const float* p = pos + pids[r] * (int64_t)H;
+  const float* t = type + tids[r] * (int64_t)H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(t + c);
+    bf16x4 o = {f2bf(a[0] + b[0] + d[0]), f2bf(a[1] + b[1] + d[1]), f2bf(a[2] + b[2] + d[2]),
+                f2bf(a[3] + b[3] + d[3])};
+    *reinterpret_cast<bf16x4*>(z + (int64_t)r * H + c) = o;
+  }
+}
+
+// word (padding_idx 0 skipped, as nn.Embedding(padding_idx=0) does) and position tables
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, const int64_t* pids,
+                                                         const __bf16* dz, float* dword,
+                                                         float* dpos, int rows, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t id = ids[r];
+  float* w = dword + id * (int64_t)H;
+  float* p = dpos + pids[r] * (int64_t)H;
+  for (int c = lane; c < H; c += 64) {
+    const float g = bf2f(dz[(int64_t)r * H + c]);
+    if (id != 0) atomicAdd(w + c, g);
+    atomicAdd(p + c, g);
+  }
+}
+
+// token-type table (2 rows): per-block partial sums, then one atomic per (type, column, block)
+__global__ __launch_bounds__(256) void embed_type_bwd_kernel(const int64_t* tids, const __bf16* dz,
+                                                              float* dtype, int rows, int H,
+                                                              int rows_per_block, int ntype) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  __shared__ float red[4][4][64];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < H)
+    for (int r = r0 + sub; r < r1; r += 4) {
+      const int t = (int)tids[r];
+      const float g = bf2f(dz[(int64_t)r * H + c]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += (t == k) ? g : 0.f;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[sub][k][threadIdx.x & 63] = acc[k];
+  __syncthreads();
+  if (sub == 0 && c < H)
+    for (int k = 0; k < ntype && k < 4; ++k) {
+      const float s = red[0][k][threadIdx.x] + red[1][k][threadIdx.x] + red[2][k][threadIdx.x] + red[3][k][threadIdx.x];
+      if (s != 0.f) atomicAdd(dtype + (int64_t)k * H + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------- casts
+__global__ __launch_bounds__(256) void cast_pack_kernel(const float* src, int64_t ld_src, int rows,
+                                                         int cols, __bf16* dst, int64_t ld_dst,
+                                                         __bf16* dst_t, int64_t ld_dst_t,
+                                                         int col_off_t) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) v = src[(int64_t)r * ld_src + c];
+    tile[ty + 8 * k][tx] = v;
+    if (dst != nullptr && r < rows && c < ld_dst) dst[(int64_t)r * ld_dst + c] = f2bf(v);
+  }
+  if (dst_t == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;  // transposed: row index of dst_t is c
+    if (c < cols && r < rows) dst_t[(int64_t)c * ld_dst_t + col_off_t + r] = f2bf(tile[tx][ty + 8 * k]);
+  }
+}
+
+__global__ void cast_f32_kernel(const __bf16* src, int64_t ld_src, int rows, int cols, float* dst,
+                                int64_t ld_dst) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i - r * cols;
+    dst[r * ld_dst + c] = bf2f(src[r * ld_src + c]);
+  }
+}
+
+__global__ void dropout_mask_kernel(DropDev d, int64_t n, uint8_t* keep) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    keep[i] = (d.thresh16 == 0 || mvptr_rand16((uint64_t)i, d.seed_lo, d.seed_hi) >= d.thresh16) ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------- cross entropy
+__device__ __forceinline__ void block_max_sum(float& m, float& s, float* sm) {
+  // combine (max, sum-of-exp) pairs over a 256-thread block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+    const float mm = fmaxf(m, m2);
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sm[wave] = m;
+    sm[4 + wave] = s;
+  }
+  __syncthreads();
+  float mm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  float ss = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) ss += sm[4 + w] * __expf(sm[w] - mm);
+  m = mm;
+  s = ss;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, int64_t ld,
+                                                      const int64_t* labels, float* loss_row,
+                                                      float* lse_row, int M, int V) {
+  __shared__ float sm[8];
+  const int r = blockIdx.x;
+  const float* x = logits + (int64_t)r * ld;
+  float m = -1e30f, s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const float v = x[c];
+    const float mm = fmaxf(m, v);
+    s = s * __expf(m - mm) + __expf(v - mm);
+    m = mm;
+  }
+  block_max_sum(m, s, sm);
+  if (threadIdx.x == 0) {
+    const float lse = m + logf(s);
+    lse_row[r] = lse;
+    const int64_t lab = labels[r];
+    loss_row[r] = (lab >= 0 && lab < V) ? (lse - x[lab]) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int64_t ld,
+                                                      const int64_t* labels, const float* lse_row,
+                                                      const float* scale, __bf16* dlogits,
+                                                      int64_t ld_d, int M, int V, int Vpad) {
+  const int r = blockIdx.x;
+  const float* x = logits + (int64_t)r * ld;
+  __bf16* d = dlogits + (int64_t)r * ld_d;
+  const int64_t lab = labels[r];
+  const bool valid = lab >= 0 && lab < V;
+  const float sc = valid ? scale[0] : 0.f;
+  const float lse = lse_row[r];
+  for (int c = threadIdx.x; c < Vpad; c += 256) {
+    float g = 0.f;
+    if (c < V && valid) g = (__expf(x[c] - lse) - ((int64_t)c == lab ? 1.f : 0.f)) * sc;
+    d[c] = f2bf(g);
+  }
+}
+
+thread_local char g_err[512] = {0};
+
+}  // namespace
+
+void mvptr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mvptr_last_error(void) { return g_err; }
+
+extern "C" int mvptr_query(int what, int64_t* out) {
+  if (!out) MVPTR_FAIL(MVPTR_BAD_ARG, "query: out is NULL");
+  if (what == MVPTR_Q_ABI_VERSION) {
+    *out = MVPTR_ABI_VERSION;
+    return MVPTR_OK;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    MVPTR_FAIL(MVPTR_HIP_ERROR, "query: no HIP device");
+  if (what == MVPTR_Q_ARCH_OK) {
+    *out = (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+    return MVPTR_OK;
+  }
+  if (what == MVPTR_Q_NUM_CU) {
+    *out = prop.multiProcessorCount;
+    return MVPTR_OK;
+  }
+  MVPTR_FAIL(MVPTR_BAD_ARG, "query: unknown code %d", what);
+}
+
+extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const float* beta, float eps,
+                                   void* y, float* mean, float* rstd, int M, int H,
+                                   int rows_per_group, int group_stride, int row_offset,
+                                   const mvptr_dropout* drop, void* stream) {
+  if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: M must be > 0");
+  if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: H=%d must be a multiple of 8, <= 1024", H);
+  if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_fwd: rows_per_group must be > 0");
+  if (((uintptr_t)z & 15) || ((uintptr_t)y & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "layernorm_fwd: z,y must be 16-byte aligned");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)z, gamma, beta, eps, (__bf16*)y, mean, rstd, M, H,
+                     rows_per_group, group_stride, row_offset, make_dropdev(drop));
+  MVPTR_CHECK_LAUNCH("layernorm_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* mean,
+                                   const float* rstd, const float* gamma, void* dz, void* dd,
+                                   float* dgamma, float* dbeta, float* dbias, int M, int H,
+                                   int rows_per_group, int group_stride, int row_offset,
+                                   const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop,
+                                   void* stream) {
+  if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: M must be > 0");
+  if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: H=%d must be a multiple of 8, <= 1024", H);
+  if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: rows_per_group must be > 0");
+  if (!dy || !z || !mean || !rstd || !gamma || !dz) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: NULL argument");
+  int grid = (M + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,
+                     (__bf16*)dd, dgamma, dbeta, dbias, M, H, rows_per_group, group_stride,
+                     row_offset, make_dropdev(y_drop), make_dropdev(dense_drop));
+  MVPTR_CHECK_LAUNCH("layernorm_bwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                               const float* word, const float* pos, const float* type, void* z,
+                               int rows, int H, int64_t vocab, int64_t npos, int64_t ntype,
+                               void* stream) {
+  if (rows <= 0 || (H & 3)) MVPTR_FAIL(MVPTR_BAD_SHAPE, "embed_fwd: rows > 0 and H %% 4 == 0 required");
+  if (!ids || !pos_ids || !type_ids) MVPTR_FAIL(MVPTR_BAD_ARG, "embed_fwd: ids/pos_ids/type_ids must be given");
+  (void)vocab;
+  (void)npos;
+  (void)ntype;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids,
+                     pos_ids, type_ids, word, pos, type, (__bf16*)z, rows, H);
+  MVPTR_CHECK_LAUNCH("embed_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_embed_bwd(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                               const void* dz, float* dword, float* dpos, float* dtype, int rows,
+                               int H, void* stream) {
+  if (rows <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "embed_bwd: rows must be > 0");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids,
+                     pos_ids, (const __bf16*)dz, dword, dpos, rows, H);
+  MVPTR_CHECK_LAUNCH("embed_bwd");
+  const int rpb = 512;
+  hipLaunchKernelGGL(embed_type_bwd_kernel, dim3((H + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0,
+                     (hipStream_t)stream, type_ids, (const __bf16*)dz, dtype, rows, H, rpb, 4);
+  MVPTR_CHECK_LAUNCH("embed_type_bwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_cast_pack(const float* src, int64_t ld_src, int rows, int cols, void* dst,
+                               int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int col_off_t,
+                               void* stream) {
+  if (rows <= 0 || cols <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "cast_pack: rows, cols must be > 0");
+  if (dst && ld_dst < cols) MVPTR_FAIL(MVPTR_BAD_SHAPE, "cast_pack: ld_dst < cols");
+  const int64_t wcols = (dst && ld_dst > cols) ? ld_dst : cols;
+  dim3 grid((unsigned)((wcols + 31) / 32), (rows + 31) / 32);
+  hipLaunchKernelGGL(cast_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, rows,
+                     cols, (__bf16*)dst, ld_dst, (__bf16*)dst_t, ld_dst_t, col_off_t);
+  MVPTR_CHECK_LAUNCH("cast_pack");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_cast_f32(const void* src, int64_t ld_src, int rows, int cols, float* dst,
+                              int64_t ld_dst, void* stream) {
+  if (rows <= 0 || cols <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "cast_f32: rows, cols must be > 0");
+  const int64_t n = (int64_t)rows * cols;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)src, ld_src, rows, cols, dst, ld_dst);
+  MVPTR_CHECK_LAUNCH("cast_f32");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_dropout_mask(const mvptr_dropout* drop, int64_t n, uint8_t* keep, void* stream) {
+  if (n <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "dropout_mask: n must be > 0");
+  int grid = (int)((n + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     make_dropdev(drop), n, keep);
+  MVPTR_CHECK_LAUNCH("dropout_mask");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_ce_fwd(const float* logits, int64_t ld, const int64_t* labels, float* loss_row,
+                            float* lse_row, int M, int V, void* stream) {
+  if (M <= 0 || V <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "ce_fwd: M, V must be > 0");
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels,
+                     loss_row, lse_row, M, V);
+  MVPTR_CHECK_LAUNCH("ce_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_ce_bwd(const float* logits, int64_t ld, const int64_t* labels,
+                            const float* lse_row, const float* scale, void* dlogits, int64_t ld_d,
+                            int M, int V, int Vpad, void* stream) {
+  if (M <= 0 || V <= 0 || Vpad < V || ld_d < Vpad) MVPTR_FAIL(MVPTR_BAD_SHAPE, "ce_bwd: bad shape");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ld, labels,
+                     lse_row, scale, (__bf16*)dlogits, ld_d, M, V, Vpad);
+  MVPTR_CHECK_LAUNCH("ce_bwd");
+  return MVPTR_OK;
+}

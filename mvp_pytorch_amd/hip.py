@@ -1,0 +1,253 @@
+"""ctypes binding of libmvptr_hip.so (the C ABI declared in include/mvptr.h).
+
+PyTorch is used here only for device memory and streams: every wrapper takes torch tensors,
+passes raw device pointers + the current HIP stream, and raises ``RuntimeError`` with
+``mvptr_last_error()`` on failure (the reference raises ValueError/RuntimeError from the same
+places, e.g. oscar/modeling/modeling_vlbert.py:435,542).  There is no CPU fallback: importing
+works without a GPU (so host logic is testable), calling a kernel without the library or a
+device fails loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint32, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip.so")
+
+# epilogue codes (mvptr_epilogue)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIAS_TANH = range(7)
+
+# every symbol include/mvptr.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_colsum",
+    "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
+    "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
+    "mvptr_ce_bwd", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
+    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
+]
+
+
+class Dropout(Structure):
+    _fields_ = [("seed_lo", c_uint32), ("seed_hi", c_uint32), ("thresh16", c_uint32), ("pad_", c_uint32)]
+
+
+class LayerDesc(Structure):
+    _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("heads", c_int), ("I", c_int),
+                ("eps", c_float), ("training", c_int), ("p_hidden16", c_uint32),
+                ("p_attn16", c_uint32), ("seed", c_uint64)]
+
+
+class LayerWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "w_qkv_t", "b_qkv", "w_o", "w_o_t", "b_o", "ln1_g", "ln1_b", "w_i", "w_i_t", "b_i",
+        "w_out", "w_out_t", "b_out", "ln2_g", "ln2_b")]
+
+
+class LayerGrads(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "b_qkv", "w_o", "b_o", "ln1_g", "ln1_b", "w_i", "b_i", "w_out", "b_out", "ln2_g",
+        "ln2_b")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmvptr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mvp_pytorch_amd/csrc` (expected at %s)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mvptr_last_error.restype = c_char_p
+    lib.mvptr_layer_saved_bytes.restype = c_int64
+    lib.mvptr_layer_workspace_bytes.restype = c_int64
+    lib.mvptr_layer_saved_bytes.argtypes = [POINTER(LayerDesc)]
+    lib.mvptr_layer_workspace_bytes.argtypes = [POINTER(LayerDesc)]
+    P, I64, I, F = c_void_p, c_int64, c_int, c_float
+    lib.mvptr_query.argtypes = [I, POINTER(c_int64)]
+    lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
+    lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P]
+    lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
+    lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_layernorm_fwd.argtypes = [P, P, P, F, P, P, P, I, I, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_layernorm_bwd.argtypes = [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, POINTER(Dropout), POINTER(Dropout), P]
+    lib.mvptr_embed_fwd.argtypes = [P, P, P, P, P, P, P, I, I, I64, I64, I64, P]
+    lib.mvptr_embed_bwd.argtypes = [P, P, P, P, P, P, P, I, I, P]
+    lib.mvptr_cast_pack.argtypes = [P, I64, I, I, P, I64, P, I64, I, P]
+    lib.mvptr_cast_f32.argtypes = [P, I64, I, I, P, I64, P]
+    lib.mvptr_ce_fwd.argtypes = [P, I64, P, P, P, I, I, P]
+    lib.mvptr_ce_bwd.argtypes = [P, I64, P, P, P, P, I64, I, I, I, P]
+    lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
+    lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
+    lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("mvptr error %d: %s" % (rc, load().mvptr_last_error().decode()))
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mvp_pytorch_amd: tensor is not on a HIP device — the encoder path has no CPU fallback")
+    return c_void_p(t.data_ptr())
+
+
+def make_dropout(p, seed):
+    """Dropout descriptor for probability p and a 64-bit seed (None when p == 0)."""
+    t = int(round(float(p) * 65536.0))
+    if t <= 0:
+        return None
+    if t >= 65536:
+        raise ValueError("dropout p must be < 1")
+    return Dropout(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, t, 0)
+
+
+def _dp(d):
+    return ctypes.byref(d) if d is not None else None
+
+
+def query(what):
+    out = c_int64(0)
+    _check(load().mvptr_query(what, ctypes.byref(out)))
+    return out.value
+
+
+# ------------------------------------------------------------------------------------------ ops
+def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, vec_out=None,
+            drop=None, n=None):
+    """out[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue.  a, b: bf16 2-D (row stride arbitrary)."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16)
+    if epilogue == EPI_BIAS_GELU and out1 is None:
+        out1 = torch.empty_like(out)
+    assert out.stride(1) == 1
+    _check(load().mvptr_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, epilogue, _p(bias),
+                                _p(aux), aux.stride(0) if aux is not None else 0, _p(out), _p(out1),
+                                out.stride(0), _p(vec_out), _dp(drop), _stream()))
+    return (out, out1) if epilogue == EPI_BIAS_GELU else out
+
+
+def gemm_tn(dy, x, dw, n=None, k=None):
+    """dw[N,K] += dy[M,N]^T @ x[M,K]  (f32 accumulate into dw)."""
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    M = dy.shape[0]
+    N = dy.shape[1] if n is None else n
+    K = x.shape[1] if k is None else k
+    assert x.shape[0] == M and dw.stride(1) == 1
+    _check(load().mvptr_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), M, N, K, _p(dw), dw.stride(0), _stream()))
+    return dw
+
+
+def colsum(x, out, n=None):
+    _check(load().mvptr_colsum(_p(x), x.stride(0), x.shape[0], x.shape[1] if n is None else n, _p(out), _stream()))
+    return out
+
+
+def attention_fwd(qkv, mask_add, B, L, heads, drop=None, need_lse=True):
+    H = heads * 64
+    ctx = torch.empty((B * L, H), device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty((B, heads, L), device=qkv.device, dtype=torch.float32) if need_lse else None
+    _check(load().mvptr_attention_fwd(_p(qkv), _p(mask_add), _p(ctx), _p(lse), B, L, heads, _dp(drop), _stream()))
+    return ctx, lse
+
+
+def attention_bwd(qkv, mask_add, ctx, dctx, lse, B, L, heads, drop=None):
+    dqkv = torch.empty_like(qkv)
+    _check(load().mvptr_attention_bwd(_p(qkv), _p(mask_add), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, L, heads, _dp(drop), _stream()))
+    return dqkv
+
+
+def layernorm_fwd(z, gamma, beta, eps, out=None, rows_per_group=None, group_stride=0, row_offset=0,
+                  drop=None, save_stats=True):
+    M, H = z.shape
+    if out is None:
+        out = torch.empty_like(z)
+    mean = torch.empty(M, device=z.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=z.device, dtype=torch.float32) if save_stats else None
+    _check(load().mvptr_layernorm_fwd(_p(z), _p(gamma), _p(beta), float(eps), _p(out), _p(mean), _p(rstd),
+                                      M, H, rows_per_group or M, group_stride, row_offset, _dp(drop), _stream()))
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, rows_per_group=None,
+                  group_stride=0, row_offset=0, y_drop=None, dense_drop=None):
+    M, H = z.shape
+    dz = torch.empty_like(z)
+    dd = torch.empty_like(z) if dense_drop is not None else None
+    _check(load().mvptr_layernorm_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dd),
+                                      _p(dgamma), _p(dbeta), _p(dbias), M, H, rows_per_group or M,
+                                      group_stride, row_offset, _dp(y_drop), _dp(dense_drop), _stream()))
+    return dz, dd
+
+
+def embed_fwd(ids, pos_ids, type_ids, word, pos, typ):
+    rows = ids.numel()
+    H = word.shape[1]
+    z = torch.empty((rows, H), device=word.device, dtype=torch.bfloat16)
+    _check(load().mvptr_embed_fwd(_p(ids), _p(pos_ids), _p(type_ids), _p(word), _p(pos), _p(typ), _p(z),
+                                  rows, H, word.shape[0], pos.shape[0], typ.shape[0], _stream()))
+    return z
+
+
+def embed_bwd(ids, pos_ids, type_ids, dz, dword, dpos, dtype_):
+    rows, H = dz.shape
+    _check(load().mvptr_embed_bwd(_p(ids), _p(pos_ids), _p(type_ids), _p(dz), _p(dword), _p(dpos), _p(dtype_), rows, H, _stream()))
+
+
+def cast_pack(src, dst=None, dst_t=None, col_off_t=0):
+    """f32 [rows, cols] -> bf16 dst [rows, ld>=cols] (zero padded) and/or transposed dst_t."""
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    _check(load().mvptr_cast_pack(_p(src), src.stride(0), rows, cols, _p(dst), dst.stride(0) if dst is not None else 0,
+                                  _p(dst_t), dst_t.stride(0) if dst_t is not None else 0, col_off_t, _stream()))
+
+
+def cast_f32(src, rows=None, cols=None):
+    rows = src.shape[0] if rows is None else rows
+    cols = src.shape[1] if cols is None else cols
+    dst = torch.empty((rows, cols), device=src.device, dtype=torch.float32)
+    _check(load().mvptr_cast_f32(_p(src), src.stride(0), rows, cols, _p(dst), cols, _stream()))
+    return dst
+
+
+def ce_fwd(logits, labels, V=None):
+    M = logits.shape[0]
+    V = logits.shape[1] if V is None else V
+    loss = torch.empty(M, device=logits.device, dtype=torch.float32)
+    lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    _check(load().mvptr_ce_fwd(_p(logits), logits.stride(0), _p(labels), _p(loss), _p(lse), M, V, _stream()))
+    return loss, lse
+
+
+def ce_bwd(logits, labels, lse, scale, V, Vpad):
+    M = logits.shape[0]
+    d = torch.empty((M, Vpad), device=logits.device, dtype=torch.bfloat16)
+    _check(load().mvptr_ce_bwd(_p(logits), logits.stride(0), _p(labels), _p(lse), _p(scale), _p(d), Vpad, M, V, Vpad, _stream()))
+    return d
+
+
+def dropout_mask(drop, n, device):
+    keep = torch.empty(n, device=device, dtype=torch.uint8)
+    _check(load().mvptr_dropout_mask(_dp(drop), n, _p(keep), _stream()))
+    return keep

@@ -1,0 +1,286 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 on the same
+bf16-rounded inputs.  Tolerances are for bf16 outputs with f32 accumulation."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.float()
+    b = b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (200, 2304, 768), (160, 768, 3072), (37, 100, 64), (130, 3129, 768), (500, 768, 2056)])
+def test_gemm_nt_bias(dev, M, N, K):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(1)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
+    ref = a.float() @ b.float().t() + bias
+    err = _rel(out, ref)
+    print("gemm_nt bias", M, N, K, err)
+    assert err < 4e-3
+    out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
+    assert _rel(out32, ref) < 1e-5
+
+
+def test_gemm_nt_identity_layout(dev):
+    """A = I against an asymmetric B catches transposed / permuted fragment maps exactly."""
+    from mvp_pytorch_amd import hip
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    b = (torch.arange(192 * K, device=dev, dtype=torch.float32).reshape(192, K) % 251 - 125).to(torch.bfloat16)
+    out = hip.gemm_nt(a, b, hip.EPI_F32)
+    assert torch.equal(out, b.float().t().contiguous())
+
+
+def test_gemm_nt_epilogues(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(2)
+    M, N, K = 300, 768, 256
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = _bf(torch.randn(M, N, generator=g)).to(dev)
+    base = a.float() @ b.float().t()
+    u, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+    assert _rel(u, base + bias) < 4e-3
+    assert _rel(act, torch.nn.functional.gelu(u.float())) < 4e-3
+    z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux)
+    assert _rel(z, base + bias + aux.float()) < 4e-3
+    t = hip.gemm_nt(a, b, hip.EPI_BIAS_TANH, bias=bias)
+    assert _rel(t, torch.tanh(base + bias)) < 4e-3
+    ad = hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux)
+    assert _rel(ad, base + aux.float()) < 4e-3
+    ad0 = hip.gemm_nt(a, b, hip.EPI_ADD)
+    assert _rel(ad0, base) < 4e-3
+    # gelu backward epilogue: out = acc * gelu'(aux), colsum
+    vec = torch.zeros(N, device=dev)
+    du = hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=aux, vec_out=vec)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(base)
+    assert _rel(du, x.grad) < 4e-3
+    assert _rel(vec, du.float().sum(0)) < 1e-3
+
+
+def test_gemm_nt_dropout_matches_mask(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 128, 256, 64
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g)).to(dev)
+    aux = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    drop = hip.make_dropout(0.1, 0x1234567890)
+    z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, aux=aux, drop=drop)
+    keep = hip.dropout_mask(drop, M * N, dev).reshape(M, N).float()
+    scale = 65536.0 / (65536.0 - drop.thresh16)
+    ref = (a.float() @ b.float().t()) * keep * scale
+    assert _rel(z, ref) < 4e-3
+    frac = 1.0 - keep.mean().item()
+    assert abs(frac - 0.1) < 0.01
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 256, 3072), (333, 2304, 768), (64, 128, 128), (515, 1000, 136)])
+def test_gemm_tn(dev, M, N, K):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(4)
+    ldn = (N + 7) // 8 * 8
+    dy = torch.zeros(M, ldn, dtype=torch.bfloat16)
+    dy[:, :N] = _bf(torch.randn(M, N, generator=g))
+    dy = dy.to(dev)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    dw = torch.zeros(N, K, device=dev)
+    hip.gemm_tn(dy, x, dw, n=N)
+    ref = dy[:, :N].float().t() @ x.float()
+    err = _rel(dw, ref)
+    print("gemm_tn", M, N, K, err)
+    assert err < 1e-5
+    hip.gemm_tn(dy, x, dw, n=N)  # accumulates
+    assert _rel(dw, 2 * ref) < 1e-5
+
+
+def test_gemm_tn_layout_exact(dev):
+    from mvp_pytorch_amd import hip
+    M, N, K = 64, 128, 128
+    dy = torch.zeros(M, N)
+    dy[torch.arange(M), torch.arange(M)] = 1.0  # dy[m, n=m] = 1 -> dW[n] = x[n] for n < M
+    x = (torch.arange(M * K).reshape(M, K) % 251 - 125).float()
+    dw = torch.zeros(N, K, device=dev)
+    hip.gemm_tn(_bf(dy).to(dev), _bf(x).to(dev), dw)
+    ref = torch.zeros(N, K)
+    ref[:M] = x
+    assert torch.equal(dw.cpu(), ref)
+
+
+def _attn_ref(qkv, mask, B, L, heads, keep=None, scale=1.0):
+    H = heads * 64
+    q, k, v = qkv.float().reshape(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / 8.0 + mask[:, None, None, :]
+    p = torch.softmax(s, -1)
+    if keep is not None:
+        p = p * keep * scale
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    return ctx, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 45, 2), (2, 125, 12), (2, 70, 12), (1, 193, 4), (2, 256, 2), (2, 5, 1)])
+def test_attention_fwd_bwd(dev, B, L, heads):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(5)
+    H = heads * 64
+    qkv = _bf(torch.randn(B * L, 3 * H, generator=g)).to(dev)
+    mask = torch.zeros(B, L)
+    for b in range(B):
+        nvalid = max(1, L - 3 * b - (L // 4) * (b % 2))
+        mask[b, nvalid:] = -10000.0
+    mask = mask.to(dev)
+    ctx, lse = hip.attention_fwd(qkv, mask, B, L, heads)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qr, mask, B, L, heads)
+    e1 = _rel(ctx, ref)
+    e2 = (lse - lse_ref).abs().max().item()
+    print("attn fwd", B, L, heads, e1, e2)
+    assert e1 < 6e-3 and e2 < 2e-3
+    dctx = _bf(torch.randn(B * L, H, generator=g)).to(dev)
+    ref.backward(dctx.float())
+    dqkv = hip.attention_bwd(qkv, mask, ctx, dctx, lse, B, L, heads)
+    d = dqkv.float().reshape(B * L, 3, H)
+    r = qr.grad.reshape(B * L, 3, H)
+    errs = [_rel(d[:, i], r[:, i]) for i in range(3)]
+    print("attn bwd dq,dk,dv", errs)
+    assert max(errs) < 1.5e-2
+
+
+def test_attention_dropout(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(6)
+    B, L, heads = 2, 75, 2
+    H = heads * 64
+    qkv = _bf(torch.randn(B * L, 3 * H, generator=g)).to(dev)
+    mask = torch.zeros(B, L, device=dev)
+    drop = hip.make_dropout(0.1, 987654321)
+    keep = hip.dropout_mask(drop, B * heads * L * L, dev).reshape(B, heads, L, L).float()
+    scale = 65536.0 / (65536.0 - drop.thresh16)
+    ctx, lse = hip.attention_fwd(qkv, mask, B, L, heads, drop=drop)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref, _ = _attn_ref(qr, mask, B, L, heads, keep, scale)
+    assert _rel(ctx, ref) < 6e-3
+    dctx = _bf(torch.randn(B * L, H, generator=g)).to(dev)
+    ref.backward(dctx.float())
+    dqkv = hip.attention_bwd(qkv, mask, ctx, dctx, lse, B, L, heads, drop=drop)
+    assert _rel(dqkv, qr.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,H", [(1000, 768), (77, 128), (5, 1024)])
+def test_layernorm(dev, M, H):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(7)
+    z = _bf(torch.randn(M, H, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    y, mean, rstd = hip.layernorm_fwd(z, gamma, beta, 1e-12)
+    zr = z.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(zr, (H,), gr, br, 1e-12)
+    assert _rel(y, ref) < 4e-3
+    dy = _bf(torch.randn(M, H, generator=g)).to(dev)
+    ref.backward(dy.float())
+    dg = torch.zeros(H, device=dev)
+    db = torch.zeros(H, device=dev)
+    dbias = torch.zeros(H, device=dev)
+    dz, dd = hip.layernorm_bwd(dy, z, mean, rstd, gamma, dg, db, dbias)
+    assert dd is None
+    assert _rel(dz, zr.grad) < 6e-3
+    assert _rel(dg, gr.grad) < 1e-3 and _rel(db, br.grad) < 1e-3
+    assert _rel(dbias, dz.float().sum(0)) < 5e-3
+
+
+def test_layernorm_remap_and_dropout(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(8)
+    B, R, G, H = 3, 10, 6, 128
+    z = _bf(torch.randn(B * R, H, generator=g)).to(dev)
+    gamma = torch.ones(H, device=dev)
+    beta = torch.zeros(H, device=dev)
+    out = torch.zeros(B * (G + R), H, dtype=torch.bfloat16, device=dev)
+    drop = hip.make_dropout(0.25, 42)
+    hip.layernorm_fwd(z, gamma, beta, 1e-12, out=out, rows_per_group=R, group_stride=G + R, row_offset=G, drop=drop)
+    keep = hip.dropout_mask(drop, B * R * H, dev).reshape(B * R, H).float()
+    scale = 65536.0 / (65536.0 - drop.thresh16)
+    ref = torch.nn.functional.layer_norm(z.float(), (H,)) * keep * scale
+    o = out.reshape(B, G + R, H)
+    assert torch.all(o[:, :G] == 0)
+    assert _rel(o[:, G:].reshape(B * R, H), ref) < 4e-3
+
+
+def test_embed(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(9)
+    V, P, T, H, rows = 500, 64, 2, 128, 300
+    word = torch.randn(V, H, generator=g).to(dev)
+    pos = torch.randn(P, H, generator=g).to(dev)
+    typ = torch.randn(T, H, generator=g).to(dev)
+    ids = torch.randint(0, V, (rows,), generator=g).to(dev)
+    ids[:20] = 0
+    pids = torch.randint(0, P, (rows,), generator=g).to(dev)
+    tids = torch.randint(0, T, (rows,), generator=g).to(dev)
+    z = hip.embed_fwd(ids, pids, tids, word, pos, typ)
+    ref = word[ids] + pos[pids] + typ[tids]
+    assert _rel(z, ref) < 4e-3
+    dz = _bf(torch.randn(rows, H, generator=g)).to(dev)
+    dw = torch.zeros_like(word)
+    dp = torch.zeros_like(pos)
+    dt = torch.zeros_like(typ)
+    hip.embed_bwd(ids, pids, tids, dz, dw, dp, dt)
+    rw = torch.zeros_like(word).index_add_(0, ids, dz.float())
+    rw[0] = 0  # padding_idx
+    rp = torch.zeros_like(pos).index_add_(0, pids, dz.float())
+    rt = torch.zeros_like(typ).index_add_(0, tids, dz.float())
+    assert _rel(dw, rw) < 1e-5 and _rel(dp, rp) < 1e-5 and _rel(dt, rt) < 1e-5
+
+
+def test_cast_pack(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(10)
+    src = torch.randn(70, 2054, generator=g).to(dev)
+    dst = torch.full((70, 2056), 7.0, dtype=torch.bfloat16, device=dev)
+    dst_t = torch.zeros(2054, 200, dtype=torch.bfloat16, device=dev)
+    hip.cast_pack(src, dst=dst, dst_t=dst_t, col_off_t=100)
+    assert torch.equal(dst[:, :2054], src.to(torch.bfloat16))
+    assert torch.all(dst[:, 2054:] == 0)
+    assert torch.equal(dst_t[:, 100:170], src.to(torch.bfloat16).t())
+    assert torch.all(dst_t[:, :100] == 0) and torch.all(dst_t[:, 170:] == 0)
+    assert torch.equal(hip.cast_f32(dst, cols=2054), src.to(torch.bfloat16).float())
+
+
+def test_cross_entropy(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, V, Vpad = 50, 30522, 30528
+    logits = torch.zeros(M, Vpad)
+    logits[:, :V] = torch.randn(M, V, generator=g) * 3
+    logits = logits.to(dev)
+    labels = torch.randint(0, V, (M,), generator=g)
+    labels[::7] = -1
+    labels = labels.to(dev)
+    loss, lse = hip.ce_fwd(logits, labels, V=V)
+    lr = logits[:, :V].clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-1, reduction="none")
+    assert (loss - ref).abs().max().item() < 1e-4
+    nvalid = (labels >= 0).sum()
+    ref.sum().div(nvalid).backward()
+    scale = (1.0 / nvalid.float()).reshape(1)
+    d = hip.ce_bwd(logits, labels, lse, scale, V, Vpad)
+    assert torch.all(d[:, V:] == 0)
+    assert _rel(d[:, :V], lr.grad) < 4e-3
