@@ -119,7 +119,8 @@ int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
  * row_offset + (r % rows_per_group)  (lets the caller write straight into a concatenated
  * sequence buffer; rows_per_group = M, group_stride = 0, row_offset = 0 for the identity).
  * mean/rstd: f32 [M] saved statistics (may be NULL).  H % 8 == 0, H <= 1024.
- * drop element index = r * H + c. */
+ * drop element index = r * H + c.  gamma == NULL selects the identity (y = dropout(z)), used for
+ * the image embedding when use_img_layernorm is off (modeling_vlbert.py:499-503). */
 int mvptr_layernorm_fwd(const void* z, const float* gamma, const float* beta, float eps,
                         void* y, float* mean, float* rstd, int M, int H, int rows_per_group,
                         int group_stride, int row_offset, const mvptr_dropout* drop,

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int col = ch * 8 + e;
-        float t = (v[c][e] - mu) * rs * gamma[col] + beta[col];
+        float t = (gamma != nullptr) ? (v[c][e] - mu) * rs * gamma[col] + beta[col] : v[c][e];
         t = drop_apply(drop, (uint64_t)r * (uint64_t)H + col, t);
         o[e] = f2bf(t);
       }
@@ -97,10 +97,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
     for (int e = 0; e < 8; ++e) {
       ag[c][e] = ab[c][e] = abias[c][e] = 0.f;
       const int col = (lane + 64 * c) * 8 + e;
-      gm[c][e] = (col < H) ? gamma[col] : 0.f;
+      gm[c][e] = (col < H && gamma != nullptr) ? gamma[col] : 0.f;
     }
+  const bool ident = (gamma == nullptr);
   for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
-    const float mu = mean[r], rs = rstd[r];
+    const float mu = ident ? 0.f : mean[r], rs = ident ? 1.f : rstd[r];
     const int64_t irow = remap_row(r, rpg, gstride, roff);
     float xh[LN_MAXC][8], g[LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
           float d = bf2f(a[e]);
           d = drop_apply(ydrop, (uint64_t)r * (uint64_t)H + ch * 8 + e, d);
           xh[c][e] = (bf2f(x[e]) - mu) * rs;
-          g[c][e] = d * gm[c][e];
+          g[c][e] = ident ? d : d * gm[c][e];
           s1 += g[c][e];
           s2 += g[c][e] * xh[c][e];
           ag[c][e] += d * xh[c][e];
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
         for (int e = 0; e < 8; ++e) xh[c][e] = g[c][e] = 0.f;
       }
     }
-    const float c1 = wave_sum(s1) / (float)H;
-    const float c2 = wave_sum(s2) / (float)H;
+    const float c1 = ident ? 0.f : wave_sum(s1) / (float)H;
+    const float c2 = ident ? 0.f : wave_sum(s2) / (float)H;
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
       const int ch = lane + 64 * c;
@@ -402,7 +403,8 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
   if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: M must be > 0");
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: rows_per_group must be > 0");
-  if (!dy || !z || !mean || !rstd || !gamma || !dz) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: NULL argument");
+  if (!dy || !z || !dz) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: NULL argument");
+  if (gamma && (!mean || !rstd)) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: mean/rstd required");
   int grid = (M + 3) / 4;
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,

@@ -1,0 +1,410 @@
+"""Autograd glue between the `oscar.modeling`-style modules and the HIP kernels.
+
+Everything on the encoder path runs in bf16 with f32 accumulation through the C ABI
+(mvp_pytorch_amd.hip); the nn.Parameters stay f32 master weights with the reference's names
+and shapes, and kernel-friendly bf16 copies (Q|K|V packed, plus transposed copies for the
+data-gradient GEMMs) are rebuilt whenever a parameter's version counter changes.
+
+Functions
+  InputEmbedFn   BertEmbeddings (+ image embedding + concat)   modeling_bert.py:262-277,
+                                                                modeling_vlbert.py:328-336,498-506
+  EncoderFn      CaptionBertEncoder (n layers)                  modeling_vlbert.py:134-199
+  LinearFn       nn.Linear (+gelu) on bf16 rows                 modeling_bert.py:484-488
+  LayerNormFn    BertLayerNorm on bf16 rows                     modeling_bert.py:242-246
+  DecoderCEFn    vocabulary decoder + CrossEntropyLoss          modeling_bert.py:513-516,
+                                                                modeling_vlbert.py:1228-1249
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+_seed_counter = [0x5DEECE66D]
+
+
+def next_seed():
+    """Fresh 64-bit dropout seed; derived from torch's RNG so torch.manual_seed controls it."""
+    _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return (_seed_counter[0] ^ (base << 20)) & 0xFFFFFFFFFFFFFFFF
+
+
+def _f32(p):
+    t = p.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class WeightCache:
+    """bf16 working copies of a group of f32 parameters, refreshed when any version changes."""
+
+    def __init__(self):
+        self._key = None
+        self.t = {}
+
+    def stale(self, params):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._key:
+            self._key = key
+            return True
+        return False
+
+
+def cast_weight(w, want_t=True, kpad=None):
+    """f32 [N,K] -> (bf16 [N,Kp], bf16 [K,Np] or None).  Leading dims padded to multiples of 8."""
+    w = _f32(w)
+    N, K = w.shape
+    Kp = pad8(K) if kpad is None else kpad
+    dst = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16)
+    dst_t = torch.zeros((K, pad8(N)), device=w.device, dtype=torch.bfloat16) if want_t else None
+    hip.cast_pack(w, dst=dst, dst_t=dst_t)
+    return dst, dst_t
+
+
+# ---------------------------------------------------------------------------------------------
+class LayerPack:
+    """Kernel-side view of one CaptionBertLayer's parameters."""
+    NAMES = ["attention.self.query.weight", "attention.self.query.bias",
+             "attention.self.key.weight", "attention.self.key.bias",
+             "attention.self.value.weight", "attention.self.value.bias",
+             "attention.output.dense.weight", "attention.output.dense.bias",
+             "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+             "intermediate.dense.weight", "intermediate.dense.bias",
+             "output.dense.weight", "output.dense.bias",
+             "output.LayerNorm.weight", "output.LayerNorm.bias"]
+
+    def __init__(self):
+        self.cache = WeightCache()
+        self.w = None
+        self.keep = None
+
+    def refresh(self, params):
+        if not self.cache.stale(params):
+            return self.w
+        (qw, qb, kw, kb, vw, vb, ow, ob, g1, b1, iw, ib, pw, pb, g2, b2) = params
+        dev = qw.device
+        H = qw.shape[1]
+        I = iw.shape[0]
+        bf = torch.bfloat16
+        w_qkv = torch.empty((3 * H, H), device=dev, dtype=bf)
+        w_qkv_t = torch.empty((H, 3 * H), device=dev, dtype=bf)
+        for i, w in enumerate((qw, kw, vw)):
+            hip.cast_pack(_f32(w), dst=w_qkv[i * H:(i + 1) * H], dst_t=w_qkv_t, col_off_t=i * H)
+        b_qkv = torch.cat([_f32(qb), _f32(kb), _f32(vb)])
+        w_o, w_o_t = cast_weight(ow)
+        w_i, w_i_t = cast_weight(iw)
+        w_out, w_out_t = cast_weight(pw)
+        f = [_f32(x) for x in (ob, g1, b1, ib, pb, g2, b2)]
+        self.keep = [w_qkv, w_qkv_t, b_qkv, w_o, w_o_t, w_i, w_i_t, w_out, w_out_t] + f
+        lw = hip.LayerWeights()
+        lw.w_qkv, lw.w_qkv_t, lw.b_qkv = w_qkv.data_ptr(), w_qkv_t.data_ptr(), b_qkv.data_ptr()
+        lw.w_o, lw.w_o_t, lw.b_o = w_o.data_ptr(), w_o_t.data_ptr(), f[0].data_ptr()
+        lw.ln1_g, lw.ln1_b = f[1].data_ptr(), f[2].data_ptr()
+        lw.w_i, lw.w_i_t, lw.b_i = w_i.data_ptr(), w_i_t.data_ptr(), f[3].data_ptr()
+        lw.w_out, lw.w_out_t, lw.b_out = w_out.data_ptr(), w_out_t.data_ptr(), f[4].data_ptr()
+        lw.ln2_g, lw.ln2_b = f[5].data_ptr(), f[6].data_ptr()
+        self.w = lw
+        self.dims = (H, I)
+        return lw
+
+
+class EncoderMeta:
+    """Static description handed to EncoderFn (not a tensor)."""
+
+    def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn):
+        self.packs, self.B, self.L, self.H, self.heads, self.I = packs, B, L, H, heads, I
+        self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
+
+
+def _thresh(p):
+    return int(round(float(p) * 65536.0))
+
+
+class EncoderFn(torch.autograd.Function):
+    """n stacked encoder layers: x bf16 [B*L,H], additive mask f32 [B,L] -> bf16 [B*L,H]."""
+
+    @staticmethod
+    def forward(ctx, x, mask_add, meta, *params):
+        lib = hip.load()
+        n = len(meta.packs)
+        assert len(params) == 16 * n
+        need_grad = meta.training or any(p.requires_grad for p in params) or x.requires_grad
+        descs, stashes, xs = [], [], [x]
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        cur = x
+        scratch = None
+        for li in range(n):
+            lw = meta.packs[li].refresh(params[16 * li:16 * (li + 1)])
+            d = hip.LayerDesc(meta.B, meta.L, meta.H, meta.heads, meta.I, meta.eps,
+                              1 if meta.training else 0, _thresh(meta.p_hidden), _thresh(meta.p_attn),
+                              next_seed() if meta.training else 0)
+            nbytes = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
+            if nbytes < 0:
+                hip._check(-1)
+            if need_grad or scratch is None:
+                stash = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+                scratch = stash
+            else:
+                stash = scratch
+            y = torch.empty_like(cur)
+            hip._check(lib.mvptr_encoder_layer_fwd(ctypes.byref(d), ctypes.byref(lw), hip._p(cur), hip._p(mask_add),
+                                                   hip._p(y), hip._p(stash), None, 0, stream))
+            descs.append(d)
+            stashes.append(stash)
+            cur = y
+            xs.append(y)
+        ctx.meta, ctx.descs, ctx.stashes, ctx.xs, ctx.mask = meta, descs, stashes, xs, mask_add
+        ctx.params = params
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.load()
+        meta = ctx.meta
+        n = len(meta.packs)
+        dev = dy.device
+        H, I = meta.H, meta.I
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ws_bytes = lib.mvptr_layer_workspace_bytes(ctypes.byref(ctx.descs[0]))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
+        total = sum(sizes)
+        grads = [None] * (16 * n)
+        d_cur = dy.contiguous()
+        for li in reversed(range(n)):
+            flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            parts, o = [], 0
+            for s in sizes:
+                parts.append(flat[o:o + s])
+                o += s
+            g = hip.LayerGrads()
+            (g.w_qkv, g.b_qkv, g.w_o, g.b_o, g.ln1_g, g.ln1_b, g.w_i, g.b_i, g.w_out, g.b_out, g.ln2_g,
+             g.ln2_b) = [p.data_ptr() for p in parts]
+            dx = torch.empty_like(d_cur)
+            hip._check(lib.mvptr_encoder_layer_bwd(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
+                                                   hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
+                                                   hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream))
+            wq = parts[0].view(3, H, H)
+            bq = parts[1].view(3, H)
+            gl = [wq[0], bq[0], wq[1], bq[1], wq[2], bq[2], parts[2].view(H, H), parts[3], parts[4], parts[5],
+                  parts[6].view(I, H), parts[7], parts[8].view(H, I), parts[9], parts[10], parts[11]]
+            for j in range(16):
+                p = ctx.params[16 * li + j]
+                if p.requires_grad:
+                    grads[16 * li + j] = gl[j].to(p.dtype)
+            d_cur = dx
+        ctx.stashes = ctx.xs = None
+        return (d_cur, None, None) + tuple(grads)
+
+
+# ---------------------------------------------------------------------------------------------
+class InputEmbedFn(torch.autograd.Function):
+    """Token embeddings (+ region-feature embedding) -> concatenated bf16 [B, Lt+R, H].
+
+    args: ids/type_ids/pos_ids int64 [B,Lt]; img_feats f32 [B,R,D] or None; meta dict with
+    eps, img_eps, use_img_ln, p (hidden dropout), training, cache (WeightCache-like dict);
+    params: word, pos, type, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b (missing -> None)."""
+
+    @staticmethod
+    def forward(ctx, ids, type_ids, pos_ids, img_feats, meta, word, pos, typ, ln_w, ln_b, img_w, img_b,
+                img_ln_w, img_ln_b):
+        B, Lt = ids.shape
+        H = word.shape[1]
+        R = img_feats.shape[1] if img_feats is not None else 0
+        Ltot = Lt + R
+        dev = word.device
+        training = meta["training"]
+        p = meta["p"] if training else 0.0
+        out = torch.empty((B * Ltot, H), device=dev, dtype=torch.bfloat16)
+        idf, tyf, pof = ids.reshape(-1).contiguous(), type_ids.reshape(-1).contiguous(), pos_ids.reshape(-1).contiguous()
+        wordf, posf, typf = _f32(word), _f32(pos), _f32(typ)
+        z = hip.embed_fwd(idf, pof, tyf, wordf, posf, typf)
+        drop_t = hip.make_dropout(p, next_seed()) if p > 0 else None
+        lnw, lnb = _f32(ln_w), _f32(ln_b)
+        _, mean, rstd = hip.layernorm_fwd(z, lnw, lnb, meta["eps"], out=out, rows_per_group=Lt,
+                                          group_stride=Ltot, row_offset=0, drop=drop_t)
+        ctx.txt = (idf, tyf, pof, z, mean, rstd, lnw, drop_t)
+        ctx.img = None
+        if R > 0:
+            D = img_feats.shape[2]
+            Dp = pad8(D)
+            feats = img_feats.reshape(B * R, D)
+            if feats.dtype != torch.float32:
+                feats = feats.float()
+            fb = torch.empty((B * R, Dp), device=dev, dtype=torch.bfloat16)
+            hip.cast_pack(feats.contiguous(), dst=fb)
+            cache = meta["cache"]
+            if cache.stale([img_w]):
+                cache.t["img_w"] = cast_weight(img_w, want_t=False)[0]
+            zi = hip.gemm_nt(fb, cache.t["img_w"], hip.EPI_BIAS, bias=_f32(img_b))
+            p_img = meta.get("p_img", meta["p"]) if training else 0.0
+            drop_i = hip.make_dropout(p_img, next_seed()) if p_img > 0 else None
+            use_ln = img_ln_w is not None and meta["use_img_ln"]
+            g = _f32(img_ln_w) if use_ln else None
+            bta = _f32(img_ln_b) if use_ln else None
+            _, mi, ri = hip.layernorm_fwd(zi, g, bta, meta["img_eps"], out=out, rows_per_group=R,
+                                          group_stride=Ltot, row_offset=Lt, drop=drop_i, save_stats=use_ln)
+            ctx.img = (fb, zi, mi, ri, g, drop_i, D)
+        ctx.dims = (B, Lt, R, H)
+        ctx.shapes = (word.shape, pos.shape, typ.shape)
+        ctx.needs = [t is not None and t.requires_grad for t in (word, pos, typ, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b)]
+        return out.view(B, Ltot, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Lt, R, H = ctx.dims
+        Ltot = Lt + R
+        dev = dout.device
+        dout = dout.contiguous().view(B * Ltot, H)
+        idf, tyf, pof, z, mean, rstd, lnw, drop_t = ctx.txt
+        f32 = dict(device=dev, dtype=torch.float32)
+        dg, db = torch.zeros(H, **f32), torch.zeros(H, **f32)
+        dz, _ = hip.layernorm_bwd(dout, z, mean, rstd, lnw, dg, db, None, rows_per_group=Lt,
+                                  group_stride=Ltot, row_offset=0, y_drop=drop_t)
+        dword = torch.zeros(ctx.shapes[0], **f32)
+        dpos = torch.zeros(ctx.shapes[1], **f32)
+        dtyp = torch.zeros(ctx.shapes[2], **f32)
+        hip.embed_bwd(idf, pof, tyf, dz, dword, dpos, dtyp)
+        gi_w = gi_b = gi_lw = gi_lb = None
+        if ctx.img is not None:
+            fb, zi, mi, ri, g, drop_i, D = ctx.img
+            dbias = torch.zeros(H, **f32)
+            gi_lw = torch.zeros(H, **f32) if g is not None else None
+            gi_lb = torch.zeros(H, **f32) if g is not None else None
+            dzi, _ = hip.layernorm_bwd(dout, zi, mi, ri, g, gi_lw, gi_lb, dbias, rows_per_group=R,
+                                       group_stride=Ltot, row_offset=Lt, y_drop=drop_i)
+            dw = torch.zeros((H, fb.shape[1]), **f32)
+            hip.gemm_tn(dzi, fb, dw)
+            gi_w, gi_b = dw[:, :D].contiguous(), dbias
+        outs = [dword, dpos, dtyp, dg, db, gi_w, gi_b, gi_lw, gi_lb]
+        outs = [o if need else None for o, need in zip(outs, ctx.needs)]
+        ctx.txt = ctx.img = None
+        return (None, None, None, None, None) + tuple(outs)
+
+
+# ---------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) on bf16 rows; act in {None, 'gelu'}; W f32 [N,K] master weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, cache):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or (x2.stride(0) % 8) or (x2.data_ptr() % 16):
+            x2 = x2.contiguous()
+        if cache.stale([weight]):
+            cache.t["w"], cache.t["wt"] = cast_weight(weight)
+        b = _f32(bias) if bias is not None else None
+        N = weight.shape[0]
+        if act == "gelu":
+            u, y = hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS_GELU, bias=b, n=N)
+        else:
+            u, y = None, hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS, bias=b, n=N)
+        ctx.save = (x2, u, cache, weight.shape, bias is not None)
+        ctx.needs = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, cache, wshape, has_bias = ctx.save
+        N, K = wshape
+        dy2 = dy.reshape(-1, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dev = dy.device
+        db = torch.zeros(N, device=dev, dtype=torch.float32) if has_bias else None
+        wt = cache.t["wt"]  # bf16 [K, pad8(N)]
+        Np = wt.shape[1]
+        if Np != N:
+            pad = torch.zeros((dy2.shape[0], Np), device=dev, dtype=torch.bfloat16)
+            pad[:, :N] = dy2
+            dy2 = pad
+        if u is not None:
+            # dy2 is d(gelu(u)); d(u) = dy * gelu'(u): run it through the identity-free path
+            xg = u.float().requires_grad_(True)
+            with torch.enable_grad():
+                torch.nn.functional.gelu(xg).backward(dy2[:, :N].float())
+            du = xg.grad.to(torch.bfloat16)
+            if Np != N:
+                pad = torch.zeros((du.shape[0], Np), device=dev, dtype=torch.bfloat16)
+                pad[:, :N] = du
+                du = pad
+            dy2 = du
+        if db is not None:
+            hip.colsum(dy2, db, n=N)
+        dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
+        dw = None
+        if ctx.needs[1]:
+            dw = torch.zeros((N, x2.shape[1]), device=dev, dtype=torch.float32)
+            hip.gemm_tn(dy2, x2, dw, n=N)
+            dw = dw[:, :K]
+        if dx is not None:
+            dx = dx.view(ctx.xshape)
+        return dx, dw, (db if ctx.needs[2] else None), None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, weight, bias, eps):
+        z2 = z.reshape(-1, z.shape[-1]).contiguous()
+        w, b = _f32(weight), _f32(bias)
+        y, mean, rstd = hip.layernorm_fwd(z2, w, b, eps)
+        ctx.save = (z2, mean, rstd, w)
+        return y.view(z.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z2, mean, rstd, w = ctx.save
+        H = z2.shape[1]
+        dg = torch.zeros(H, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(H, device=dy.device, dtype=torch.float32)
+        dz, _ = hip.layernorm_bwd(dy.reshape(-1, H).contiguous(), z2, mean, rstd, w, dg, db)
+        return dz.view(dy.shape), dg, db, None
+
+
+class DecoderCEFn(torch.autograd.Function):
+    """loss = mean_{labels>=0} CE(h W^T + b, labels); W f32 [V,H] (vocabulary decoder).
+    Returns (loss, logits f32 [M,V] view) — logits are a non-differentiable side output."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, labels, cache):
+        M, H = h.shape
+        V = weight.shape[0]
+        Vp = pad8(V)
+        if cache.stale([weight]):
+            cache.t["w"], cache.t["wt"] = cast_weight(weight)
+        h = h.contiguous()
+        logits = torch.empty((M, Vp), device=h.device, dtype=torch.float32)
+        hip.gemm_nt(h, cache.t["w"], hip.EPI_F32, bias=_f32(bias), out=logits, n=V)
+        labels = labels.contiguous()
+        loss_row, lse = hip.ce_fwd(logits, labels, V=V)
+        nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32)
+        loss = loss_row.sum() / nvalid
+        ctx.save = (h, logits, labels, lse, nvalid, cache, V, Vp)
+        ctx.needs = (h.requires_grad, weight.requires_grad, bias.requires_grad)
+        out_logits = logits[:, :V]
+        ctx.mark_non_differentiable(out_logits)
+        return loss, out_logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        h, logits, labels, lse, nvalid, cache, V, Vp = ctx.save
+        scale = (gloss.to(torch.float32) / nvalid).reshape(1).contiguous()
+        d = hip.ce_bwd(logits, labels, lse, scale, V, Vp)
+        H = h.shape[1]
+        dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H) if ctx.needs[0] else None
+        dw = db = None
+        if ctx.needs[1]:
+            dw = torch.zeros((V, H), device=h.device, dtype=torch.float32)
+            hip.gemm_tn(d, h, dw, n=V)
+        if ctx.needs[2]:
+            db = torch.zeros(V, device=h.device, dtype=torch.float32)
+            hip.colsum(d, db, n=V)
+        ctx.save = None
+        return dh, dw, db, None, None

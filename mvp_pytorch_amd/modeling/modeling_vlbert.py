@@ -1,0 +1,611 @@
+"""MVPTR model classes with the class / config / checkpoint surface of
+oscar/modeling/modeling_vlbert.py, running on the HIP encoder.
+
+  CaptionBertEncoder           vl:123-178      BertImgModel               vl:202-352
+  BiBertImgModel               vl:354-874      BertPreTrainingHeads       vl:970-980
+  BertImgForPreTraining        vl:1024-1130    BiBertImgForPreTraining    vl:1133-1311
+  BiImageBertForRetrieval      vl:1598-1712    BiImageBertForSequenceClassification vl:1715-1798
+  BiImageBertForVQA            vl:1801-1870    WRA helpers                vl:1502-1596
+
+(`vl` = oscar/modeling/modeling_vlbert.py in the reference tree.)  Keyword arguments, return
+tuples, state_dict keys and config attributes follow the reference; encoder activations are
+bf16 tensors, pooled outputs / logits / losses are f32.
+"""
+import copy
+import logging
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn import CrossEntropyLoss, MSELoss
+
+from .. import engine
+from .modeling_bert import (BertConfig, BertEmbeddings, BertLayer, BertLayerNorm, BertLMPredictionHead,
+                            BertPooler, BertPreTrainedModel, BertQAPredictionHead, embed_inputs)
+from .modeling_utils import ImgPreTrainedModel
+
+logger = logging.getLogger(__name__)
+
+
+def soft_cross_entropy(target, input_prob, reduction="mean"):
+    """vl:27-40."""
+    logprobs = F.log_softmax(input_prob, dim=1)
+    target = target.float()
+    target = torch.stack([1 - target, target], dim=1)
+    batchloss = -torch.sum(target.view(target.shape[0], -1) * logprobs, dim=1)
+    if reduction == "none":
+        return batchloss
+    if reduction == "mean":
+        return torch.mean(batchloss)
+    if reduction == "sum":
+        return torch.sum(batchloss)
+    raise NotImplementedError("Unsupported reduction mode.")
+
+
+def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
+    """vl:878-883."""
+    assert logits.dim() == 2
+    loss = F.binary_cross_entropy_with_logits(logits, labels, reduction=reduction, pos_weight=pos_weight)
+    if reduction == "mean":
+        loss = loss * labels.size(1)
+    return loss
+
+
+def additive_mask(attention_mask):
+    """vl:278-292 / vl:430-460 — [B,L] 0/1 -> f32 [B,L] additive (0 / -10000); the kernel
+    broadcasts it over heads and query positions like the reference's [B,1,1,L] tensor."""
+    if attention_mask.dim() != 2:
+        raise NotImplementedError("only 2-D attention masks are supported by the HIP attention kernel")
+    return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+
+
+class CaptionBertLayer(BertLayer):
+    pass
+
+
+class CaptionBertEncoder(nn.Module):
+    """vl:123-178.  forward(hidden [B,L,H] bf16, additive mask f32 [B,L]) -> (hidden,)"""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.output_attentions or config.output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused encoder")
+        self.output_attentions = config.output_attentions
+        self.output_hidden_states = config.output_hidden_states
+        self.num_layers = config.num_hidden_layers
+        self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
+        self._packs = [engine.LayerPack() for _ in range(config.num_hidden_layers)]
+        self._dims = (config.hidden_size, config.num_attention_heads, config.intermediate_size, config.layer_norm_eps)
+
+    def _flat_params(self):
+        out = []
+        for layer in self.layer:
+            a = layer.attention
+            out += [a.self.query.weight, a.self.query.bias, a.self.key.weight, a.self.key.bias,
+                    a.self.value.weight, a.self.value.bias, a.output.dense.weight, a.output.dense.bias,
+                    a.output.LayerNorm.weight, a.output.LayerNorm.bias, layer.intermediate.dense.weight,
+                    layer.intermediate.dense.bias, layer.output.dense.weight, layer.output.dense.bias,
+                    layer.output.LayerNorm.weight, layer.output.LayerNorm.bias]
+        return out
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None,
+                return_at_layer=None):
+        if isinstance(attention_mask, list) or encoder_history_states is not None or return_at_layer is not None:
+            raise NotImplementedError("phase masks / history states / return_at_layer are outside the accelerated path")
+        if head_mask is not None and any(h is not None for h in head_mask):
+            raise NotImplementedError("head_mask must stay None")
+        B, L, H = hidden_states.shape
+        Hc, heads, I, eps = self._dims
+        l0 = self.layer[0]
+        meta = engine.EncoderMeta(self._packs, B, L, Hc, heads, I, eps, self.training,
+                                  l0.output.dropout.p, l0.attention.self.dropout.p)
+        x = hidden_states.to(torch.bfloat16).contiguous().view(B * L, H)
+        y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params())
+        return (y.view(B, L, H),)
+
+
+def _check_img_type(config):
+    if getattr(config, "img_feature_type", "faster_r-cnn") in ("dis_code", "dis_code_t", "dis_code_scale"):
+        raise NotImplementedError("discrete-code image features are outside the accelerated path")
+
+
+class _ImgBackboneMixin:
+    def _init_img(self, config):
+        _check_img_type(config)
+        self.img_dim = config.img_feature_dim
+        self.img_feature_type = config.img_feature_type
+        self.use_img_layernorm = getattr(config, "use_img_layernorm", None)
+        self.img_embedding = nn.Linear(self.img_dim, config.hidden_size, bias=True)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        if self.use_img_layernorm:
+            self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.img_layer_norm_eps)
+
+    def _resize_token_embeddings(self, new_num_tokens):
+        self.embeddings.word_embeddings = self._get_resized_embeddings(self.embeddings.word_embeddings, new_num_tokens)
+        return self.embeddings.word_embeddings
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+
+class BertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
+    """vl:202-352 — single-stream backbone over [text ; regions]."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = CaptionBertEncoder(config)
+        self.pooler = BertPooler(config)
+        self._init_img(config)
+        self.apply(self.init_weights)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None,
+                head_mask=None, img_feats=None, encoder_history_states=None):
+        if head_mask is not None or encoder_history_states:
+            raise NotImplementedError("head_mask / encoder_history_states are outside the accelerated path")
+        if attention_mask is None:
+            n = input_ids.shape[1] + (img_feats.shape[1] if img_feats is not None else 0)
+            attention_mask = torch.ones((input_ids.shape[0], n), dtype=torch.long, device=input_ids.device)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        mask = additive_mask(attention_mask)
+        x = embed_inputs(self.embeddings, input_ids, token_type_ids, position_ids, img_feats, self)
+        sequence_output = self.encoder(x, mask)[0]
+        return (sequence_output, self.pooler(sequence_output))
+
+
+class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
+    """vl:354-874 — MVPTR two-stage backbone: txt_encoder / vis_encoder (uni-modal) and
+    mul_encoder (joint), CLIP-style global similarity and in-batch hard negatives."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        half = copy.deepcopy(config)
+        half.num_hidden_layers = half.num_hidden_layers // 2
+        self.vis_encoder = CaptionBertEncoder(half)
+        self.txt_encoder = CaptionBertEncoder(half)
+        self.mul_encoder = CaptionBertEncoder(half)
+        self.pooler = BertPooler(config)
+        scale = config.hidden_size ** -0.5
+        self.txt_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
+        self.vis_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
+        self._init_img(config)
+        self.apply(self.init_weights)
+
+    # -- stage 1: uni-modal encoders (vl:479-513)
+    def _uni(self, input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a, input_ids_b,
+             token_type_ids_b, attention_mask_b, position_ids_b, img_feats):
+        if attention_mask_a is None:
+            attention_mask_a = torch.ones_like(input_ids_a)
+        if attention_mask_b is None:
+            attention_mask_b = torch.ones_like(input_ids_b)
+        if token_type_ids_a is None:
+            token_type_ids_a = torch.zeros_like(input_ids_a)
+        if token_type_ids_b is None:
+            token_type_ids_b = torch.zeros_like(input_ids_b)
+        mask_a = additive_mask(attention_mask_a)
+        mask_b = additive_mask(attention_mask_b)
+        xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
+        xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self)
+        txt = self.txt_encoder(xa, mask_a)[0]
+        vis = self.vis_encoder(xb, mask_b)[0]
+        return txt, vis, mask_a, mask_b
+
+    def _globals(self, txt, vis):
+        """vl:525-526 — f32 (feeds argmax: kept out of bf16)."""
+        gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
+        gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj, p=2, dim=-1)
+        return gt, gi
+
+    def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
+                use_b=False, position_ids_a=None, input_ids_b=None, token_type_ids_b=None,
+                attention_mask_b=None, phrase_layer=None, position_ids_b=None, head_mask=None,
+                img_feats=None, encoder_history_states=None, encode_hn=False, hn_mod="hard", logit=None):
+        if head_mask is not None or encoder_history_states or phrase_layer is not None:
+            raise NotImplementedError("head_mask / encoder_history_states / phrase_layer are outside the accelerated path")
+        txt, vis, mask_a, mask_b = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
+                                             input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats)
+        cut = 1 if use_b else max_tag_length
+        only_vis = vis[:, cut:, :]
+        only_vis_mask = mask_b[:, cut:]
+        global_txt, global_img = self._globals(txt, vis)
+        sim_mat = global_txt @ global_img.t()
+
+        hard_out = hard_pooled = hard_txt_full = hard_img_full = None
+        if encode_hn:
+            n = sim_mat.shape[0]
+            dev = sim_mat.device
+            if hn_mod == "hard":
+                masked = sim_mat - 2 * torch.eye(n, dtype=sim_mat.dtype, device=dev)
+                hard_img = torch.max(masked, dim=1)[1]
+                hard_txt = torch.max(masked, dim=0)[1]
+            elif hn_mod == "sample":
+                masked = (logit * sim_mat) - 10000 * torch.eye(n, dtype=sim_mat.dtype, device=dev)
+                hard_img = torch.multinomial(F.softmax(masked, dim=1), num_samples=1).squeeze()
+                hard_txt = torch.multinomial(F.softmax(masked.t(), dim=1), num_samples=1).squeeze()
+            else:
+                raise NotImplementedError
+            dice = torch.randperm(n, device=dev)
+            first, second = dice[: n // 2], dice[n // 2:]
+            ar = torch.arange(n, device=dev)
+            # rows of the hard batch: (text i, image hard_img[i]) for i in first,
+            #                         (text hard_txt[j], image j)  for j in second       (vl:544-566)
+            hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
+            hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
+            hard_seqs = torch.cat([txt.index_select(0, hard_txt_full), only_vis.index_select(0, hard_img_full)], 1)
+            hard_mask = torch.cat([mask_a.index_select(0, hard_txt_full), only_vis_mask.index_select(0, hard_img_full)], 1)
+            hard_out = self.mul_encoder(hard_seqs, hard_mask)[0]
+            hard_pooled = self.pooler(hard_out)
+
+        joint = torch.cat([txt, only_vis], dim=1)
+        joint_mask = torch.cat([mask_a, only_vis_mask], dim=-1)
+        sequence_output = self.mul_encoder(joint, joint_mask)[0]
+        pooled_output = self.pooler(sequence_output)
+        outputs = (sequence_output, pooled_output, hard_out, hard_pooled)
+        return outputs, (txt, vis, sim_mat), (hard_txt_full, hard_img_full)
+
+    def forward_single(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
+                       position_ids_a=None, input_ids_b=None, token_type_ids_b=None, attention_mask_b=None,
+                       position_ids_b=None, head_mask=None, img_feats=None, encoder_history_states=None):
+        """vl:611-723 — uni-modal encoders + projections only (retrieval coarse stage)."""
+        txt, vis, _, _ = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
+                                   input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats)
+        return self._globals(txt, vis)
+
+
+# ------------------------------------------------------------------------------------------ heads
+class BertPreTrainingHeads(nn.Module):
+    """vl:970-980."""
+
+    def __init__(self, config, only_vocab=False):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config, only_vocab=only_vocab)
+        n = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
+        self.seq_relationship = nn.Linear(config.hidden_size, n)
+
+    def forward(self, sequence_output, pooled_output):
+        return self.predictions(sequence_output), self.seq_relationship(pooled_output.float())
+
+
+class BertVQAHeads(nn.Module):
+    """vl:983-990."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertQAPredictionHead(config)
+
+    def forward(self, sequence_output):
+        return self.predictions(sequence_output)
+
+
+def _masked_rows(seq, labels):
+    """rows of seq [B,L,H] whose label > -1 (vl:1231-1234 masked_select + reshape) and their labels."""
+    keep = (labels > -1).reshape(-1)
+    idx = torch.nonzero(keep).squeeze(1)
+    rows = seq.reshape(-1, seq.shape[-1]).index_select(0, idx)
+    return rows, labels.reshape(-1).index_select(0, idx)
+
+
+# ------------------------------------------------------------------------------------------- WRA
+def mask_slice_and_stack(features, valid_index):
+    """vl:1502-1508."""
+    vi = valid_index.tolist()
+    return torch.cat([features[i, s:e] for i, (s, e) in enumerate(vi)], dim=0)
+
+
+def t2i_sim(sim_matrix):
+    """vl:1543-1550."""
+    if sim_matrix.shape[0] == 0:
+        return torch.zeros((), dtype=sim_matrix.dtype, device=sim_matrix.device)
+    f_sim = sim_matrix.topk(3, dim=1)[0]
+    rand_index = torch.randint(0, 3, (f_sim.shape[0],), device=f_sim.device)
+    return f_sim[torch.arange(f_sim.shape[0], device=f_sim.device), rand_index].mean()
+
+
+def get_pos_neg_sims(sims, text_index, img_index):
+    """vl:1553-1596 (borders computed on the host once instead of per-sample device syncs)."""
+    tb = [0] + torch.cumsum(text_index[:, 1] - text_index[:, 0], 0).tolist()
+    ib = [0] + torch.cumsum(img_index[:, 1] - img_index[:, 0], 0).tolist()
+    n = text_index.shape[0]
+    pos, neg = [], []
+    for t in range(n):
+        pos.append(t2i_sim(sims[tb[t]:tb[t + 1], ib[t]:ib[t + 1]]))
+        j = random.choice(list(range(0, t)) + list(range(t + 1, n)))
+        neg.append(t2i_sim(sims[tb[t]:tb[t + 1], ib[j]:ib[j + 1]]))
+    return torch.stack(pos), torch.stack(neg)
+
+
+def get_pos_sims(sequence_output, text_index, img_index):
+    """vl:1510-1527."""
+    out = []
+    ti, ii = text_index.tolist(), img_index.tolist()
+    for i in range(len(ti)):
+        f = sequence_output[i].float()
+        t = F.normalize(f[ti[i][0]:ti[i][1]], p=2, dim=-1)
+        v = F.normalize(f[ii[i][0]:ii[i][1]], p=2, dim=-1)
+        out.append(t2i_sim(t @ v.t()) if t.shape[0] else torch.zeros((), dtype=v.dtype, device=v.device))
+    return torch.stack(out)
+
+
+# ------------------------------------------------------------------------------------ task models
+class BertImgForPreTraining(ImgPreTrainedModel):
+    """vl:1024-1130 — single-stream MLM + ITM."""
+    config_class = BertConfig
+    base_model_prefix = "bert"
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = BertImgModel(config)
+        self.cls = BertPreTrainingHeads(config)
+        self.num_seq_relations = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
+        self.max_text_seq_length = config.max_text_seq_length if hasattr(config, "max_text_seq_length") else None
+        self.apply(self.init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        self._tie_or_clone_weights(self.cls.predictions.decoder, self.bert.embeddings.word_embeddings)
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, masked_lm_labels=None,
+                next_sentence_label=None, position_ids=None, head_mask=None, img_feats=None):
+        sequence_output, pooled_output = self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
+                                                   attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats)
+        T = self.max_text_seq_length
+        text = sequence_output[:, :T, :] if T is not None else sequence_output
+        seq_relationship_score = self.cls.seq_relationship(pooled_output)
+        if masked_lm_labels is None or next_sentence_label is None:
+            return (self.cls.predictions(text), seq_relationship_score)
+        labels = masked_lm_labels[:, :T].contiguous() if T is not None else masked_lm_labels
+        masked_lm_loss, scores = self.cls.predictions.loss_and_scores(text.reshape(-1, text.shape[-1]), labels.reshape(-1))
+        prediction_scores = scores.reshape(text.shape[0], text.shape[1], -1)
+        loss_fct = CrossEntropyLoss(ignore_index=-1)
+        next_sentence_loss = loss_fct(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
+        total_loss = masked_lm_loss + next_sentence_loss
+        return (total_loss, prediction_scores, seq_relationship_score, masked_lm_loss)
+
+
+class BiBertImgForPreTraining(ImgPreTrainedModel):
+    """vl:1133-1311 — the model oscar/run_pretrain_ml.py trains (:25,324): masked-concept MLM on
+    tags, CLIP-style retrieval loss, text MLM, ITM on [matched ; hard-negative] pairs, WRA."""
+    config_class = BertConfig
+    base_model_prefix = "bert"
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = BiBertImgModel(config)
+        self.cls = BertPreTrainingHeads(config, only_vocab=True)
+        self.half_mlm = BertLMPredictionHead(config, only_vocab=True)
+        self.qa_head = nn.Linear(config.hidden_size, config.qa_answer_size)
+        self.only_vocab_size = config.only_word_size
+        self.num_seq_relations = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
+        self.max_text_seq_length = config.max_text_seq_length if hasattr(config, "max_text_seq_length") else None
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.apply(self.init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        emb = self.bert.embeddings.word_embeddings
+        self._tie_or_clone_weights(self.cls.predictions.decoder, emb, only_vocab=True, only_word_size=self.only_vocab_size)
+        self._tie_or_clone_weights(self.half_mlm.decoder, emb, only_vocab=True, only_word_size=self.only_vocab_size)
+
+    def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, masked_lm_labels_a=None,
+                qa_ans=None, input_ids_b=None, token_type_ids_b=None, attention_mask_b=None,
+                masked_lm_labels_b=None, max_tag_length=20, position_ids_a=None, position_ids_b=None,
+                head_mask=None, img_feats=None, is_img_match=None, img_index=None, phrase_index=None,
+                phrase_mod="sample"):
+        outputs, single, hard_indexes = self.bert(
+            input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
+            attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats, input_ids_b=input_ids_b,
+            position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b, attention_mask_b=attention_mask_b,
+            max_tag_length=max_tag_length, encode_hn=True)
+        txt_out, vis_out, sim_mat = single
+        ce_loss = CrossEntropyLoss(ignore_index=-1)
+
+        vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b)
+        vis_mlm_loss, _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels)
+
+        logits = sim_mat * self.logit_scale.exp()
+        pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
+        retrieval_loss = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
+
+        sequence_output, pooled_output, hard_sequence_output, hard_pooled_output = outputs
+        rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a)
+        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels)
+        seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
+        n = pooled_output.shape[0]
+        next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long), torch.ones(n, dtype=torch.long)]).to(seq_relationship_score.device)
+        next_sentence_loss = ce_loss(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
+
+        total_loss = vis_mlm_loss + retrieval_loss + masked_lm_loss + next_sentence_loss
+        outs = (vis_mlm_loss, retrieval_loss, masked_lm_loss, next_sentence_loss)
+        if qa_ans is not None:
+            qa_loss = ce_loss(self.qa_head(pooled_output), qa_ans)
+            total_loss = total_loss + qa_loss
+            outs = outs + (qa_loss,)
+        if phrase_index is not None:
+            if phrase_mod == "hard":
+                hard_txt_index, hard_img_index = hard_indexes
+                hard_phrase_index = phrase_index.index_select(0, hard_txt_index)
+                hard_object_index = img_index.index_select(0, hard_img_index)
+                pos_sims = get_pos_sims(sequence_output, phrase_index, img_index)
+                neg_sims = get_pos_sims(hard_sequence_output, hard_phrase_index, hard_object_index)
+                valid = ((phrase_index[:, 1] - phrase_index[:, 0]) > 0) & ((hard_phrase_index[:, 1] - hard_phrase_index[:, 0]) > 0)
+            elif phrase_mod == "sample":
+                seq32 = sequence_output.float()
+                valid_phrases = F.normalize(mask_slice_and_stack(seq32, phrase_index), p=2, dim=-1)
+                valid_images = F.normalize(mask_slice_and_stack(seq32, img_index), p=2, dim=-1)
+                pos_sims, neg_sims = get_pos_neg_sims(valid_phrases @ valid_images.t(), phrase_index, img_index)
+                valid = (phrase_index[:, 1] - phrase_index[:, 0]) > 0
+            else:
+                raise NotImplementedError
+            wra_loss = torch.mean(torch.masked_select(torch.clamp(neg_sims + 0.2 - pos_sims, min=0), valid))
+            total_loss = total_loss + wra_loss
+            return (total_loss,) + outs + (wra_loss,)
+        return (total_loss,) + outs
+
+
+def _make_classifier(config, num_labels):
+    if hasattr(config, "classifier"):
+        if not hasattr(config, "cls_hidden_scale"):
+            config.cls_hidden_scale = 2
+        if config.classifier == "linear":
+            return nn.Linear(config.hidden_size, num_labels)
+        if config.classifier == "mlp":
+            return nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * config.cls_hidden_scale), nn.ReLU(),
+                                 nn.Linear(config.hidden_size * config.cls_hidden_scale, num_labels))
+    return nn.Linear(config.hidden_size, num_labels)
+
+
+def _bi_kwargs(kw):
+    return dict(input_ids_a=kw["input_ids_a"], position_ids_a=kw.get("position_ids_a"),
+                token_type_ids_a=kw.get("token_type_ids_a"), attention_mask_a=kw.get("attention_mask_a"),
+                head_mask=kw.get("head_mask"), img_feats=kw.get("img_feats"), input_ids_b=kw.get("input_ids_b"),
+                position_ids_b=kw.get("position_ids_b"), token_type_ids_b=kw.get("token_type_ids_b"),
+                attention_mask_b=kw.get("attention_mask_b"), max_tag_length=kw.get("max_tag_length", 20))
+
+
+class BiImageBertForRetrieval(BertPreTrainedModel):
+    """vl:1598-1712 — `forward_mod` in {'train','coarse','fine'} (run_retrieval.py:598-601)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.num_labels = 2
+        self.loss_type = config.loss_type
+        self.config = config
+        if config.img_feature_dim <= 0:
+            raise NotImplementedError("text-only BertModel is outside the accelerated path")
+        self.bert = BiBertImgModel(config)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.forward_mod = "train"
+        self.classifier = _make_classifier(config, self.config.num_labels)
+        self.apply(self.init_weights)
+
+    def reinit_cls_head(self):
+        self.classifier.apply(self.init_weights)
+
+    def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                token_type_ids_b=None, attention_mask_b=None, max_tag_length=20, position_ids_a=None,
+                position_ids_b=None, head_mask=None, img_feats=None):
+        kw = dict(input_ids_a=input_ids_a, token_type_ids_a=token_type_ids_a, attention_mask_a=attention_mask_a,
+                  input_ids_b=input_ids_b, token_type_ids_b=token_type_ids_b, attention_mask_b=attention_mask_b,
+                  img_feats=img_feats, max_tag_length=max_tag_length, position_ids_a=position_ids_a,
+                  position_ids_b=position_ids_b, head_mask=head_mask)
+        if self.forward_mod == "train":
+            return self.forward_train(**kw)
+        if self.forward_mod == "coarse":
+            return self.forward_emb(**kw)
+        if self.forward_mod == "fine":
+            return self.forward_fine(**kw)
+        raise NotImplementedError
+
+    def forward_train(self, **kw):
+        outputs, single, _ = self.bert(encode_hn=True, **_bi_kwargs(kw))
+        sim_mat = single[2]
+        ce_loss = CrossEntropyLoss(ignore_index=-1)
+        logits = sim_mat * self.logit_scale.exp()
+        pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
+        retrieval_loss = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
+        _, pooled, _, hard_pooled = outputs
+        score = self.classifier(self.dropout(torch.cat([pooled, hard_pooled], dim=0)))
+        n = pooled.shape[0]
+        label = torch.cat([torch.ones(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)]).to(score.device)
+        itm_loss = ce_loss(score.view(-1, self.num_labels), label.view(-1))
+        return (retrieval_loss + itm_loss, score, retrieval_loss, itm_loss, label)
+
+    def forward_emb(self, **kw):
+        k = _bi_kwargs(kw)
+        return tuple(self.bert.forward_single(**k))
+
+    def forward_fine(self, **kw):
+        outputs, _, _ = self.bert(encode_hn=False, **_bi_kwargs(kw))
+        return self.classifier(outputs[1])
+
+
+def _cls_loss(self, logits, labels, soft_label):
+    """shared by the VE / VQA wrappers (vl:1777-1797, vl:1849-1869)."""
+    if self.num_labels == 1:
+        return MSELoss()(logits.view(-1), labels.to(torch.float).view(-1))
+    if soft_label:
+        return soft_cross_entropy(labels, logits)
+    if self.loss_type == "kl":
+        log_p = torch.nn.LogSoftmax(dim=-1)(logits.contiguous().view(-1, 3129))
+        return torch.nn.KLDivLoss(reduction="batchmean")(log_p, labels.contiguous())
+    if self.loss_type == "bce":
+        return instance_bce_with_logits(logits, labels)
+    return CrossEntropyLoss()(logits.view(-1, self.num_labels), labels.view(-1))
+
+
+class _FreezeMixin:
+    def freeze_backbone(self):
+        for p in self.bert.parameters():
+            p.requires_grad = False
+
+    def unfreeze_backbone(self):
+        for p in self.bert.parameters():
+            p.requires_grad = True
+
+
+class BiImageBertForSequenceClassification(_FreezeMixin, BertPreTrainedModel):
+    """vl:1715-1798 — VE (and VQA without --use_pretrain)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.num_labels = config.num_labels
+        self.loss_type = config.loss_type
+        self.config = config
+        if config.img_feature_dim <= 0:
+            raise NotImplementedError("text-only BertModel is outside the accelerated path")
+        self.bert = BiBertImgModel(config)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.classifier = _make_classifier(config, self.config.num_labels)
+        self.apply(self.init_weights)
+
+    def reinit_cls_head(self):
+        self.classifier.apply(self.init_weights)
+
+    def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, labels=None, input_ids_b=None,
+                token_type_ids_b=None, attention_mask_b=None, max_tag_length=20, use_b=False,
+                position_ids_a=None, position_ids_b=None, head_mask=None, img_feats=None, soft_label=False):
+        outputs, _, _ = self.bert(input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
+                                  attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats, use_b=use_b,
+                                  input_ids_b=input_ids_b, position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b,
+                                  attention_mask_b=attention_mask_b, max_tag_length=max_tag_length, encode_hn=False)
+        logits = self.classifier(self.dropout(outputs[1]))
+        out = (logits,) + outputs[2:]
+        if labels is not None:
+            out = (_cls_loss(self, logits, labels, soft_label),) + out
+        return out
+
+
+class BiImageBertForVQA(_FreezeMixin, BertPreTrainedModel):
+    """vl:1801-1870 — answer classifier on the raw [CLS] state of the joint encoder."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.num_labels = config.num_labels
+        self.loss_type = config.loss_type
+        self.config = config
+        if config.img_feature_dim <= 0:
+            raise NotImplementedError("text-only BertModel is outside the accelerated path")
+        self.bert = BiBertImgModel(config)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.cls = BertVQAHeads(config)
+        self.apply(self.init_weights)
+
+    def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, labels=None, input_ids_b=None,
+                token_type_ids_b=None, attention_mask_b=None, max_tag_length=20, position_ids_a=None,
+                position_ids_b=None, head_mask=None, img_feats=None, soft_label=False):
+        outputs, _, _ = self.bert(input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
+                                  attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats,
+                                  input_ids_b=input_ids_b, position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b,
+                                  attention_mask_b=attention_mask_b, max_tag_length=max_tag_length, encode_hn=False)
+        logits = self.cls(self.dropout(outputs[0][:, 0]))
+        out = (logits,) + outputs[2:]
+        if labels is not None:
+            out = (_cls_loss(self, logits, labels, soft_label),) + out
+        return out

@@ -1,0 +1,80 @@
+"""Synthetic pre-training batches with the layout `OscarTSVDataset_C.__getitem__` produces
+(oscar/oscar_datasets_ml/oscar_tsv4.py:363-377, convert_example_to_features :896-1092):
+13 tensors per batch, masks prefix-contiguous, phrase ids above `only_word_size`, labels -1 =
+ignore, >= 3 valid regions per image (the WRA top-3 needs them, modeling_vlbert.py:1547).
+"""
+import torch
+
+CLS, SEP, MASK = 101, 102, 103
+
+
+def synthetic_batch(dims, cfg, seed, single_stream=False, fixed_length=False, device=None):
+    """dims: dict(B, T, P, G, R).  cfg: dict with vocab_size, only_word_size, img_feature_dim.
+    fixed_length=True fills every slot (roofline run); otherwise lengths are random."""
+    g = torch.Generator().manual_seed(int(seed))
+    B, T, P, G, R = (dims[k] for k in ("B", "T", "P", "G", "R"))
+    V, W, D = cfg["vocab_size"], cfg["only_word_size"], cfg["img_feature_dim"]
+    lo = 110 if W < 2000 else 1000
+
+    def ri(a, b, size=()):
+        return torch.randint(a, b, size, generator=g)
+
+    La = T if single_stream else T + P
+    img = torch.zeros(B, R, D)
+    ids_a = torch.zeros(B, La, dtype=torch.long)
+    mask_a = torch.zeros(B, La, dtype=torch.long)
+    lab_a = torch.full((B, La), -1, dtype=torch.long)
+    ids_b = torch.zeros(B, G, dtype=torch.long)
+    mask_b = torch.zeros(B, G + R, dtype=torch.long)
+    lab_b = torch.full((B, G + R), -1, dtype=torch.long)
+    phrase_index = torch.zeros(B, 2, dtype=torch.long)
+    image_index = torch.zeros(B, 2, dtype=torch.long)
+    for b in range(B):
+        n_r = R if fixed_length else int(ri(min(3, R), R + 1))
+        feat = torch.randn(n_r, D, generator=g)
+        feat[:, -6:] = torch.rand(n_r, 6, generator=g)
+        img[b, :n_r] = feat
+        max_t = T - 2
+        n_t = max_t if fixed_length else int(ri(min(4, max_t), max_t + 1))
+        n_p = 0 if single_stream else (P if fixed_length else int(ri(0, P + 1)))
+        toks = ri(lo, W, (n_t,))
+        seq = [CLS] + toks.tolist()
+        if n_p:
+            seq += ri(W, V, (n_p,)).tolist()
+        seq.append(SEP)
+        ids_a[b, :len(seq)] = torch.tensor(seq)
+        mask_a[b, :len(seq)] = 1
+        pick = torch.rand(n_t, generator=g) < 0.15
+        if not pick.any():
+            pick[int(ri(0, n_t))] = True
+        for i in torch.nonzero(pick).flatten().tolist():
+            lab_a[b, 1 + i] = toks[i]
+            if torch.rand((), generator=g) < 0.8:
+                ids_a[b, 1 + i] = MASK
+        phrase_index[b] = torch.tensor([1 + n_t, 1 + n_t + n_p])
+        image_index[b] = torch.tensor([La, La + n_r])
+        max_g = G - 2
+        n_g = max_g if fixed_length else int(ri(min(3, max_g), max_g + 1))
+        tags = ri(lo, W, (n_g,))
+        ids_b[b, :n_g + 2] = torch.tensor([CLS] + tags.tolist() + [SEP])
+        mask_b[b, :n_g + 2] = 1
+        mask_b[b, G:G + n_r] = 1
+        pick = torch.rand(n_g, generator=g) < 0.15
+        if not pick.any():
+            pick[int(ri(0, n_g))] = True
+        for i in torch.nonzero(pick).flatten().tolist():
+            lab_b[b, 1 + i] = tags[i]
+            if torch.rand((), generator=g) < 0.8:
+                ids_b[b, 1 + i] = MASK
+    if single_stream:
+        batch = dict(img_feats=img, input_ids=ids_a, input_mask=torch.cat([mask_a, mask_b[:, G:]], 1),
+                     segment_ids=torch.zeros_like(ids_a), lm_label_ids=lab_a, is_next=ri(0, 2, (B,)))
+    else:
+        batch = dict(img_feats=img, input_ids_a=ids_a, input_mask_a=mask_a, segment_ids_a=torch.zeros_like(ids_a),
+                     lm_label_ids_a=lab_a, input_ids_b=ids_b, input_mask_b=mask_b,
+                     segment_ids_b=torch.ones_like(ids_b), lm_label_ids_b=lab_b,
+                     is_next=torch.zeros(B, dtype=torch.long), is_img_match=torch.zeros(B, dtype=torch.long),
+                     phrase_index=phrase_index, image_index=image_index)
+    if device is not None:
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch
