@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py — image-text pairs/s of one MVPTR pre-training step (forward + backward + AdamW,
+gradients all-reduced when N > 1) on MI355X.
+
+Workload = BASELINE.json configs[1]: BiBertImgForPreTraining (the model oscar/run_pretrain_ml.py
+trains), BERT-base, batch 256 per GPU, 70 text tokens + 5 phrase slots, 20 tag slots, 50 regions
+of 2054-d features, all heads (masked-concept, contrastive, MLM, ITM, WRA), dropout 0.1 as in the
+reference config, bf16 MFMA kernels with f32 master weights.  Synthetic data, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §Measurement for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BASE_CFG = dict(vocab_size=86051, only_word_size=30522, hidden_size=768, num_hidden_layers=12,
+                num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12,
+                img_feature_dim=2054, img_feature_type="faster_r-cnn", use_img_layernorm=1,
+                img_layer_norm_eps=1e-12, num_contrast_classes=2, qa_answer_size=10,
+                max_position_embeddings=512, type_vocab_size=2, hidden_act="gelu",
+                initializer_range=0.02, loss_type="ce", num_labels=2,
+                hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_pair(dims, cfg, masked_text_rows, masked_tag_rows):
+    """Algorithmic FLOPs: 2MNK per GEMM, attention 4·L·H per token per layer,
+    backward = 2x forward; elementwise / softmax / LayerNorm not counted."""
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    nl = cfg["num_hidden_layers"] // 2
+    La, Lb = dims["T"] + dims["P"], dims["G"] + dims["R"]
+    Lj = La + dims["R"]
+    per_tok = 2 * (4 * H * H + 2 * H * I)
+
+    def enc(L):
+        return nl * L * (per_tok + 4 * L * H)
+
+    fwd = enc(La) + enc(Lb) + 2 * enc(Lj)
+    fwd += 2 * dims["R"] * cfg["img_feature_dim"] * H
+    fwd += (masked_text_rows + masked_tag_rows) * (2 * H * H + 2 * H * cfg["only_word_size"])
+    return fwd, 3 * fwd
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (CPU restatement of the reference, kind='port') timed on this host at
+    BASELINE.json configs[0] shapes: B=4, 35 tok (+5 phrase slots), 20 tags, 10 regions."""
+    import golden_util as gu
+    from mvp_pytorch_amd.modeling import param_shapes
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    from oracle import mvptr_oracle as orc
+    # small-batch fp32 GEMMs stop scaling (and oversubscribe badly) past a few dozen threads
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    cfg, dims = gu.BASE_CFG, gu.CFG1_DIMS
+    g = torch.Generator().manual_seed(0)
+    sd = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in param_shapes("BiBertImgForPreTraining", cfg).items()}
+    with torch.no_grad():
+        for k in sd:
+            if k.endswith("LayerNorm.weight"):
+                sd[k].fill_(1.0)
+            if k == "logit_scale":
+                sd[k].fill_(2.659)
+    b = synthetic_batch(dims, cfg, 99)
+    state = {}
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 2 or (time.time() < t_end and len(times) < 12):
+        t0 = time.time()
+        res = orc.bi_bert_img_for_pretraining(
+            sd, cfg, b["input_ids_a"], b["segment_ids_a"], b["input_mask_a"], b["lm_label_ids_a"],
+            b["input_ids_b"], b["segment_ids_b"], b["input_mask_b"], b["lm_label_ids_b"], dims["G"],
+            b["img_feats"], b["image_index"], b["phrase_index"])
+        res[0].backward()
+        with torch.no_grad():
+            grads = {k: v.grad for k, v in sd.items() if v.grad is not None}
+            params = {k: v.data for k, v in sd.items()}
+            orc.adamw_step(params, grads, state, lr=5e-5, eps=1e-8, weight_decay=0.01)
+            for v in sd.values():
+                v.grad = None
+        times.append(time.time() - t0)
+    steady = sorted(times[1:])
+    med = steady[len(steady) // 2]
+    return dict(value=round(dims["B"] / med, 3), unit="pairs/s", cores=cores, kind="port",
+                sample="%d warm steps of the CPU oracle (fp32 torch, fwd+bwd+AdamW), B=4, 35 tok+5 phrase, 20 tags, 10 regions; median %.3f s/step"
+                       % (len(steady), med))
+
+
+def kernel_roofline(dev, dims, cfg):
+    """Dominant kernel = gemm_nt_kernel<EPI_BIAS_GELU> (BertIntermediate, 768->3072): replay
+    its per-step launch mix (6 layers x {txt, vis, joint, hard}) and time it with HIP events on
+    the launch stream."""
+    from mvp_pytorch_amd import hip
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    B = dims["B"]
+    Ls = [dims["T"] + dims["P"], dims["G"] + dims["R"], dims["T"] + dims["P"] + dims["R"], dims["T"] + dims["P"] + dims["R"]]
+    w = torch.randn(I, H, device=dev).to(torch.bfloat16)
+    bias = torch.zeros(I, device=dev)
+    xs = [torch.randn(B * L, H, device=dev).to(torch.bfloat16) for L in Ls]
+    outs = [(torch.empty(B * L, I, device=dev, dtype=torch.bfloat16), torch.empty(B * L, I, device=dev, dtype=torch.bfloat16)) for L in Ls]
+    for x, (u, a) in zip(xs, outs):
+        hip.gemm_nt(x, w, hip.EPI_BIAS_GELU, bias=bias, out=u, out1=a)
+    torch.cuda.synchronize()
+    reps, n = 6, 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for x, (u, a) in zip(xs, outs):
+            hip.gemm_nt(x, w, hip.EPI_BIAS_GELU, bias=bias, out=u, out1=a)
+            n += 1
+    e1.record()
+    torch.cuda.synchronize()
+    avg_ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * (B * sum(Ls) / len(Ls)) * I * H
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI_BIAS_GELU> (M=B*L, N=3072, K=768)", achieved=round(ach, 1),
+                peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                avg_launch_us=round(avg_ms * 1e3, 1), traffic=None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-length", action="store_true", help="every token/region slot valid")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP encoder has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mvp_pytorch_amd import dp, hip, modeling, train
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    hip.load()
+    dims = dict(B=args.batch, T=70, P=5, G=20, R=50)
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = modeling.BiBertImgForPreTraining(modeling.make_config(BASE_CFG)).to(dev)
+    model.train()
+    opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
+    sync = dp.GradSync(model) if world > 1 else None
+    batch = synthetic_batch(dims, BASE_CFG, 1234 + rank, fixed_length=args.fixed_length, device=dev)
+    n_text = int((batch["lm_label_ids_a"] > -1).sum().item())
+    n_tag = int((batch["lm_label_ids_b"] > -1).sum().item())
+
+    def step():
+        return train.pretrain_step(model, batch, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    if rank == 0:
+        fwd, fb = flops_per_pair(dims, BASE_CFG, n_text / args.batch, n_tag / args.batch)
+        step_tflops = fb * args.batch / (ms_per_step * 1e-3) / 1e12
+        roof = kernel_roofline(dev, dims, BASE_CFG)
+        roof["step_achieved"] = round(step_tflops, 1)
+        roof["step_frac"] = round(step_tflops / MFMA_BF16_PEAK_TFLOPS, 4)
+        roof["flops_per_pair_fwd_bwd"] = fb
+        out = {
+            "metric": "image-text pairs/s (pre-train step, BERT-base, 70tok+50region)",
+            "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: BiBertImgForPreTraining BERT-base, %d pairs/GPU, "
+                                   "70 tok + 5 phrase slots, 20 tag slots, 50 regions x 2054-d, MLM+MCP+ITM+contrastive+WRA, "
+                                   "dropout 0.1, AdamW, bf16 MFMA / f32 master weights" % args.batch,
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "final_loss": round(float(loss.item()), 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,12 +132,15 @@ int mvptr_layernorm_fwd(const void* z, const float* gamma, const float* beta, fl
  * dz: bf16 [M,H] gradient wrt z.  dd: bf16 [M,H] = dz with `dense_drop` applied (gradient wrt
  * the dense output that was dropped out before the residual add; element index m*H+c);
  * dd may be NULL when dense_drop is NULL/disabled (then dd == dz).
- * dgamma/dbeta/dbias: f32 [H], accumulated with atomics (dbias = colsum(dd), may be NULL). */
+ * dgamma/dbeta/dbias: f32 [H], accumulated into (dbias = colsum(dd); each may be NULL).
+ * ws: scratch of mvptr_layernorm_bwd_ws_bytes(M, H) bytes (per-workgroup column partials, summed
+ * by a second tiny kernel: one contended atomic row would serialise at ~0.09 TB/s on MI355X). */
+int64_t mvptr_layernorm_bwd_ws_bytes(int M, int H);
 int mvptr_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
                         const float* gamma, void* dz, void* dd, float* dgamma, float* dbeta,
                         float* dbias, int M, int H, int rows_per_group, int group_stride,
                         int row_offset, const mvptr_dropout* y_drop,
-                        const mvptr_dropout* dense_drop, void* stream);
+                        const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes, void* stream);
 
 /* Embedding gather + add: z[r, :] = word[ids[r]] + pos[pos_ids[r]] + type[type_ids[r]] (bf16 out).
  * Replaces BertEmbeddings.forward modeling_bert.py:268-273 (LayerNorm + dropout follow through

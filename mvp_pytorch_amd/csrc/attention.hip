@@ -51,24 +51,49 @@ __device__ __forceinline__ void stage_tile(char* tile, const __bf16* src, int64_
   }
 }
 
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, chunk));
-}
-
-// transposed fragment: element j <- tile[row0 + 8*(j>>2) + (j&3)][col] for this lane's column
-// (col = 32*db + 16*cb + (lane&15)); row0 already includes the lane half's +4*hh.
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int db, int lane) {
+// The swizzle only looks at row bits 1..3, so for the two access shapes of these kernels the
+// swizzled part of the address is a per-lane constant and the block index adds a multiple of
+// 4 KiB (32 rows): offsets are computed once per lane instead of per fragment.
+struct LaneOffs {
+  uint32_t rowf[4];     // row_frag(32*blk + (lane&31), 2*ks + (lane>>5)) - blk*4096, ks = 0..3
+  uint32_t trf[2][2];   // tr_frag row0 = 32*blk + 16*st + 4*(lane>>5): [db][lo/hi], minus (32*blk+16*st)*128
+};
+__device__ __forceinline__ LaneOffs make_lane_offs(int lane) {
+  LaneOffs o;
+  const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) o.rowf[ks] = tile_off(l31, 2 * ks + hh);
   const int i16 = lane & 15, cb = (lane >> 4) & 1;
   const int q = i16 >> 2, pp = i16 & 3;
-  const int ch = db * 4 + cb * 2 + (pp >> 1);
-  const uint32_t o0 = tile_off(row0 + q, ch) + 8 * (pp & 1);
-  const uint32_t o1 = tile_off(row0 + 8 + q, ch) + 8 * (pp & 1);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const int ch = db * 4 + cb * 2 + (pp >> 1);
+    o.trf[db][0] = tile_off(4 * hh + q, ch) + 8 * (pp & 1);
+    o.trf[db][1] = tile_off(4 * hh + 8 + q, ch) + 8 * (pp & 1);
+  }
+  return o;
+}
+__device__ __forceinline__ bf16x8 row_frag_o(const char* tile, const LaneOffs& o, int blk, int ks) {
+  return *reinterpret_cast<const bf16x8*>(tile + blk * 4096 + o.rowf[ks]);
+}
+// blk16 = 2*blk + st (16-row granularity)
+__device__ __forceinline__ bf16x8 tr_frag_o(const char* tile, const LaneOffs& o, int blk16, int db) {
+  const char* base = tile + blk16 * 2048;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + o0));
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(base + o.trf[db][0]));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + o1));
+      (__attribute__((address_space(3))) s16x4*)LDS_PTR(base + o.trf[db][1]));
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
+}
+// 16 per-row f32 values of a 32-row block in accumulator-register order (4 x ds_read_b128)
+__device__ __forceinline__ void load_rows16(const float* v, int blk, int hh, float out[16]) {
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(v + 32 * blk + 8 * t4 + 4 * hh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[4 * t4 + e] = x[e];
+  }
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
@@ -113,21 +138,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
   const int l31 = lane & 31, hh = lane >> 5;
   const int nb = Lp >> 5;
+  const LaneOffs lo_ = make_lane_offs(lane);
   for (int qb = wave; qb < nb; qb += 4) {
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_frag(tQ, 32 * qb + l31, 2 * ks + hh);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = row_frag_o(tQ, lo_, qb, ks);
     // pass 1: running max / sum of this lane's query column
     float m_run = -1e30f, l_run = 0.f;
     for (int kb = 0; kb < nb; ++kb) {
       f32x16 st = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], st, 0, 0, 0);
-      float bm = -1e30f;
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tK, lo_, kb, ks), qf[ks], st, 0, 0, 0);
+      float bm = -1e30f, mk[16];
+      load_rows16(maskv, kb, hh, mk);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        st[r] = st[r] * 0.125f + maskv[32 * kb + acc_row(r, hh)];
+        st[r] = st[r] * 0.125f + mk[r];
         bm = fmaxf(bm, st[r]);
       }
       const float m_new = fmaxf(m_run, bm);
@@ -153,11 +180,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       f32x16 st = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tK, lo_, kb, ks), qf[ks], st, 0, 0, 0);
+      float mk[16];
+      load_rows16(maskv, kb, hh, mk);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * kb + acc_row(r, hh);
-        float pv = __expf(st[r] * 0.125f + maskv[key] - lse);
+        float pv = __expf(st[r] * 0.125f + mk[r] - lse);
         if (p.drop.thresh16 != 0)
           pv = drop_apply(p.drop, ((uint64_t)bh * L + q) * (uint64_t)L + key, pv);
         st[r] = pv;
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         const bf16x8 pb = pack8(st, s);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tV, 32 * kb + 16 * s + 4 * hh, db, lane), pb, o[db], 0, 0, 0);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tV, lo_, 2 * kb + s, db), pb, o[db], 0, 0, 0);
       }
     }
     if (q < L) {
@@ -229,16 +258,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
   const int l31 = lane & 31, hh = lane >> 5;
   const int nb = Lp >> 5;
+  const LaneOffs lo_ = make_lane_offs(lane);
   __bf16* dq_base = p.dqkv + (int64_t)b * L * ldq + hd * 64;
 
   // ---------------- pass A: waves own key blocks; key on lane, query in registers
   for (int kb = wave; kb < nb; kb += 4) {
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = row_frag(tK, 32 * kb + l31, 2 * ks + hh);
-      vf[ks] = row_frag(tV, 32 * kb + l31, 2 * ks + hh);
-    }
     const int key = 32 * kb + l31;
     const float mk = maskv[key];
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
@@ -246,30 +270,36 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tQ, 32 * qb + l31, 2 * ks + hh), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tD, 32 * qb + l31, 2 * ks + hh), vf[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tQ, lo_, qb, ks), row_frag_o(tK, lo_, kb, ks), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tD, lo_, qb, ks), row_frag_o(tV, lo_, kb, ks), dp, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = 32 * qb + acc_row(r, hh);
-        const float pr = __expf(s[r] * 0.125f + mk - lsev[q]);
-        float pd = pr, dpp = dp[r];
-        if (p.drop.thresh16 != 0) {
-          const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
-          pd = keep ? pr * p.drop.scale : 0.f;
-          dpp = keep ? dpp * p.drop.scale : 0.f;
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lsev + 32 * qb + 8 * t4 + 4 * hh);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(deltav + 32 * qb + 8 * t4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * t4 + e;
+          const int q = 32 * qb + 8 * t4 + 4 * hh + e;
+          const float pr = __expf(s[r] * 0.125f + mk - ls4[e]);
+          float pd = pr, dpp = dp[r];
+          if (p.drop.thresh16 != 0) {
+            const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
+            pd = keep ? pr * p.drop.scale : 0.f;
+            dpp = keep ? dpp * p.drop.scale : 0.f;
+          }
+          s[r] = pd;                        // dropped-out probabilities (for dV)
+          dp[r] = pr * (dpp - dl4[e]);      // dS
         }
-        s[r] = pd;                         // dropped-out probabilities (for dV)
-        dp[r] = pr * (dpp - deltav[q]);    // dS
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
         const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
-        const int row0 = 32 * qb + 16 * st + 4 * hh;
+        const int blk16 = 2 * qb + st;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tD, row0, db, lane), pb, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tQ, row0, db, lane), dsb, dk[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tD, lo_, blk16, db), pb, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tQ, lo_, blk16, db), dsb, dk[db], 0, 0, 0);
         }
       }
     }
@@ -292,12 +322,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
   // ---------------- pass B: waves own query blocks; query on lane, key in registers
   for (int qb = wave; qb < nb; qb += 4) {
-    bf16x8 qf[4], dof[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = row_frag(tQ, 32 * qb + l31, 2 * ks + hh);
-      dof[ks] = row_frag(tD, 32 * qb + l31, 2 * ks + hh);
-    }
     const int q = 32 * qb + l31;
     const float ls = lsev[q], dl = deltav[q];
     f32x16 dq[2] = {zero16(), zero16()};
@@ -305,13 +329,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tK, 32 * kb + l31, 2 * ks + hh), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(tV, 32 * kb + l31, 2 * ks + hh), dof[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tK, lo_, kb, ks), row_frag_o(tQ, lo_, qb, ks), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tV, lo_, kb, ks), row_frag_o(tD, lo_, qb, ks), dp, 0, 0, 0);
       }
+      float mk16[16];
+      load_rows16(maskv, kb, hh, mk16);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = 32 * kb + acc_row(r, hh);
-        const float pr = __expf(s[r] * 0.125f + maskv[key] - ls);
+        const float pr = __expf(s[r] * 0.125f + mk16[r] - ls);
         float dpp = dp[r];
         if (p.drop.thresh16 != 0) {
           const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
@@ -324,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         const bf16x8 dsb = pack8(s, st);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tK, 32 * kb + 16 * st + 4 * hh, db, lane), dsb, dq[db], 0, 0, 0);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tK, lo_, 2 * kb + st, db), dsb, dq[db], 0, 0, 0);
       }
     }
     if (q < L) {

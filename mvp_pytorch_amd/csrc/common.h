@@ -75,13 +75,26 @@ __device__ __forceinline__ float drop_apply(const DropDev& d, uint64_t idx, floa
   return (mvptr_rand16(idx, d.seed_lo, d.seed_hi) >= d.thresh16) ? v * d.scale : 0.f;
 }
 
+// erf-GELU (modeling_bert.py:142-148) through erfc(z) = poly(t) * exp(-z^2), t = 1/(1 + p z)
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7): one v_exp_f32 + one v_rcp_f32 instead of the
+// libm erff call; the same exp(-x^2/2) also gives the normal pdf for the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf2, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float pe = poly * e;            // erfc(z)
+  cdf2 = (x < 0.f) ? pe : 2.0f - pe;    // 1 + erf(x / sqrt(2))
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float cdf2, e;
+  gelu_parts(x, cdf2, e);
+  return 0.5f * x * cdf2;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf2, e;
+  gelu_parts(x, cdf2, e);
+  return 0.5f * cdf2 + x * e * 0.39894228040143267794f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -5,19 +5,50 @@
 // :394-397 (dense+gelu :142-148), :407-411, oscar/modeling/modeling_vlbert.py:71-73 (Q/K/V),
 // and the data-gradient GEMMs autograd derives from them.
 //
-// CDNA4 design: 128x128x64 tile per 256-thread workgroup (4 waves as 2x2, each 64x64 =
-// 4x4 v_mfma_f32_16x16x32_bf16 tiles), operands staged HBM -> LDS with buffer_load ... lds
-// (16 B per lane, no VGPR round trip), double buffered, XOR-swizzled 128-B rows so every
-// ds_read_b128 fragment read is bank-conflict free, XCD-aware tile order.  Out-of-range
-// rows / K tail come back as zeros from the buffer bounds check.
-// The MFMA is issued with the weight tile as the A operand and the activation tile as the
-// B operand, so a lane ends up with 4 consecutive output columns of one row (8-byte stores).
+// CDNA4 design
+//  * 256(M) x 128(N) x 64(K) tile per 512-thread workgroup: 8 waves as 4(M) x 2(N), each wave a
+//    64x64 block = 4x4 v_mfma_f32_16x16x32_bf16 tiles (64 accumulator registers).
+//  * operands go HBM/L2 -> LDS with buffer_load ... lds (16 B per lane, no VGPR round trip);
+//    out-of-range rows and the K tail come back as zeros from the buffer bounds check.
+//  * 3-stage LDS ring (3 x 48 KiB): two K-steps stay in flight across the barrier behind a
+//    counted s_waitcnt vmcnt(6) + raw s_barrier (a __syncthreads() would drain them).  With the
+//    short K of this model (768..3072) a one-deep prefetch is pure load latency.
+//  * 128-byte LDS rows, 16-byte chunks XOR-swizzled (chunk ^= (row>>1)&7): every ds_read_b128
+//    fragment read is bank-conflict free; the swizzle is applied on the per-lane SOURCE address
+//    (the LDS-DMA destination is lane-linear) and on the read.
+//  * tile order: bijective XCD remap, then groups of 4 row-tiles x all column tiles, so the 32
+//    workgroups that share an XCD's L2 work on a 4 x 8 patch of tiles (A and B panels L2 resident).
+//  * the weight tile is the MFMA A operand and the activation tile the B operand, so a lane holds
+//    4 consecutive output columns; the epilogue restages the wave's 64x64 f32 block through LDS
+//    and finishes in row-chunk form (8 consecutive columns per lane): 16-byte bias / residual
+//    loads and 16-byte coalesced stores.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BM = 256, BN = 128, STAGES = 3;
+constexpr int ST_LD = 68;  // f32 row stride of the epilogue staging block
+constexpr int GROUP_M = 4;
+// BK = 64: 3 x 48 KiB ring, one workgroup per CU.  BK = 32: 3 x 24 KiB ring, two workgroups per
+// CU, so one workgroup's epilogue (stores) overlaps the other's MFMA main loop.
+template <int BK>
+struct Cfg {
+  static constexpr int A_BYTES = BM * BK * 2;
+  static constexpr int B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int ROW_B = BK * 2;             // bytes per LDS row
+  static constexpr int CHUNKS = BK / 8;            // 16-byte chunks per row
+  static constexpr int ROWS_PER_INSTR = 1024 / ROW_B;
+  static constexpr int NA = BM / ROWS_PER_INSTR / 8;  // A staging instructions per wave
+  static constexpr int NB = BN / ROWS_PER_INSTR / 8;  // B staging instructions per wave
+  static constexpr int KS = BK / 32;               // MFMA k-substeps per stage
+};
+// chunk swizzles that make the 16x16x32 ds_read_b128 fragment reads conflict free
+__device__ __forceinline__ int swz_row(int row, int chunks) {
+  return chunks == 8 ? ((row >> 1) & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3);  // LUT {0,2,3,1}
+}
 
 struct GemmNtArgs {
   const __bf16* A;
@@ -33,45 +64,31 @@ struct GemmNtArgs {
   float* vec_out;
   DropDev drop;
   int tiles_m, tiles_n;
-  int vec_store;  // ldc % 4 == 0 and 8-byte aligned bases: packed stores allowed
+  int vec_out_ok;   // 16-byte stores allowed on out0/out1
+  int vec_aux_ok;   // 16-byte loads allowed on aux
+  int vec_bias_ok;  // 16-byte loads allowed on bias
 };
 
-__device__ __forceinline__ void store_bf16x4(__bf16* base, int64_t ld, int m, int n, int N,
-                                             bool vec, const float v[4]) {
-  __bf16* p = base + (int64_t)m * ld + n;
-  if (vec && n + 3 < N) {
-    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    *reinterpret_cast<bf16x4*>(p) = o;
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (n + r < N) p[r] = f2bf(v[r]);
-  }
-}
+extern __shared__ __attribute__((aligned(1024))) char lds[];
 
-__device__ __forceinline__ void load_bf16x4(const __bf16* base, int64_t ld, int m, int n, int N,
-                                            bool vec, float v[4]) {
-  const __bf16* p = base + (int64_t)m * ld + n;
-  if (vec && n + 3 < N) {
-    bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = bf2f(o[r]);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (n + r < N) ? bf2f(p[r]) : 0.f;
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_BYTES];
+template <int EPI, int BK>
+__global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs p) {
+  using C = Cfg<BK>;
+  constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, ROW_B = C::ROW_B, CHUNKS = C::CHUNKS;
+  constexpr int RPI = C::ROWS_PER_INSTR, NA = C::NA, NB = C::NB, KS = C::KS;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = p.tiles_m * p.tiles_n;
   const int t = xcd_remap(blockIdx.x, nwg);
-  const int tm = t / p.tiles_n;
-  const int tn = t - tm * p.tiles_n;
+  // grouped order: GROUP_M row-tiles x all column tiles, row-tile fastest
+  const int gsz = GROUP_M * p.tiles_n;
+  const int grp = t / gsz;
+  const int first_m = grp * GROUP_M;
+  const int gm = min(GROUP_M, p.tiles_m - first_m);
+  const int in_g = t - grp * gsz;
+  const int tm = first_m + in_g % gm;
+  const int tn = in_g / gm;
   const int m0 = tm * BM, n0 = tn * BN;
   const int rows_a = min(BM, p.M - m0);
   const int rows_b = min(BN, p.N - n0);
@@ -81,46 +98,50 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
   const __amdgpu_buffer_rsrc_t rsB =
       make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
 
-  // staging: instruction i of this wave fills LDS rows (i*4+wave)*8 .. +8 of a tile
-  // (1 KiB, lane-linear); lane -> (row, physical chunk); logical chunk = phys ^ swz(row)
-  uint32_t offA[4], offB[4];
-  int kc[4];
+  // staging: a wave instruction fills RPI LDS rows (1 KiB, lane-linear); NA per wave for A, NB for B
+  uint32_t offA[NA], offB[NB];
+  int kcA[NA], kcB[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    kc[i] = c * 8;
+  for (int i = 0; i < NA; ++i) {
+    const int row = (i * 8 + wave) * RPI + lane / CHUNKS;
+    const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
+    kcA[i] = c * 8;
     offA[i] = (uint32_t)(row * p.lda * 2 + c * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (i * 8 + wave) * RPI + lane / CHUNKS;
+    const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
+    kcB[i] = c * 8;
     offB[i] = (uint32_t)(row * p.ldb * 2 + c * 16);
   }
   auto stage = [&](int buf, int k0) {
-    char* la = lds + buf * 2 * TILE_BYTES;
-    char* lb = la + TILE_BYTES;
+    char* la = lds + buf * STAGE_BYTES;
+    char* lb = la + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool kok = (k0 + kc[i]) < p.K;
-      const uint32_t va = kok ? offA[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
-      const uint32_t vb = kok ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 4 + wave) * 1024), 16, va,
-                                               0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 4 + wave) * 1024), 16, vb,
-                                               0, 0, 0);
+    for (int i = 0; i < NA; ++i) {
+      const uint32_t va = (k0 + kcA[i] < p.K) ? offA[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 8 + wave) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const uint32_t vb = (k0 + kcB[i] < p.K) ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 8 + wave) * 1024), 16, vb, 0, 0, 0);
     }
   };
 
   const int wm = wave >> 1, wn = wave & 1;
   const int c16 = lane & 15, q4 = lane >> 4;
-  // fragment read byte offsets inside a tile (per mt / nt, ks)
-  uint32_t fx[4][2], fw[4][2];
+  uint32_t fx[4][KS], fw[4][KS];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rx = wm * 64 + i * 16 + c16;
     const int rw = wn * 64 + i * 16 + c16;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int ch = ks * 4 + q4;
-      fx[i][ks] = rx * 128 + ((ch ^ ((rx >> 1) & 7)) << 4);
-      fw[i][ks] = rw * 128 + ((ch ^ ((rw >> 1) & 7)) << 4);
+      fx[i][ks] = rx * ROW_B + ((ch ^ swz_row(rx, CHUNKS)) << 4);
+      fw[i][ks] = rw * ROW_B + ((ch ^ swz_row(rw, CHUNKS)) << 4);
     }
   }
 
@@ -132,14 +153,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 
   const int nk = (p.K + BK - 1) / BK;
   stage(0, 0);
+  if (nk > 1) stage(1, BK);
+  int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    const char* la = lds + (kt & 1) * 2 * TILE_BYTES;
-    const char* lb = la + TILE_BYTES;
+    // stage kt has landed once at most the NA+NB loads of stage kt+1 remain in flight
+    if (kt + 1 < nk) {
+      if (NA + NB == 6)
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (kt + 2 < nk) {
+      int nb = buf + 2;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, (kt + 2) * BK);
+    }
+    const char* la = lds + buf * STAGE_BYTES;
+    const char* lb = la + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 xf[4], wf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -152,109 +186,172 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
         for (int mt = 0; mt < 4; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
     }
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
 
   // ------------------------------------------------------------------ epilogue
-  const bool vec = p.vec_store != 0;
+  __syncthreads();  // every wave is done with the operand ring
+  // the wave's 64x64 f32 block is restaged in two 32-row halves (fits the 72-KiB BK=32 ring)
+  float* st = reinterpret_cast<float*>(lds) + wave * (32 * ST_LD);
+
+  const int ch = lane & 7, rsub = lane >> 3;
+  const int n = n0 + wn * 64 + ch * 8;
+  const bool nfull = (n + 7 < p.N);
+  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr && n < p.N) {
+    if (nfull && p.vec_bias_ok) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int n = n0 + wn * 64 + nt * 16 + q4 * 4;
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD) {
-      if (p.bias != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) b4[r] = p.bias[n + r];
+      for (int e = 0; e < 4; ++e) {
+        b8[e] = b0[e];
+        b8[4 + e] = b1[e];
       }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) b8[e] = p.bias[n + e];
     }
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto store_bf8 = [&](void* base, int m, const float v[8]) {
+    __bf16* op = (__bf16*)base + (int64_t)m * p.ldc + n;
+    if (nfull && p.vec_out_ok) {
+      bf16x8 o;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + c16;
-      const bool mok = (m < p.M) && (n < p.N);
-      float v[4];
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x8*>(op) = o;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r] + b4[r];
-      if (EPI == MVPTR_EPI_BIAS) {
-        if (mok) store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-      } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-        if (mok) {
-          store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-          float g[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) g[r] = gelu_erf(bf2f(f2bf(v[r])));
-          store_bf16x4((__bf16*)p.out1, p.ldc, m, n, p.N, vec, g);
-        }
-      } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-        if (mok) {
-          float a[4];
-          load_bf16x4(p.aux, p.ld_aux, m, n, p.N, vec, a);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            v[r] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), v[r]) + a[r];
-          store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-        }
-      } else if (EPI == MVPTR_EPI_GELU_BWD) {
-        if (mok) {
-          float a[4];
-          load_bf16x4(p.aux, p.ld_aux, m, n, p.N, vec, a);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = bf2f(f2bf(v[r] * gelu_erf_grad(a[r])));
-            cs[r] += v[r];
-          }
-          store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-        }
-      } else if (EPI == MVPTR_EPI_ADD) {
-        if (mok) {
-          if (p.aux != nullptr) {
-            float a[4];
-            load_bf16x4(p.aux, p.ld_aux, m, n, p.N, vec, a);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += a[r];
-          }
-          store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-        }
-      } else if (EPI == MVPTR_EPI_F32) {
-        if (mok) {
-          float* o = (float*)p.out0 + (int64_t)m * p.ldc + n;
-          if (vec && n + 3 < p.N) {
-            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < p.N) o[r] = v[r];
-          }
-        }
-      } else if (EPI == MVPTR_EPI_BIAS_TANH) {
-        if (mok) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-          store_bf16x4((__bf16*)p.out0, p.ldc, m, n, p.N, vec, v);
-        }
-      }
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) op[e] = f2bf(v[e]);
     }
-    if (EPI == MVPTR_EPI_GELU_BWD && p.vec_out != nullptr) {
-      // reduce the 16 rows held by lanes with equal q4 (xor over the low 4 lane bits)
+  };
+
+  // all residual / pre-activation rows of this lane are requested before any is consumed, so the
+  // epilogue pays one memory latency, not eight
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+  const bool has_aux = kNeedsAux && p.aux != nullptr;
+  bf16x8 auxv[8];
+  if (kNeedsAux) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = cs[r];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        if (c16 == 0 && n + r < p.N) atomicAdd(p.vec_out + n + r, s);
+    for (int it = 0; it < 8; ++it) {
+      const int m = m0 + wm * 64 + it * 8 + rsub;
+      bf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
+      if (has_aux && m < p.M && n < p.N) {
+        const __bf16* ap = p.aux + (int64_t)m * p.ld_aux + n;
+        if (nfull && p.vec_aux_ok) {
+          x = *reinterpret_cast<const bf16x8*>(ap);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) x[e] = ap[e];
+        }
       }
+      auxv[it] = x;
+    }
+  }
+
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    if ((it & 3) == 0) {
+      const int half = it >> 2;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+          *reinterpret_cast<f32x4*>(st + (mh * 16 + c16) * ST_LD + nt * 16 + q4 * 4) = acc[nt][2 * half + mh];
+    }
+    const int row = it * 8 + rsub;
+    const int lrow = row & 31;
+    const int m = m0 + wm * 64 + row;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8 + 4);
+    if (m >= p.M || n >= p.N) continue;
+    float v[8], a[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = v0[e] + b8[e];
+      v[4 + e] = v1[e] + b8[4 + e];
+    }
+    if (kNeedsAux) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it][e]);
+    }
+    if (EPI == MVPTR_EPI_BIAS) {
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_BIAS_GELU) {
+      store_bf8(p.out0, m, v);
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = gelu_erf(bf2f(f2bf(v[e])));
+      store_bf8(p.out1, m, g);
+    } else if (EPI == MVPTR_EPI_BIAS_RESID) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]) + a[e];
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_GELU_BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = bf2f(f2bf(v[e] * gelu_erf_grad(a[e])));
+        if (n + e < p.N) cs[e] += v[e];
+      }
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_F32) {
+      float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
+      if (nfull && p.vec_out_ok) {
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) op[e] = v[e];
+      }
+    } else if (EPI == MVPTR_EPI_BIAS_TANH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      store_bf8(p.out0, m, v);
+    }
+  }
+  if (EPI == MVPTR_EPI_GELU_BWD && p.vec_out != nullptr) {
+    // sum the 8 row-lanes (lane>>3) that share a column chunk, then one atomic per column
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = cs[e];
+      s += __shfl_xor(s, 8);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (rsub == 0 && n + e < p.N) atomicAdd(p.vec_out + n + e, s);
     }
   }
 }
 
-template <int EPI>
-int launch(const GemmNtArgs& a, hipStream_t s) {
+template <int EPI, int BK>
+int launch_bk(const GemmNtArgs& a, hipStream_t s) {
+  constexpr int LDS_BYTES = Cfg<BK>::LDS_BYTES;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(nwg), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK>), dim3(nwg), dim3(512), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
+}
+
+template <int EPI>
+int launch(const GemmNtArgs& a, hipStream_t s) {
+  // MVPTR_GEMM_BK=64 selects the one-workgroup-per-CU variant (tuning knob, default 32)
+  const char* env = getenv("MVPTR_GEMM_BK");
+  if (env != nullptr && env[0] == '6') return launch_bk<EPI, 64>(a, s);
+  return launch_bk<EPI, 32>(a, s);
 }
 
 }  // namespace
@@ -270,7 +367,7 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt: A and B must be 16-byte aligned");
   if (lda < K || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: lda/ldb smaller than K");
-  if ((int64_t)128 * lda * 2 >= (int64_t)0x7fffffff || (int64_t)128 * ldb * 2 >= (int64_t)0x7fffffff)
+  if ((int64_t)BM * lda * 2 >= (int64_t)0x7fffffff || (int64_t)BN * ldb * 2 >= (int64_t)0x7fffffff)
     MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
   if (out0 == nullptr) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: out0 is NULL");
   GemmNtArgs a;
@@ -292,10 +389,12 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.tiles_m = (M + BM - 1) / BM;
   a.tiles_n = (N + BN - 1) / BN;
   const int esz = (epilogue == MVPTR_EPI_F32) ? 4 : 2;
-  bool vec = (ldc % 4 == 0) && (((uintptr_t)out0 % (4 * esz)) == 0);
-  if (out1) vec = vec && (((uintptr_t)out1 & 7) == 0);
-  if (aux) vec = vec && (ld_aux % 4 == 0) && (((uintptr_t)aux & 7) == 0);
-  a.vec_store = vec ? 1 : 0;
+  bool vo = (ldc % 8 == 0) && (((uintptr_t)out0 & 15) == 0);
+  if (out1) vo = vo && (((uintptr_t)out1 & 15) == 0);
+  (void)esz;
+  a.vec_out_ok = vo ? 1 : 0;
+  a.vec_aux_ok = (aux && (ld_aux % 8 == 0) && (((uintptr_t)aux & 15) == 0)) ? 1 : 0;
+  a.vec_bias_ok = (bias && (((uintptr_t)bias & 15) == 0)) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case MVPTR_EPI_BIAS:

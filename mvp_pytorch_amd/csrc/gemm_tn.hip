@@ -6,16 +6,18 @@
 // CDNA4 design: the reduction index (token row m) is the ROW of both row-major operands, so
 // the MFMA fragments are fetched with the gfx950 transposed LDS read ds_read_b64_tr_b16 from
 // row-major 64x128 tiles (256-B rows, XOR swizzle that is conflict free for these reads).
-// 128(n) x 128(k) output tile per 256-thread workgroup, 4 waves as 2x2, each 64x64 = 2x2
-// v_mfma_f32_32x32x16_bf16; tiles staged with buffer_load ... lds, double buffered.
+// 256(n) x 128(k) output tile per 512-thread workgroup, 8 waves as 4x2, each 64x64 = 2x2
+// v_mfma_f32_32x32x16_bf16; tiles staged with buffer_load ... lds into a 3-stage ring.
 // M is split across blockIdx.y; partial sums are added with f32 atomics whose wave
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
 
 namespace {
 
-constexpr int TN_ = 128, TK_ = 128, TM_ = 64;
-constexpr int TILE_B = TM_ * 256;  // 16 KiB
+constexpr int TN_ = 256, TK_ = 128, TM_ = 64, STAGES = 3;
+constexpr int SUB_B = TM_ * 256;            // one 64 x 128 bf16 sub-tile: 16 KiB
+constexpr int STAGE_B = 3 * SUB_B;          // A = 2 sub-tiles (256 n), B = 1 sub-tile (128 k)
+constexpr int LDS_B = STAGES * STAGE_B;     // 144 KiB
 
 struct GemmTnArgs {
   const __bf16* A;
@@ -39,8 +41,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, uint32_t off_lo, uin
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
-  __shared__ __attribute__((aligned(1024))) char lds[4 * TILE_B];
+extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+// 256(n) x 128(k) output tile per 512-thread workgroup (8 waves as 4(n) x 2(k), each 64x64 =
+// 2x2 v_mfma_f32_32x32x16_bf16), 64 token rows per step, 3-stage LDS ring with a counted
+// vmcnt(6) + raw s_barrier (two steps in flight).
+__global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,32 +70,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
   const __amdgpu_buffer_rsrc_t rsB = make_rsrc(
       p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
 
-  // staging: instruction i of this wave fills LDS rows (i*4+wave)*4 .. +4 (1 KiB)
-  uint32_t offA[4], offB[4];
+  // staging: a wave instruction fills 4 LDS rows (1 KiB) of a 64x128 sub-tile
+  uint32_t offA[4], offB[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wave) * 4 + (lane >> 4);
+    const int j = i * 8 + wave;  // 0..31: sub-tile j>>4, row group j&15
+    const int row = (j & 15) * 4 + (lane >> 4);
     const int ch = (lane & 15) ^ swz256(row);
-    offA[i] = (ch * 8 < ncols) ? (uint32_t)(row * p.lda * 2 + ch * 16) : MVPTR_OOB;
+    const int col = (j >> 4) * 128 + ch * 8;
+    offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = i * 8 + wave;  // 0..15
+    const int row = j * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ swz256(row);
     offB[i] = (ch * 8 < kcols) ? (uint32_t)(row * p.ldb * 2 + ch * 16) : MVPTR_OOB;
   }
   auto stage = [&](int buf, int mrow0) {
-    char* la = lds + buf * 2 * TILE_B;
-    char* lb = la + TILE_B;
+    char* la = lds + buf * STAGE_B;
+    char* lb = la + 2 * SUB_B;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)(mrow0 * p.lda * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 8 + wave) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
       const uint32_t vb = (offB[i] == MVPTR_OOB) ? MVPTR_OOB : offB[i] + (uint32_t)(mrow0 * p.ldb * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 4 + wave) * 1024), 16, va, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 4 + wave) * 1024), 16, vb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 8 + wave) * 1024), 16, vb, 0, 0, 0);
     }
   };
 
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave >> 1, wk = wave & 1;  // wn 0..3 (64 n each), wk 0..1 (64 k each)
   const int g = lane >> 4, i16 = lane & 15;
   const int h = g >> 1, cb = g & 1;
   const int q = i16 >> 2, pp = i16 & 3;
-  // transposed-read byte offsets: [substep s][block b][lo/hi]
+  const uint32_t a_sub = (uint32_t)(wn >> 1) * SUB_B;  // which 128-column sub-tile of A
   uint32_t ta[4][2][2], tb[4][2][2];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -98,9 +115,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) {
         const int row = 16 * s + 8 * h + 4 * hl + q;
-        const int cha = wn * 8 + b * 4 + 2 * cb + (pp >> 1);
+        const int cha = (wn & 1) * 8 + b * 4 + 2 * cb + (pp >> 1);
         const int chb = wk * 8 + b * 4 + 2 * cb + (pp >> 1);
-        ta[s][b][hl] = row * 256 + ((cha ^ swz256(row)) << 4) + 8 * (pp & 1);
+        ta[s][b][hl] = a_sub + row * 256 + ((cha ^ swz256(row)) << 4) + 8 * (pp & 1);
         tb[s][b][hl] = row * 256 + ((chb ^ swz256(row)) << 4) + 8 * (pp & 1);
       }
 
@@ -114,12 +131,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
 
   const int nsteps = (rows + TM_ - 1) / TM_;
   stage(0, 0);
+  if (nsteps > 1) stage(1, TM_);
+  int buf = 0;
   for (int st = 0; st < nsteps; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 1 < nsteps) stage((st + 1) & 1, (st + 1) * TM_);
-    const char* la = lds + (st & 1) * 2 * TILE_B;
-    const char* lb = la + TILE_B;
+    if (st + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + 2 < nsteps) {
+      int nb = buf + 2;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, (st + 2) * TM_);
+    }
+    const char* la = lds + buf * STAGE_B;
+    const char* lb = la + 2 * SUB_B;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8 af[2], bfr[2];
@@ -134,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs p) {
         for (int kb = 0; kb < 2; ++kb)
           acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
     }
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
 
   const int l31 = lane & 31, hh = lane >> 5;
@@ -191,10 +217,20 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   a.tiles_n = (N + TN_ - 1) / TN_;
   a.tiles_k = (K + TK_ - 1) / TK_;
   const int tiles = a.tiles_n * a.tiles_k;
-  int splits = (512 + tiles - 1) / tiles;
+  // split M so that the 144-KiB workgroups fill the 256 CUs in whole rounds, pricing the f32
+  // atomics of every extra split (~1.3 TB/s chip-wide) against the rounds they save
+  int splits = 1;
+  double best = 1e30;
   const int max_splits = (M + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
+    const double rounds = (double)((tiles * sp + 255) / 256);
+    const double steps = (double)((M + sp * TM_ - 1) / (sp * TM_));
+    const double cost = rounds * steps * 1.0 + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.5;
+    if (cost < best) {
+      best = cost;
+      splits = sp;
+    }
+  }
   int rps = (M + splits - 1) / splits;
   rps = (rps + TM_ - 1) / TM_ * TM_;
   // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)
@@ -202,7 +238,9 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   while ((int64_t)rps * ldmax * 2 >= (int64_t)0x7fffffff && rps > TM_) rps = (rps / 2 + TM_ - 1) / TM_ * TM_;
   splits = (M + rps - 1) / rps;
   a.rows_per_split = rps;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), LDS_B, (hipStream_t)stream, a);
   MVPTR_CHECK_LAUNCH("gemm_tn");
   return MVPTR_OK;
 }

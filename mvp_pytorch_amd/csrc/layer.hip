@@ -78,7 +78,7 @@ extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   if (check_desc("layer_workspace_bytes", d)) return -1;
   const int64_t M = (int64_t)d->B * d->L, H = d->H;
   const int64_t W = d->I > 3 * H ? d->I : 3 * H;
-  return 3 * al256(M * H * 2) + al256(M * W * 2);
+  return 3 * al256(M * H * 2) + al256(M * W * 2) + al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H));
 }
 
 extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
@@ -126,6 +126,9 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   char* bufB = bufA + al256((int64_t)M * H * 2);
   char* bufC = bufB + al256((int64_t)M * H * 2);
   char* bufU = bufC + al256((int64_t)M * H * 2);
+  const int64_t W_ = I > 3 * H ? I : 3 * H;
+  char* lnws = bufU + al256((int64_t)M * W_ * 2);
+  const int64_t lnws_bytes = mvptr_layernorm_bwd_ws_bytes(M, H);
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
   const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
@@ -134,7 +137,7 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   // output.LayerNorm / output.dense
   RUN(mvptr_layernorm_bwd(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
                           g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
-                          hdrop ? &dr_out : nullptr, stream));
+                          hdrop ? &dr_out : nullptr, lnws, lnws_bytes, stream));
   const char* d2 = hdrop ? bufB : bufA;
   if (g->w_out) RUN(mvptr_gemm_tn(d2, H, s.a, I, M, H, I, g->w_out, I, stream));
   RUN(mvptr_gemm_nt(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
@@ -146,7 +149,7 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   // attention.output.LayerNorm / dense
   RUN(mvptr_layernorm_bwd(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufA, hdrop ? bufB : nullptr,
                           g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
-                          hdrop ? &dr_o : nullptr, stream));
+                          hdrop ? &dr_o : nullptr, lnws, lnws_bytes, stream));
   const char* d1 = hdrop ? bufB : bufA;
   if (g->w_o) RUN(mvptr_gemm_tn(d1, H, s.ctx, H, M, H, H, g->w_o, H, stream));
   RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,

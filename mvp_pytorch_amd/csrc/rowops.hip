@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const floa
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __bf16* z,
                                                        const float* mean, const float* rstd,
                                                        const float* gamma, __bf16* dz, __bf16* dd,
-                                                       float* dgamma, float* dbeta, float* dbias,
+                                                       float* partial,
                                                        int M, int H, int rpg, int gstride, int roff,
                                                        DropDev ydrop, DropDev ddrop) {
   __shared__ float red[3][3][1024];  // waves 1..3 publish, wave 0 sums
@@ -169,12 +169,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
           const float a = ag[c][e] + red[0][0][col] + red[0][1][col] + red[0][2][col];
           const float b = ab[c][e] + red[1][0][col] + red[1][1][col] + red[1][2][col];
           const float d = abias[c][e] + red[2][0][col] + red[2][1][col] + red[2][2][col];
-          if (dgamma) atomicAdd(dgamma + col, a);
-          if (dbeta) atomicAdd(dbeta + col, b);
-          if (dbias) atomicAdd(dbias + col, d);
+          float* pp = partial + (int64_t)blockIdx.x * 3 * H;
+          pp[col] = a;
+          pp[H + col] = b;
+          pp[2 * H + col] = d;
         }
       }
   }
+}
+
+// second stage: out[q][col] += sum over blocks of partial[blk][q][col]
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* partial, int nblk, int H,
+                                                               float* dgamma, float* dbeta,
+                                                               float* dbias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // over 3*H
+  if (i >= 3 * H) return;
+  const int q = i / H, col = i - q * H;
+  float* dst = (q == 0) ? dgamma : (q == 1 ? dbeta : dbias);
+  if (dst == nullptr) return;
+  // blockIdx.y slices the partial rows; 32 slices -> 32 adds per address, no contention to speak of
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += partial[(int64_t)b * 3 * H + i];
+  if (b1 > b0) atomicAdd(dst + col, s);
 }
 
 // --------------------------------------------------------------------------------- embeddings
@@ -394,12 +412,19 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
   return MVPTR_OK;
 }
 
+extern "C" int64_t mvptr_layernorm_bwd_ws_bytes(int M, int H) {
+  int grid = (M + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  return (int64_t)grid * 3 * H * 4;
+}
+
 extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, void* dd,
                                    float* dgamma, float* dbeta, float* dbias, int M, int H,
                                    int rows_per_group, int group_stride, int row_offset,
                                    const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop,
-                                   void* stream) {
+                                   void* ws, int64_t ws_bytes, void* stream) {
   if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: M must be > 0");
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: rows_per_group must be > 0");
@@ -407,11 +432,17 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
   if (gamma && (!mean || !rstd)) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: mean/rstd required");
   int grid = (M + 3) / 4;
   if (grid > 1024) grid = 1024;
+  if (!ws || ws_bytes < mvptr_layernorm_bwd_ws_bytes(M, H))
+    MVPTR_FAIL(MVPTR_WORKSPACE_TOO_SMALL, "layernorm_bwd: workspace %ld < %ld bytes", (long)ws_bytes,
+               (long)mvptr_layernorm_bwd_ws_bytes(M, H));
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,
-                     (__bf16*)dd, dgamma, dbeta, dbias, M, H, rows_per_group, group_stride,
+                     (__bf16*)dd, (float*)ws, M, H, rows_per_group, group_stride,
                      row_offset, make_dropdev(y_drop), make_dropdev(dense_drop));
   MVPTR_CHECK_LAUNCH("layernorm_bwd");
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)ws, grid, H, dgamma, dbeta, dbias);
+  MVPTR_CHECK_LAUNCH("layernorm_bwd_finalize");
   return MVPTR_OK;
 }
 

@@ -23,7 +23,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 SYMBOLS = [
     "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
-    "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
+    "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
 ]
@@ -77,7 +77,9 @@ def load():
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_layernorm_fwd.argtypes = [P, P, P, F, P, P, P, I, I, I, I, I, POINTER(Dropout), P]
-    lib.mvptr_layernorm_bwd.argtypes = [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, POINTER(Dropout), POINTER(Dropout), P]
+    lib.mvptr_layernorm_bwd.argtypes = [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, POINTER(Dropout), POINTER(Dropout), P, I64, P]
+    lib.mvptr_layernorm_bwd_ws_bytes.restype = c_int64
+    lib.mvptr_layernorm_bwd_ws_bytes.argtypes = [I, I]
     lib.mvptr_embed_fwd.argtypes = [P, P, P, P, P, P, P, I, I, I64, I64, I64, P]
     lib.mvptr_embed_bwd.argtypes = [P, P, P, P, P, P, P, I, I, P]
     lib.mvptr_cast_pack.argtypes = [P, I64, I, I, P, I64, P, I64, I, P]
@@ -195,9 +197,11 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, rows_per_
     M, H = z.shape
     dz = torch.empty_like(z)
     dd = torch.empty_like(z) if dense_drop is not None else None
+    nws = load().mvptr_layernorm_bwd_ws_bytes(M, H)
+    ws = torch.empty(nws, device=z.device, dtype=torch.uint8)
     _check(load().mvptr_layernorm_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dd),
                                       _p(dgamma), _p(dbeta), _p(dbias), M, H, rows_per_group or M,
-                                      group_stride, row_offset, _dp(y_drop), _dp(dense_drop), _stream()))
+                                      group_stride, row_offset, _dp(y_drop), _dp(dense_drop), _p(ws), nws, _stream()))
     return dz, dd
 
 

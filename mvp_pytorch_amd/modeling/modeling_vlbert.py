@@ -230,6 +230,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                 hard_txt = torch.multinomial(F.softmax(masked.t(), dim=1), num_samples=1).squeeze()
             else:
                 raise NotImplementedError
+            if getattr(self, "hard_override", None) is not None:
+                # parity-test hook: inject captured hard-negative indices
+                hard_img, hard_txt = (t.to(dev) for t in self.hard_override)
             dice = torch.randperm(n, device=dev)
             first, second = dice[: n // 2], dice[n // 2:]
             ar = torch.arange(n, device=dev)
@@ -292,32 +295,88 @@ def _masked_rows(seq, labels):
 
 
 # ------------------------------------------------------------------------------------------- WRA
+def _flat_rows(index, seq_len):
+    """host-side: [B,2] (start, end) ranges -> flat row ids into [B*L], owner sample per row,
+    and per-sample (start offset, count) in the stacked order (vl:1502-1508 semantics)."""
+    rows, owner, starts, counts = [], [], [], []
+    for i, (s, e) in enumerate(index.tolist()):
+        starts.append(len(rows))
+        counts.append(max(0, e - s))
+        for r in range(s, e):
+            rows.append(i * seq_len + r)
+            owner.append(i)
+    return rows, owner, starts, counts
+
+
 def mask_slice_and_stack(features, valid_index):
-    """vl:1502-1508."""
-    vi = valid_index.tolist()
-    return torch.cat([features[i, s:e] for i, (s, e) in enumerate(vi)], dim=0)
+    """vl:1502-1508 — one index_select instead of a per-sample loop (a per-sample slice costs a
+    full-size zero-filled gradient buffer each in backward)."""
+    B, L, H = features.shape
+    rows, _, _, _ = _flat_rows(valid_index, L)
+    idx = torch.tensor(rows, dtype=torch.long, device=features.device)
+    return features.reshape(B * L, H).index_select(0, idx)
 
 
-def t2i_sim(sim_matrix):
-    """vl:1543-1550."""
-    if sim_matrix.shape[0] == 0:
-        return torch.zeros((), dtype=sim_matrix.dtype, device=sim_matrix.device)
-    f_sim = sim_matrix.topk(3, dim=1)[0]
-    rand_index = torch.randint(0, 3, (f_sim.shape[0],), device=f_sim.device)
-    return f_sim[torch.arange(f_sim.shape[0], device=f_sim.device), rand_index].mean()
+def _draw_top3_picks(counts):
+    """The reference draws, per sample t: randint(0,3,(n_t,)) for the positive pair, then
+    random.choice of a negative image, then randint again (vl:1566-1576, 1547-1549); samples
+    without phrases draw no randint.  Same order here, on the host."""
+    n = len(counts)
+    pos_pick, neg_pick, neg_img = [], [], []
+    for t in range(n):
+        if counts[t] > 0:
+            pos_pick.append(torch.randint(0, 3, (counts[t],)).cpu())
+        j = random.choice(list(range(0, t)) + list(range(t + 1, n)))
+        neg_img.append(j)
+        if counts[t] > 0:
+            neg_pick.append(torch.randint(0, 3, (counts[t],)).cpu())
+    cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0, dtype=torch.long)  # noqa: E731
+    return cat(pos_pick), cat(neg_pick), neg_img
+
+
+def _segment_top3_mean(sims, row_owner, col_start, col_count, picks, n):
+    """mean over a sample's phrase rows of a random one of the top-3 similarities inside the
+    column range [col_start, col_start+col_count) of each row (t2i_sim, vl:1543-1550)."""
+    dev = sims.device
+    rmax = int(col_count.max().item()) if col_count.numel() else 0
+    ar = torch.arange(max(rmax, 3), device=dev)
+    cols = col_start[:, None] + ar[None, :]
+    valid = ar[None, :] < col_count[:, None]
+    vals = sims.gather(1, cols.clamp(max=sims.shape[1] - 1)).masked_fill(~valid, float("-inf"))
+    top = vals.topk(3, dim=1)[0]
+    picked = top.gather(1, picks.to(dev)[:, None]).squeeze(1)
+    sums = torch.zeros(n, dtype=sims.dtype, device=dev).index_add_(0, row_owner, picked)
+    cnt = torch.zeros(n, dtype=sims.dtype, device=dev).index_add_(0, row_owner, torch.ones_like(picked))
+    return sums / cnt.clamp(min=1.0)
 
 
 def get_pos_neg_sims(sims, text_index, img_index):
-    """vl:1553-1596 (borders computed on the host once instead of per-sample device syncs)."""
-    tb = [0] + torch.cumsum(text_index[:, 1] - text_index[:, 0], 0).tolist()
-    ib = [0] + torch.cumsum(img_index[:, 1] - img_index[:, 0], 0).tolist()
+    """vl:1553-1596, vectorised: per sample the mean top-3-pick similarity of its phrases against
+    its own regions (pos) and against one randomly chosen other image (neg)."""
+    dev = sims.device
     n = text_index.shape[0]
-    pos, neg = [], []
-    for t in range(n):
-        pos.append(t2i_sim(sims[tb[t]:tb[t + 1], ib[t]:ib[t + 1]]))
-        j = random.choice(list(range(0, t)) + list(range(t + 1, n)))
-        neg.append(t2i_sim(sims[tb[t]:tb[t + 1], ib[j]:ib[j + 1]]))
-    return torch.stack(pos), torch.stack(neg)
+    _, owner, _, tcounts = _flat_rows(text_index, 1 << 20)
+    _, _, istarts, icounts = _flat_rows(img_index, 1 << 20)
+    if any(c < 3 for c in icounts) and len(owner):
+        raise RuntimeError("selected index k out of range: every image needs >= 3 valid regions (topk(3), vl:1547)")
+    pos_pick, neg_pick, neg_img = _draw_top3_picks(tcounts)
+    owner_t = torch.tensor(owner, dtype=torch.long, device=dev)
+    istarts_t = torch.tensor(istarts, dtype=torch.long, device=dev)
+    icounts_t = torch.tensor(icounts, dtype=torch.long, device=dev)
+    neg_t = torch.tensor(neg_img, dtype=torch.long, device=dev)
+    pos = _segment_top3_mean(sims, owner_t, istarts_t[owner_t], icounts_t[owner_t], pos_pick, n)
+    nj = neg_t[owner_t]
+    neg = _segment_top3_mean(sims, owner_t, istarts_t[nj], icounts_t[nj], neg_pick, n)
+    return pos, neg
+
+
+def t2i_sim(sim_matrix):
+    """vl:1543-1550 (single matrix form, used by phrase_mod='hard')."""
+    if sim_matrix.shape[0] == 0:
+        return torch.zeros((), dtype=sim_matrix.dtype, device=sim_matrix.device)
+    f_sim = sim_matrix.topk(3, dim=1)[0]
+    rand_index = torch.randint(0, 3, (f_sim.shape[0],)).to(f_sim.device)
+    return f_sim[torch.arange(f_sim.shape[0], device=f_sim.device), rand_index].mean()
 
 
 def get_pos_sims(sequence_output, text_index, img_index):

@@ -1,0 +1,112 @@
+"""AdamW + LR schedules with the numerics of transformers/pytorch_transformers/optimization.py
+(:107-189 AdamW — decoupled weight decay applied after the Adam update, bias correction on by
+default, eps 1e-6; :33-61 warmup schedules).  The update runs as fused multi-tensor torch ops
+on the device (a handful of launches per step instead of ~5 per parameter)."""
+import math
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LambdaLR
+
+
+class ConstantLRSchedule(LambdaLR):
+    def __init__(self, optimizer, last_epoch=-1):
+        super().__init__(optimizer, lambda _: 1.0, last_epoch=last_epoch)
+
+
+class WarmupConstantSchedule(LambdaLR):
+    """optimization.py:33-45."""
+
+    def __init__(self, optimizer, warmup_steps, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        return 1.0
+
+
+class WarmupLinearSchedule(LambdaLR):
+    """optimization.py:48-61 (KAT: tests/test_host_logic.py, from optimization_test.py:105-110)."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        self.t_total = t_total
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
+
+
+class AdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps, gs, ms, vs = [], [], [], []
+            b1, b2 = group["betas"]
+            step_no = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                step_no = st["step"] if step_no is None else step_no
+                if st["step"] != step_no:  # parameters of a group that joined later: single-tensor path
+                    self._single(p, st, group)
+                    continue
+                ps.append(p)
+                gs.append(p.grad)
+                ms.append(st["exp_avg"])
+                vs.append(st["exp_avg_sq"])
+            if not ps:
+                continue
+            torch._foreach_mul_(ms, b1)
+            torch._foreach_add_(ms, gs, alpha=1.0 - b1)
+            torch._foreach_mul_(vs, b2)
+            torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
+            denom = torch._foreach_sqrt(vs)
+            torch._foreach_add_(denom, group["eps"])
+            step_size = group["lr"]
+            if group["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** step_no) / (1.0 - b1 ** step_no)
+            torch._foreach_addcdiv_(ps, ms, denom, value=-step_size)
+            if group["weight_decay"] > 0.0:
+                torch._foreach_mul_(ps, 1.0 - group["lr"] * group["weight_decay"])
+        return loss
+
+    @staticmethod
+    def _single(p, st, group):
+        b1, b2 = group["betas"]
+        st["exp_avg"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
+        st["exp_avg_sq"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+        denom = st["exp_avg_sq"].sqrt().add_(group["eps"])
+        step_size = group["lr"]
+        if group["correct_bias"]:
+            step_size = step_size * math.sqrt(1.0 - b2 ** st["step"]) / (1.0 - b1 ** st["step"])
+        p.addcdiv_(st["exp_avg"], denom, value=-step_size)
+        if group["weight_decay"] > 0.0:
+            p.add_(p, alpha=-group["lr"] * group["weight_decay"])

@@ -1,0 +1,47 @@
+"""Pre-training step harness: the counterpart of `forward_backward` + optimizer step in
+oscar/run_pretrain_ml.py:519-562,632-644 (DeepSpeed branch call signature :528-531, without
+DeepSpeed), plus the data-parallel gradient exchange."""
+import torch
+
+from .optimization import AdamW, WarmupLinearSchedule
+
+
+def build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, warmup_steps=0, t_total=100000):
+    """run_pretrain_ml.py:379-393 — no decay on biases and LayerNorm weights."""
+    no_decay = ["bias", "LayerNorm.weight"]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = AdamW(groups, lr=lr, eps=adam_epsilon)
+    sched = WarmupLinearSchedule(opt, warmup_steps=warmup_steps, t_total=t_total)
+    return opt, sched
+
+
+def model_inputs(batch, max_tag_length):
+    """batch (13 tensors of OscarTSVDataset_C, oscar_tsv4.py:363-377) -> model kwargs
+    (run_pretrain_ml.py:528-531)."""
+    return dict(input_ids_a=batch["input_ids_a"], token_type_ids_a=batch["segment_ids_a"],
+                attention_mask_a=batch["input_mask_a"], masked_lm_labels_a=batch["lm_label_ids_a"],
+                input_ids_b=batch["input_ids_b"], img_feats=batch["img_feats"],
+                token_type_ids_b=batch["segment_ids_b"], attention_mask_b=batch["input_mask_b"],
+                masked_lm_labels_b=batch["lm_label_ids_b"], phrase_index=batch.get("phrase_index"),
+                img_index=batch.get("image_index"), max_tag_length=max_tag_length)
+
+
+def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_weight=1.0, max_grad_norm=0.0,
+                  grad_sync=None, return_losses=False):
+    """One optimisation step.  grad_sync: optional callable run between backward and the
+    optimizer (the data-parallel all-reduce, mvp_pytorch_amd.dp.GradSync)."""
+    outputs = model(**model_inputs(batch, max_tag_length))
+    loss = loss_weight * outputs[0]
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    if max_grad_norm > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    optimizer.step()
+    scheduler.step()
+    optimizer.zero_grad(set_to_none=True)
+    if return_losses:
+        return [o.detach() for o in outputs]
+    return loss.detach()

@@ -1,0 +1,227 @@
+"""Host-side logic on CPU: config / checkpoint surface, parameter tree vs the reference's
+state_dict names, schedules (reference KAT), AdamW vs the oracle, synthetic batch invariants,
+2-rank gloo gradient exchange, loud failure without a device."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import mvptr_oracle as orc
+
+
+def _tiny_model(cls="BiBertImgForPreTraining", **over):
+    from mvp_pytorch_amd import modeling
+    cfg = dict(gu.TINY_CFG, **over)
+    return getattr(modeling, cls)(modeling.make_config(cfg)), cfg
+
+
+def test_param_tree_matches_reference_names():
+    """gnorm:* keys of the fixtures are the reference's own named_parameters()."""
+    d = gu.load("tiny_bi_pretrain")
+    model, _ = _tiny_model()
+    ours = dict(model.named_parameters())
+    ref_names = [k[6:] for k in d if k.startswith("gnorm:")]
+    assert len(ref_names) > 100
+    for n in ref_names:
+        assert n in ours, n
+    # parameters the reference leaves without gradient in this step: only qa_head
+    no_grad = sorted(set(ours) - set(ref_names))
+    assert no_grad == ["qa_head.bias", "qa_head.weight"], no_grad
+    d2 = gu.load("tiny_finetune")
+    for prefix, cls, extra in (("ret_", "BiImageBertForRetrieval", dict(loss_type="ce")),
+                               ("vqa_", "BiImageBertForVQA", dict(loss_type="bce", num_labels=37)),
+                               ("ve_", "BiImageBertForSequenceClassification", dict(loss_type="ce", num_labels=3, classifier="linear"))):
+        m, _ = _tiny_model(cls, **extra)
+        ours = dict(m.named_parameters())
+        for k in d2:
+            if k.startswith(prefix + "gnorm:"):
+                assert k[len(prefix) + 6:] in ours, k
+
+
+def test_config_roundtrip_and_save_load():
+    from mvp_pytorch_amd import modeling
+    model, cfg = _tiny_model()
+    with tempfile.TemporaryDirectory() as td:
+        model.save_pretrained(td)
+        assert sorted(os.listdir(td)) == ["config.json", "pytorch_model.bin"]
+        c2 = modeling.BertConfig.from_pretrained(td, num_labels=5)
+        assert c2.num_labels == 5 and c2.img_feature_dim == 2054 and c2.only_word_size == 1000
+        m2 = modeling.BiBertImgForPreTraining.from_pretrained(td, config=modeling.BertConfig.from_pretrained(td))
+        assert not m2.training  # from_pretrained leaves the model in eval mode
+        for (n1, p1), (n2, p2) in zip(model.state_dict().items(), m2.state_dict().items()):
+            assert n1 == n2
+            if n1.endswith("decoder.weight"):
+                continue  # re-cloned from the embeddings by tie_weights() (reference behaviour)
+            assert torch.equal(p1, p2), n1
+        emb = m2.bert.embeddings.word_embeddings.weight[:1000]
+        assert torch.equal(m2.cls.predictions.decoder.weight, emb)
+        assert torch.equal(m2.half_mlm.decoder.weight, emb)
+        # legacy gamma/beta names and missing 'bert.' prefix are accepted
+        sd = {k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta"): v
+              for k, v in model.state_dict().items()}
+        m3 = modeling.BiBertImgForPreTraining.from_pretrained(td, config=c2, state_dict=sd)
+        assert torch.equal(m3.bert.embeddings.LayerNorm.weight, model.bert.embeddings.LayerNorm.weight)
+        # backbone-only checkpoint into a task model
+        bsd = model.bert.state_dict()
+        m4 = modeling.BiImageBertForRetrieval.from_pretrained(td, config=modeling.make_config(dict(cfg, loss_type="ce")), state_dict=bsd)
+        assert torch.equal(m4.bert.txt_proj, model.bert.txt_proj)
+
+
+def test_single_stream_ties_decoder():
+    model, _ = _tiny_model("BertImgForPreTraining")
+    assert model.cls.predictions.decoder.weight is model.bert.embeddings.word_embeddings.weight
+
+
+def test_unsupported_options_raise():
+    from mvp_pytorch_amd import modeling
+    with pytest.raises(NotImplementedError):
+        _tiny_model(hidden_act="relu")
+    with pytest.raises(NotImplementedError):
+        _tiny_model(img_feature_type="dis_code")
+    with pytest.raises(ValueError):
+        modeling.BertConfig(vocab_size_or_config_json_file=1.5)
+    with pytest.raises(ValueError):
+        modeling.BiBertImgModel({"not": "a config"})
+
+
+def test_fails_loudly_without_device():
+    model, _ = _tiny_model(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    d = gu.load("tiny_bi_pretrain")
+    t = lambda k: torch.from_numpy(d["in:" + k])  # noqa: E731
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.bert.forward_single(input_ids_a=t("input_ids_a"), input_ids_b=t("input_ids_b"), img_feats=t("img_feats"),
+                                  attention_mask_a=t("input_mask_a"), attention_mask_b=t("input_mask_b"))
+
+
+def test_warmup_linear_schedule_kat():
+    """transformers/pytorch_transformers/tests/optimization_test.py:105-110."""
+    from mvp_pytorch_amd.optimization import AdamW, WarmupConstantSchedule, WarmupLinearSchedule
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = AdamW([p], lr=10.0)
+    sch = WarmupLinearSchedule(opt, warmup_steps=2, t_total=10)
+    lrs = []
+    for _ in range(10):
+        sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    np.testing.assert_allclose(lrs, [5.0, 10.0, 8.75, 7.5, 6.25, 5.0, 3.75, 2.5, 1.25, 0.0], atol=1e-9)
+    opt = AdamW([p], lr=10.0)
+    sch = WarmupConstantSchedule(opt, warmup_steps=4)
+    lrs = []
+    for _ in range(10):
+        sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    np.testing.assert_allclose(lrs, [2.5, 5.0, 7.5, 10.0, 10.0, 10.0, 10.0, 10.0, 10.0, 10.0], atol=1e-9)
+
+
+def test_adamw_matches_reference_step_and_converges():
+    from mvp_pytorch_amd.optimization import AdamW
+    d = gu.load("tiny_bi_pretrain")
+    names = gu.ADAMW_PROBES
+    from mvp_pytorch_amd.modeling import param_shapes
+    shapes = param_shapes("BiBertImgForPreTraining", d["config"])
+    det = gu.det_state_dict({n: shapes[n] for n in names}, int(d["seed"]))
+    params = {n: torch.nn.Parameter(torch.from_numpy(det[n].copy())) for n in names if ("grad:" + n) in d}
+    assert len(params) >= 3
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in params.items() if not any(x in n for x in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in params.items() if any(x in n for x in no_decay)], "weight_decay": 0.0}]
+    for n, p in params.items():
+        p.grad = torch.from_numpy(d["grad:" + n].copy())
+    AdamW(groups, lr=5e-3, eps=1e-8).step()
+    for n, p in params.items():
+        np.testing.assert_allclose(p.detach().numpy(), d["adamw:" + n], rtol=1e-5, atol=1e-7, err_msg=n)
+    # optimization_test.py:58-70 — converges on a 3-element quadratic
+    w = torch.nn.Parameter(torch.tensor([0.1, -0.2, -0.1]))
+    target = torch.tensor([0.4, 0.2, -0.5])
+    opt = AdamW([w], lr=2e-1, weight_decay=0.0)
+    for _ in range(100):
+        loss = torch.nn.functional.mse_loss(w, target)
+        loss.backward()
+        opt.step()
+        w.grad.detach_()
+        w.grad.zero_()
+    np.testing.assert_allclose(w.detach().numpy(), target.numpy(), atol=1e-2)
+
+
+def test_synthetic_batch_invariants():
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg, dims = gu.BASE_CFG, dict(B=16, T=70, P=5, G=20, R=50)
+    b = synthetic_batch(dims, cfg, 3)
+    La = dims["T"] + dims["P"]
+    assert b["img_feats"].shape == (16, 50, 2054) and b["input_ids_a"].shape == (16, La)
+    assert b["input_mask_b"].shape == (16, 70) and b["lm_label_ids_b"].shape == (16, 70)
+    for i in range(16):
+        ma = b["input_mask_a"][i]
+        n = int(ma.sum())
+        assert torch.all(ma[:n] == 1) and torch.all(ma[n:] == 0)  # prefix-contiguous
+        assert b["input_ids_a"][i, 0] == 101 and b["input_ids_a"][i, n - 1] == 102
+        p0, p1 = b["phrase_index"][i].tolist()
+        assert torch.all(b["input_ids_a"][i, p0:p1] >= cfg["only_word_size"])
+        assert torch.all(b["lm_label_ids_a"][i, p0:p1] == -1)
+        i0, i1 = b["image_index"][i].tolist()
+        assert i0 == La and i1 - i0 >= 3
+        assert int(b["input_mask_b"][i, 20:].sum()) == i1 - i0
+        assert torch.all(b["img_feats"][i, i1 - i0:] == 0)
+        assert (b["lm_label_ids_a"][i] > -1).any() and (b["lm_label_ids_b"][i] > -1).any()
+        assert torch.all(b["lm_label_ids_b"][i, 20:] == -1)
+    assert torch.all(b["segment_ids_a"] == 0) and torch.all(b["segment_ids_b"] == 1)
+    f = synthetic_batch(dims, cfg, 3, fixed_length=True)
+    assert int(f["input_mask_a"].sum()) == 16 * La and int(f["input_mask_b"].sum()) == 16 * 70
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    for p in m[2].parameters():
+        pass
+    sync = dp.GradSync(m, bucket_mb=0.0002)  # tiny buckets -> several collectives
+    assert len(sync.buckets) > 1
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = []
+    for i, p in enumerate(m.parameters()):
+        if i == 5 and rank == 1:
+            p.grad = None  # a rank that produced no gradient for a parameter (qa_head-like)
+            grads.append(torch.zeros_like(p))
+        else:
+            p.grad = torch.randn(p.shape, generator=g)
+            grads.append(p.grad.clone())
+    sync()
+    out = [p.grad.clone() for p in m.parameters()]
+    vals = dp.all_reduce_metrics([float(rank + 1), 2.0, 3.0], torch.device("cpu"))
+    q.put((rank, [t.numpy() for t in grads], [t.numpy() for t in out], vals))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, o0, v0), (_, g1, o1, v1) = res
+    for a, b, x, y in zip(g0, g1, o0, o1):
+        want = (a + b) / 2
+        assert np.allclose(x, want, atol=1e-6) and np.allclose(y, want, atol=1e-6)
+    assert v0 == v1 == [3.0, 4.0, 6.0]
+
+
+def test_flops_formula_matches_survey():
+    import bench
+    fwd, fb = bench.flops_per_pair(dict(B=256, T=70, P=5, G=20, R=50), bench.BASE_CFG, 11, 3)
+    assert abs(fwd / 1e9 - 35.16) < 0.15  # 35.16 GFLOP forward per pair
+    assert fb == 3 * fwd
