@@ -11,13 +11,13 @@
 // M is split across blockIdx.y; partial sums are added with f32 atomics whose wave
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int TN_ = 256, TK_ = 128, TM_ = 64, STAGES = 3;
-constexpr int SUB_B = TM_ * 256;            // one 64 x 128 bf16 sub-tile: 16 KiB
-constexpr int STAGE_B = 3 * SUB_B;          // A = 2 sub-tiles (256 n), B = 1 sub-tile (128 k)
-constexpr int LDS_B = STAGES * STAGE_B;     // 144 KiB
+constexpr int TN_ = 256, TK_ = 128, STAGES = 3;
+// TM_ token rows per pipeline step: 64 -> 3 x 48 KiB ring (one workgroup per CU),
+// 32 -> 3 x 24 KiB ring (two workgroups per CU)
 
 struct GemmTnArgs {
   const __bf16* A;
@@ -46,7 +46,12 @@ extern __shared__ __attribute__((aligned(1024))) char lds[];
 // 256(n) x 128(k) output tile per 512-thread workgroup (8 waves as 4(n) x 2(k), each 64x64 =
 // 2x2 v_mfma_f32_32x32x16_bf16), 64 token rows per step, 3-stage LDS ring with a counted
 // vmcnt(6) + raw s_barrier (two steps in flight).
+template <int TM_>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
+  constexpr int SUB_B = TM_ * 256;     // one TM_ x 128 bf16 sub-tile
+  constexpr int STAGE_B = 3 * SUB_B;   // A = 2 sub-tiles (256 n), B = 1 sub-tile (128 k)
+  constexpr int GROUPS = TM_ / 4;      // 4-row wave instructions per sub-tile
+  constexpr int NA = 2 * GROUPS / 8, NB = GROUPS / 8, NS = TM_ / 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,18 +76,18 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
       p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
 
   // staging: a wave instruction fills 4 LDS rows (1 KiB) of a 64x128 sub-tile
-  uint32_t offA[4], offB[2];
+  uint32_t offA[NA], offB[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = i * 8 + wave;  // 0..31: sub-tile j>>4, row group j&15
-    const int row = (j & 15) * 4 + (lane >> 4);
+  for (int i = 0; i < NA; ++i) {
+    const int j = i * 8 + wave;  // sub-tile j / GROUPS, row group j % GROUPS
+    const int row = (j % GROUPS) * 4 + (lane >> 4);
     const int ch = (lane & 15) ^ swz256(row);
-    const int col = (j >> 4) * 128 + ch * 8;
+    const int col = (j / GROUPS) * 128 + ch * 8;
     offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int j = i * 8 + wave;  // 0..15
+  for (int i = 0; i < NB; ++i) {
+    const int j = i * 8 + wave;
     const int row = j * 4 + (lane >> 4);
     const int ch = (lane & 15) ^ swz256(row);
     offB[i] = (ch * 8 < kcols) ? (uint32_t)(row * p.ldb * 2 + ch * 16) : MVPTR_OOB;
@@ -91,12 +96,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
     char* la = lds + buf * STAGE_B;
     char* lb = la + 2 * SUB_B;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)(mrow0 * p.lda * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 8 + wave) * 1024), 16, va, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const uint32_t vb = (offB[i] == MVPTR_OOB) ? MVPTR_OOB : offB[i] + (uint32_t)(mrow0 * p.ldb * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 8 + wave) * 1024), 16, vb, 0, 0, 0);
     }
@@ -107,9 +112,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
   const int h = g >> 1, cb = g & 1;
   const int q = i16 >> 2, pp = i16 & 3;
   const uint32_t a_sub = (uint32_t)(wn >> 1) * SUB_B;  // which 128-column sub-tile of A
-  uint32_t ta[4][2][2], tb[4][2][2];
+  uint32_t ta[NS][2][2], tb[NS][2][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -134,10 +139,14 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
   if (nsteps > 1) stage(1, TM_);
   int buf = 0;
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps)
-      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else
+    if (st + 1 < nsteps) {
+      if (NA + NB == 6)
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (st + 2 < nsteps) {
       int nb = buf + 2;
       if (nb >= STAGES) nb -= STAGES;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
     const char* la = lds + buf * STAGE_B;
     const char* lb = la + 2 * SUB_B;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < NS; ++s) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -204,6 +213,14 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   if (lda < N || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: lda/ldb smaller than N/K");
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: A and B must be 16-byte aligned");
+  // 32-row steps run two workgroups per CU (better latency hiding) but need >= 512 workgroups to
+  // fill the chip; small outputs (few tiles, where every extra M-split costs atomics) use the
+  // 64-row, one-workgroup-per-CU variant.  MVPTR_GEMM_TM=64|32 overrides (tuning knob).
+  const char* env = getenv("MVPTR_GEMM_TM");
+  const int tiles_est = ((N + TN_ - 1) / TN_) * ((K + TK_ - 1) / TK_);
+  int TM_ = (tiles_est <= 24) ? 64 : 32;
+  if (env != nullptr) TM_ = (env[0] == '6') ? 64 : 32;
+  const int wg_per_round = (TM_ == 64) ? 256 : 512;
   GemmTnArgs a;
   a.A = (const __bf16*)A;
   a.B = (const __bf16*)B;
@@ -223,9 +240,9 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   double best = 1e30;
   const int max_splits = (M + 255) / 256;
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
-    const double rounds = (double)((tiles * sp + 255) / 256);
-    const double steps = (double)((M + sp * TM_ - 1) / (sp * TM_));
-    const double cost = rounds * steps * 1.0 + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.5;
+    const double rounds = (double)((tiles * sp + wg_per_round - 1) / wg_per_round);
+    const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
+    const double cost = rounds * steps * (wg_per_round == 256 ? 1.0 : 2.0) + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.7;
     if (cost < best) {
       best = cost;
       splits = sp;
@@ -238,9 +255,17 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   while ((int64_t)rps * ldmax * 2 >= (int64_t)0x7fffffff && rps > TM_) rps = (rps / 2 + TM_ - 1) / TM_ * TM_;
   splits = (M + rps - 1) / rps;
   a.rows_per_split = rps;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), LDS_B, (hipStream_t)stream, a);
+  const int lds_b = STAGES * 3 * TM_ * 256;
+  hipError_t e;
+  if (TM_ == 64) {
+    e = hipFuncSetAttribute((const void*)gemm_tn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gemm_tn_kernel<64>, dim3(tiles, splits), dim3(512), lds_b, (hipStream_t)stream, a);
+  } else {
+    e = hipFuncSetAttribute((const void*)gemm_tn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gemm_tn_kernel<32>, dim3(tiles, splits), dim3(512), lds_b, (hipStream_t)stream, a);
+  }
   MVPTR_CHECK_LAUNCH("gemm_tn");
   return MVPTR_OK;
 }

@@ -24,9 +24,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const floa
                                                       float* mean, float* rstd, int M, int H,
                                                       int rpg, int gstride, int roff, DropDev drop) {
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= M) return;
   const int nch = H >> 3;
+  // gamma / beta of this lane's columns stay in registers across rows
+  float gm[LN_MAXC][8], bt[LN_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = (lane + 64 * c) * 8 + e;
+      gm[c][e] = (gamma != nullptr && col < H) ? gamma[col] : 1.f;
+      bt[c][e] = (gamma != nullptr && col < H) ? beta[col] : 0.f;
+    }
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
   float v[LN_MAXC][8];
   float s = 0.f;
 #pragma unroll
@@ -69,12 +78,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const floa
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int col = ch * 8 + e;
-        float t = (gamma != nullptr) ? (v[c][e] - mu) * rs * gamma[col] + beta[col] : v[c][e];
+        float t = (gamma != nullptr) ? (v[c][e] - mu) * rs * gm[c][e] + bt[c][e] : v[c][e];
         t = drop_apply(drop, (uint64_t)r * (uint64_t)H + col, t);
         o[e] = f2bf(t);
       }
       *reinterpret_cast<bf16x8*>(y + orow * H + ch * 8) = o;
     }
+  }
   }
 }
 
@@ -405,7 +415,9 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_fwd: rows_per_group must be > 0");
   if (((uintptr_t)z & 15) || ((uintptr_t)y & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "layernorm_fwd: z,y must be 16-byte aligned");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+  int grid = (M + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)z, gamma, beta, eps, (__bf16*)y, mean, rstd, M, H,
                      rows_per_group, group_stride, row_offset, make_dropdev(drop));
   MVPTR_CHECK_LAUNCH("layernorm_fwd");
