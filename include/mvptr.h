@@ -53,11 +53,11 @@ typedef enum {
   MVPTR_EPI_BIAS_TANH = 6    /* out0(bf16) = tanh(acc + bias)                             */
 } mvptr_epilogue;
 
-/* Dropout descriptor: keep-mask bit for element index i is
- *   h = mvptr_hash32((uint32)(i >> 1) ^ seed_lo) ; h2 = mvptr_hash32(h + seed_hi + (uint32)(i >> 33))
- *   (mvptr_hash32 = the 'lowbias32' integer mixer: x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16)
- *   u16 = (i & 1) ? (h2 >> 16) : (h2 & 0xffff) ; keep = u16 >= thresh16
- * with thresh16 = round(p * 65536) and kept values scaled by 65536/(65536-thresh16).
+/* Dropout descriptor.  One 32-bit hash serves the element pair (2j, 2j+1):
+ *   x = ((uint32)j ^ seed_lo) + (uint32)(j >> 32) * 0x9E3779B9;
+ *   x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x += seed_hi; x *= 0x846ca68b; x ^= x >> 16;
+ *   u16(2j) = x & 0xffff ; u16(2j+1) = x >> 16 ; keep(i) = u16(i) >= thresh16
+ * with thresh16 = round(p * 65536); kept values are scaled by 65536/(65536-thresh16).
  * p == 0 (thresh16 == 0) disables dropout.  The element index is op-specific and documented
  * per call.  mvptr_dropout_mask() materialises the same mask for tests. */
 typedef struct {
@@ -102,7 +102,8 @@ int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* str
  * mask_add: f32 [B, L] additive mask (0 / -10000) broadcast over heads and queries,
  * ctx: bf16 [B*L, H], lse: f32 [B, heads, L] (row log-sum-exp, saved for backward; may be
  * NULL in inference).  head_dim must be 64, L <= 256.
- * drop: dropout on the probabilities, element index = ((b*heads + h)*L + q)*L + key. */
+ * drop: dropout on the probabilities, element index = ((b*heads + h)*L + q)*Lp + key with
+ * Lp = L rounded up to a multiple of 32 (adjacent keys of a query form the hash pairs). */
 int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse, int B,
                         int L, int heads, const mvptr_dropout* drop, void* stream);
 
@@ -178,6 +179,25 @@ int mvptr_ce_fwd(const float* logits, int64_t ld, const int64_t* labels, float* 
 int mvptr_ce_bwd(const float* logits, int64_t ld, const int64_t* labels, const float* lse_row,
                  const float* scale, void* dlogits, int64_t ld_d, int M, int V, int Vpad,
                  void* stream);
+
+/* Fused multi-tensor AdamW step with the numerics of
+ * transformers/pytorch_transformers/optimization.py:131-187: m = b1 m + (1-b1) g;
+ * v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) + eps); p *= decay  (decay = 1 - lr*wd,
+ * applied after the Adam update; step_size carries lr and the bias correction).
+ * `table` is a DEVICE array of n_tensors descriptors; chunk_tensor / chunk_offset (device, one
+ * entry per workgroup) map each chunk of `chunk_elems` elements to its tensor. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  float step_size;
+  float decay;
+} mvptr_adamw_tensor;
+int mvptr_adamw_multi(const mvptr_adamw_tensor* table, const int32_t* chunk_tensor,
+                      const int64_t* chunk_offset, int n_chunks, int chunk_elems, float beta1,
+                      float beta2, float eps, void* stream);
 
 /* Materialise the dropout keep-mask (1/0 bytes) for n elements — test support. */
 int mvptr_dropout_mask(const mvptr_dropout* drop, int64_t n, uint8_t* keep, void* stream);

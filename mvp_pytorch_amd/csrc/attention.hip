@@ -184,12 +184,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       float mk[16];
       load_rows16(maskv, kb, hh, mk);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kb + acc_row(r, hh);
-        float pv = __expf(st[r] * 0.125f + mk[r] - lse);
-        if (p.drop.thresh16 != 0)
-          pv = drop_apply(p.drop, ((uint64_t)bh * L + q) * (uint64_t)L + key, pv);
-        st[r] = pv;
+      for (int r = 0; r < 16; ++r) st[r] = __expf(st[r] * 0.125f + mk[r] - lse);
+      if (p.drop.thresh16 != 0) {
+        const uint64_t rowbase = ((uint64_t)bh * L + q) * (uint64_t)Lp + 32 * kb + 4 * hh;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {  // registers r, r+1 hold adjacent keys (even, odd)
+          float a0 = st[r], a1 = st[r + 1];
+          drop_apply2(p.drop, rowbase + (r & 3) + 8 * (r >> 2), a0, a1);
+          st[r] = a0;
+          st[r + 1] = a1;
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -273,6 +277,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tQ, lo_, qb, ks), row_frag_o(tK, lo_, kb, ks), s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tD, lo_, qb, ks), row_frag_o(tV, lo_, kb, ks), dp, 0, 0, 0);
       }
+      // dropout keep bits: the pair (key & ~1, key | 1) of query q shares one hash; this lane
+      // hashes the queries whose register parity equals its key parity and swaps with lane ^ 1
+      uint32_t keepbits = 0xffffu;
+      if (p.drop.thresh16 != 0) {
+        keepbits = 0;
+        const int par = key & 1;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 2) {
+          const int rm = r0 + par;  // the query register this lane hashes
+          const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
+          const uint64_t idx = ((uint64_t)bh * L + qm) * (uint64_t)Lp + (key & ~1);
+          const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
+          const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+          const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
+          const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
+          keepbits |= (um >= p.drop.thresh16 ? 1u : 0u) << rm;
+          keepbits |= (uo >= p.drop.thresh16 ? 1u : 0u) << (rm ^ 1);
+        }
+      }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
         const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lsev + 32 * qb + 8 * t4 + 4 * hh);
@@ -280,11 +303,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * t4 + e;
-          const int q = 32 * qb + 8 * t4 + 4 * hh + e;
           const float pr = __expf(s[r] * 0.125f + mk - ls4[e]);
           float pd = pr, dpp = dp[r];
           if (p.drop.thresh16 != 0) {
-            const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
+            const bool keep = (keepbits >> r) & 1u;
             pd = keep ? pr * p.drop.scale : 0.f;
             dpp = keep ? dpp * p.drop.scale : 0.f;
           }
@@ -334,16 +356,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       }
       float mk16[16];
       load_rows16(maskv, kb, hh, mk16);
+      if (p.drop.thresh16 != 0) {
+        const uint64_t rowbase = ((uint64_t)bh * L + q) * (uint64_t)Lp + 32 * kb + 4 * hh;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float a0 = dp[r], a1 = dp[r + 1];
+          drop_apply2(p.drop, rowbase + (r & 3) + 8 * (r >> 2), a0, a1);
+          dp[r] = a0;
+          dp[r + 1] = a1;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = 32 * kb + acc_row(r, hh);
         const float pr = __expf(s[r] * 0.125f + mk16[r] - ls);
-        float dpp = dp[r];
-        if (p.drop.thresh16 != 0) {
-          const bool keep = mvptr_rand16(((uint64_t)bh * L + q) * (uint64_t)L + key, p.drop.seed_lo, p.drop.seed_hi) >= p.drop.thresh16;
-          dpp = keep ? dpp * p.drop.scale : 0.f;
-        }
-        s[r] = pr * (dpp - dl);  // dS^T
+        s[r] = pr * (dp[r] - dl);  // dS^T
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {

@@ -47,10 +47,22 @@ __device__ __forceinline__ uint32_t mvptr_hash32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-// 16 random bits for element index i (see mvptr.h, mvptr_dropout)
+// One 32-bit hash serves the element PAIR (2j, 2j+1): low 16 bits for the even element, high 16
+// bits for the odd one (see mvptr.h, mvptr_dropout).  Kernels whose lanes own adjacent elements
+// hash once per pair; the attention backward pass that owns one key per lane trades the second
+// hash of a pair with the neighbouring lane.
+__device__ __forceinline__ uint32_t mvptr_pair_hash(uint64_t pair, uint32_t seed_lo, uint32_t seed_hi) {
+  uint32_t x = ((uint32_t)pair ^ seed_lo) + (uint32_t)(pair >> 32) * 0x9E3779B9u;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x += seed_hi;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ uint32_t mvptr_rand16(uint64_t i, uint32_t seed_lo, uint32_t seed_hi) {
-  uint32_t h = mvptr_hash32((uint32_t)(i >> 1) ^ seed_lo);
-  h = mvptr_hash32(h + seed_hi + (uint32_t)(i >> 33));
+  const uint32_t h = mvptr_pair_hash(i >> 1, seed_lo, seed_hi);
   return (i & 1) ? (h >> 16) : (h & 0xffffu);
 }
 struct DropDev {
@@ -73,6 +85,13 @@ static inline DropDev make_dropdev(const mvptr_dropout* d) {
 __device__ __forceinline__ float drop_apply(const DropDev& d, uint64_t idx, float v) {
   if (d.thresh16 == 0) return v;
   return (mvptr_rand16(idx, d.seed_lo, d.seed_hi) >= d.thresh16) ? v * d.scale : 0.f;
+}
+// dropout of the adjacent elements (idx_even, idx_even + 1) with one hash
+__device__ __forceinline__ void drop_apply2(const DropDev& d, uint64_t idx_even, float& v0, float& v1) {
+  if (d.thresh16 == 0) return;
+  const uint32_t h = mvptr_pair_hash(idx_even >> 1, d.seed_lo, d.seed_hi);
+  v0 = ((h & 0xffffu) >= d.thresh16) ? v0 * d.scale : 0.f;
+  v1 = ((h >> 16) >= d.thresh16) ? v1 * d.scale : 0.f;
 }
 
 // erf-GELU (modeling_bert.py:142-148) through erfc(z) = poly(t) * exp(-z^2), t = 1/(1 + p z)

@@ -290,9 +290,17 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs p) {
       for (int e = 0; e < 8; ++e) g[e] = gelu_erf(bf2f(f2bf(v[e])));
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
+      if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]) + a[e];
+        for (int e = 0; e < 8; e += 2)
+          drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_GELU_BWD) {
 #pragma unroll

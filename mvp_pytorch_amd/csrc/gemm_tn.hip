@@ -242,7 +242,7 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
     const double rounds = (double)((tiles * sp + wg_per_round - 1) / wg_per_round);
     const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
-    const double cost = rounds * steps * (wg_per_round == 256 ? 1.0 : 2.0) + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.7;
+    const double cost = rounds * steps * (wg_per_round == 256 ? 1.7 : 2.7) + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.7;
     if (cost < best) {
       best = cost;
       splits = sp;

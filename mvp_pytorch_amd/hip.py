@@ -24,7 +24,7 @@ SYMBOLS = [
     "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
-    "mvptr_ce_bwd", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
+    "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
 ]
 
@@ -87,6 +87,7 @@ def load():
     lib.mvptr_ce_fwd.argtypes = [P, I64, P, P, P, I, I, P]
     lib.mvptr_ce_bwd.argtypes = [P, I64, P, P, P, P, I64, I, I, I, P]
     lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
+    lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
     _lib = lib
@@ -255,3 +256,13 @@ def dropout_mask(drop, n, device):
     keep = torch.empty(n, device=device, dtype=torch.uint8)
     _check(load().mvptr_dropout_mask(_dp(drop), n, _p(keep), _stream()))
     return keep
+
+
+ADAMW_CHUNK = 65536
+
+
+def adamw_multi(table_dev, chunk_tensor_dev, chunk_offset_dev, n_chunks, beta1, beta2, eps):
+    """Fused multi-tensor AdamW (see mvptr_adamw_multi); tables are device tensors built by
+    mvp_pytorch_amd.optimization.AdamW."""
+    _check(load().mvptr_adamw_multi(_p(table_dev), _p(chunk_tensor_dev), _p(chunk_offset_dev), n_chunks,
+                                    ADAMW_CHUNK, float(beta1), float(beta2), float(eps), _stream()))

@@ -1,9 +1,11 @@
 """AdamW + LR schedules with the numerics of transformers/pytorch_transformers/optimization.py
 (:107-189 AdamW — decoupled weight decay applied after the Adam update, bias correction on by
 default, eps 1e-6; :33-61 warmup schedules).  The update runs as fused multi-tensor torch ops
-on the device (a handful of launches per step instead of ~5 per parameter)."""
+on the device, or — for f32 parameters on a HIP device — as ONE fused multi-tensor HIP kernel
+(mvptr_adamw_multi: 28 bytes of HBM traffic per parameter instead of ~6 passes)."""
 import math
 
+import numpy as np
 import torch
 from torch.optim import Optimizer
 from torch.optim.lr_scheduler import LambdaLR
@@ -84,19 +86,59 @@ class AdamW(Optimizer):
                 vs.append(st["exp_avg_sq"])
             if not ps:
                 continue
+            step_size = group["lr"]
+            if group["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** step_no) / (1.0 - b1 ** step_no)
+            if ps[0].is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for p in ps) and \
+                    all(g.dtype == torch.float32 and g.is_contiguous() for g in gs):
+                self._fused(ps, gs, ms, vs, b1, b2, group["eps"], step_size, 1.0 - group["lr"] * group["weight_decay"])
+                continue
             torch._foreach_mul_(ms, b1)
             torch._foreach_add_(ms, gs, alpha=1.0 - b1)
             torch._foreach_mul_(vs, b2)
             torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
             denom = torch._foreach_sqrt(vs)
             torch._foreach_add_(denom, group["eps"])
-            step_size = group["lr"]
-            if group["correct_bias"]:
-                step_size = step_size * math.sqrt(1.0 - b2 ** step_no) / (1.0 - b1 ** step_no)
             torch._foreach_addcdiv_(ps, ms, denom, value=-step_size)
             if group["weight_decay"] > 0.0:
                 torch._foreach_mul_(ps, 1.0 - group["lr"] * group["weight_decay"])
         return loss
+
+    _TABLE_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
+                          ("step_size", "<f4"), ("decay", "<f4")])
+
+    def _fused(self, ps, gs, ms, vs, b1, b2, eps, step_size, decay):
+        """One launch for the whole group through the C ABI (mvptr_adamw_multi)."""
+        from . import hip
+        dev = ps[0].device
+        key = tuple(p.data_ptr() for p in ps)
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            ct, co = [], []
+            for i, p in enumerate(ps):
+                for off in range(0, p.numel(), hip.ADAMW_CHUNK):
+                    ct.append(i)
+                    co.append(off)
+            ent = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev), len(ct))
+            cache[key] = ent
+        tab = np.zeros(len(ps), dtype=self._TABLE_DT)
+        tab["p"] = [p.data_ptr() for p in ps]
+        tab["g"] = [g.data_ptr() for g in gs]
+        tab["m"] = [m.data_ptr() for m in ms]
+        tab["v"] = [v.data_ptr() for v in vs]
+        tab["n"] = [p.numel() for p in ps]
+        tab["step_size"] = step_size
+        tab["decay"] = decay
+        tab_dev = torch.from_numpy(tab.view(np.uint8)).to(dev, non_blocking=True)
+        hip.adamw_multi(tab_dev, ent[0], ent[1], ent[2], b1, b2, eps)
+        # the kernel updated the parameters outside autograd's view; the bf16 weight caches key on
+        # Tensor._version, so mark the tensors as modified
+        setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+        if setter is not None:
+            setter(ps, [p._version + 1 for p in ps])
+        else:
+            torch._foreach_add_(ps, 0.0)
 
     @staticmethod
     def _single(p, st, group):

@@ -169,7 +169,8 @@ def test_attention_dropout(dev):
     qkv = _bf(torch.randn(B * L, 3 * H, generator=g)).to(dev)
     mask = torch.zeros(B, L, device=dev)
     drop = hip.make_dropout(0.1, 987654321)
-    keep = hip.dropout_mask(drop, B * heads * L * L, dev).reshape(B, heads, L, L).float()
+    Lp = (L + 31) // 32 * 32  # element index = ((b*heads+h)*L + q)*Lp + key
+    keep = hip.dropout_mask(drop, B * heads * L * Lp, dev).reshape(B, heads, L, Lp)[..., :L].float()
     scale = 65536.0 / (65536.0 - drop.thresh16)
     ctx, lse = hip.attention_fwd(qkv, mask, B, L, heads, drop=drop)
     qr = qkv.float().clone().requires_grad_(True)
@@ -284,3 +285,31 @@ def test_cross_entropy(dev):
     d = hip.ce_bwd(logits, labels, lse, scale, V, Vpad)
     assert torch.all(d[:, V:] == 0)
     assert _rel(d[:, :V], lr.grad) < 4e-3
+
+
+def test_fused_adamw_matches_oracle(dev):
+    """mvptr_adamw_multi (through mvp_pytorch_amd.optimization.AdamW) against the oracle's
+    restatement of optimization.py:131-187, three steps, two weight-decay groups, ragged sizes."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mvptr_oracle as orc
+    from mvp_pytorch_amd.optimization import AdamW
+    g = torch.Generator(device="cpu").manual_seed(12)
+    shapes = {"a.weight": (300, 257), "a.bias": (300,), "b.LayerNorm.weight": (131075,), "c.weight": (7,), "d": ()}
+    ref = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    params = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in ref.items()}
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in params.items() if not any(x in n for x in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in params.items() if any(x in n for x in no_decay)], "weight_decay": 0.0}]
+    opt = AdamW(groups, lr=1e-2, eps=1e-8)
+    state = {}
+    for step in range(3):
+        grads = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+        for k, p in params.items():
+            p.grad = grads[k].to(dev)
+        v0 = params["a.weight"]._version
+        opt.step()
+        assert params["a.weight"]._version > v0
+        orc.adamw_step(ref, grads, state, lr=1e-2, eps=1e-8, weight_decay=lambda n: 0.0 if any(x in n for x in no_decay) else 0.01)
+    for k in shapes:
+        assert torch.allclose(params[k].detach().cpu(), ref[k], rtol=2e-5, atol=1e-6), k
