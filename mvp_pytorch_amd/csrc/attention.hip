@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ----------------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;

@@ -116,10 +116,21 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * cdf2 + x * e * 0.39894228040143267794f;
 }
 
+// Sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (quad
+// swaps, half-row mirror, row mirror) and four v_readlane for the rows — no LDS crossbar
+// (ds_bpermute) round trips, which dominated the row kernels.
+#define MVPTR_DPP_ADD(v, ctrl) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = MVPTR_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
+  v = MVPTR_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
+  v = MVPTR_DPP_ADD(v, 0x141);  // row_half_mirror
+  v = MVPTR_DPP_ADD(v, 0x140);  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -72,7 +72,7 @@ struct GemmNtArgs {
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
 template <int EPI, int BK>
-__global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs p) {
+__global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNtArgs p) {
   using C = Cfg<BK>;
   constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, ROW_B = C::ROW_B, CHUNKS = C::CHUNKS;
   constexpr int RPI = C::ROWS_PER_INSTR, NA = C::NA, NB = C::NB, KS = C::KS;

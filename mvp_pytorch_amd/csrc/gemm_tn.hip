@@ -47,7 +47,7 @@ extern __shared__ __attribute__((aligned(1024))) char lds[];
 // 2x2 v_mfma_f32_32x32x16_bf16), 64 token rows per step, 3-stage LDS ring with a counted
 // vmcnt(6) + raw s_barrier (two steps in flight).
 template <int TM_>
-__global__ __launch_bounds__(512) void gemm_tn_kernel(GemmTnArgs p) {
+__global__ __launch_bounds__(512, (TM_ == 32 ? 4 : 2)) void gemm_tn_kernel(GemmTnArgs p) {
   constexpr int SUB_B = TM_ * 256;     // one TM_ x 128 bf16 sub-tile
   constexpr int STAGE_B = 3 * SUB_B;   // A = 2 sub-tiles (256 n), B = 1 sub-tile (128 k)
   constexpr int GROUPS = TM_ / 4;      // 4-row wave instructions per sub-tile
