@@ -89,9 +89,10 @@ int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M,
  * Replaces the weight gradient of nn.Linear computed by autograd (addmm backward) for every
  * Linear cited above.  The caller zeroes dW when it wants a fresh gradient.
  * lda % 8 == 0, ldb % 8 == 0 (rows padded so that partial 16-byte chunks at the N/K edge stay
- * inside the row). */
+ * inside the row).  colsum: optional f32[N], += column sums of A (the bias gradient of the
+ * same layer, computed from the tiles already in LDS). */
 int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
-                  float* dW, int64_t ldw, void* stream);
+                  float* dW, int64_t ldw, float* colsum, void* stream);
 
 /* Column sums: out[n] += sum_m X[m,n] (X bf16 [M, ldx]); bias gradients. */
 int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream);

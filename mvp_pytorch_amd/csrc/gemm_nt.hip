@@ -27,13 +27,14 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 128, STAGES = 3;
 constexpr int ST_LD = 68;  // f32 row stride of the epilogue staging block
 constexpr int GROUP_M = 4;
 // BK = 64: 3 x 48 KiB ring, one workgroup per CU.  BK = 32: 3 x 24 KiB ring, two workgroups per
 // CU, so one workgroup's epilogue (stores) overlaps the other's MFMA main loop.
-template <int BK>
+template <int BK, int STAGES, int WM, int WN, int MT_>
 struct Cfg {
+  static constexpr int BM = WM * MT_ * 16;         // workgroup tile rows
+  static constexpr int BN = WN * 64;               // workgroup tile columns (each wave owns 64)
   static constexpr int A_BYTES = BM * BK * 2;
   static constexpr int B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -41,8 +42,11 @@ struct Cfg {
   static constexpr int ROW_B = BK * 2;             // bytes per LDS row
   static constexpr int CHUNKS = BK / 8;            // 16-byte chunks per row
   static constexpr int ROWS_PER_INSTR = 1024 / ROW_B;
-  static constexpr int NA = BM / ROWS_PER_INSTR / 8;  // A staging instructions per wave
-  static constexpr int NB = BN / ROWS_PER_INSTR / 8;  // B staging instructions per wave
+  static constexpr int NWAVES = WM * WN;           // waves as WM (M) x WN (N)
+  static constexpr int MT = MT_;                   // 16-row MFMA tiles per wave (4: 64 rows, 8: 128 rows)
+  static constexpr int WG_PER_CU = (STAGES * (BM + BN) * BK * 2 <= 80 * 1024) ? 2 : 1;
+  static constexpr int NA = BM / ROWS_PER_INSTR / NWAVES;  // A staging instructions per wave
+  static constexpr int NB = BN / ROWS_PER_INSTR / NWAVES;  // B staging instructions per wave
   static constexpr int KS = BK / 32;               // MFMA k-substeps per stage
 };
 // chunk swizzles that make the 16x16x32 ds_read_b128 fragment reads conflict free
@@ -71,11 +75,16 @@ struct GemmNtArgs {
 
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
-template <int EPI, int BK>
-__global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNtArgs p) {
-  using C = Cfg<BK>;
+// WM = 4: 8 waves of 64x64 (512 threads).  WM = 2: 4 waves of 128x64 (256 threads): 25 % fewer LDS
+// fragment reads per MFMA and half the waves per barrier, 256 registers per wave available.
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_>
+__global__ __launch_bounds__(WM * WN * 64, (Cfg<BK, STAGES, WM, WN, MT_>::WG_PER_CU * WM * WN / 4))
+void gemm_nt_kernel(GemmNtArgs p) {
+  using C = Cfg<BK, STAGES, WM, WN, MT_>;
+  constexpr int BM = C::BM, BN = C::BN;
   constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, ROW_B = C::ROW_B, CHUNKS = C::CHUNKS;
   constexpr int RPI = C::ROWS_PER_INSTR, NA = C::NA, NB = C::NB, KS = C::KS;
+  constexpr int NWAVES = C::NWAVES, MT = C::MT, WROWS = C::MT * 16;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,14 +112,14 @@ __global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNt
   int kcA[NA], kcB[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = (i * 8 + wave) * RPI + lane / CHUNKS;
+    const int row = (i * NWAVES + wave) * RPI + lane / CHUNKS;
     const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
     kcA[i] = c * 8;
     offA[i] = (uint32_t)(row * p.lda * 2 + c * 16);
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int row = (i * 8 + wave) * RPI + lane / CHUNKS;
+    const int row = (i * NWAVES + wave) * RPI + lane / CHUNKS;
     const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
     kcB[i] = c * 8;
     offB[i] = (uint32_t)(row * p.ldb * 2 + c * 16);
@@ -121,70 +130,84 @@ __global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNt
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const uint32_t va = (k0 + kcA[i] < p.K) ? offA[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * 8 + wave) * 1024), 16, va, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const uint32_t vb = (k0 + kcB[i] < p.K) ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * 8 + wave) * 1024), 16, vb, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
     }
   };
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int c16 = lane & 15, q4 = lane >> 4;
-  uint32_t fx[4][KS], fw[4][KS];
+  uint32_t fx[MT][KS], fw[4][KS];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rx = wm * WROWS + i * 16 + c16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fx[i][ks] = rx * ROW_B + (((ks * 4 + q4) ^ swz_row(rx, CHUNKS)) << 4);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int rx = wm * 64 + i * 16 + c16;
     const int rw = wn * 64 + i * 16 + c16;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int ch = ks * 4 + q4;
-      fx[i][ks] = rx * ROW_B + ((ch ^ swz_row(rx, CHUNKS)) << 4);
-      fw[i][ks] = rw * ROW_B + ((ch ^ swz_row(rw, CHUNKS)) << 4);
-    }
+    for (int ks = 0; ks < KS; ++ks) fw[i][ks] = rw * ROW_B + (((ks * 4 + q4) ^ swz_row(rw, CHUNKS)) << 4);
   }
 
-  f32x4 acc[4][4];  // [nt][mt]
+  f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  stage(0, 0);
-  if (nk > 1) stage(1, BK);
+  // prologue: STAGES-1 stages in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s * BK);
   int buf = 0;
+  constexpr int LPS = NA + NB;  // loads per stage per thread
   for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once at most the NA+NB loads of stage kt+1 remain in flight
-    if (kt + 1 < nk) {
-      if (NA + NB == 6)
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-    } else {
+    // stage kt has landed once only the loads of the (up to STAGES-2) younger stages remain
+    const int younger = min(STAGES - 2, nk - 1 - kt);
+    if (younger >= 3)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
+    else if (younger == 2)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (younger == 1)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (kt + 2 < nk) {
-      int nb = buf + 2;
-      if (nb >= STAGES) nb -= STAGES;
-      stage(nb, (kt + 2) * BK);
-    }
     const char* la = lds + buf * STAGE_BYTES;
     const char* lb = la + A_BYTES;
+    // fragment reads of the first k-substep are issued before the next stage's address math and
+    // LDS-DMA issue, so that work overlaps the LDS read latency instead of preceding it
+    bf16x8 xf[MT], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
+    if (kt + STAGES - 1 < nk) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, (kt + STAGES - 1) * BK);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 xf[4], wf[4];
+      if (ks > 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][ks]);
-        wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][ks]);
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][ks]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][ks]);
       }
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
@@ -229,45 +252,45 @@ __global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNt
     }
   };
 
-  // all residual / pre-activation rows of this lane are requested before any is consumed, so the
-  // epilogue pays one memory latency, not eight
   constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
   const bool has_aux = kNeedsAux && p.aux != nullptr;
-  bf16x8 auxv[8];
-  if (kNeedsAux) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int m = m0 + wm * 64 + it * 8 + rsub;
-      bf16x8 x;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
-      if (has_aux && m < p.M && n < p.N) {
-        const __bf16* ap = p.aux + (int64_t)m * p.ld_aux + n;
-        if (nfull && p.vec_aux_ok) {
-          x = *reinterpret_cast<const bf16x8*>(ap);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) x[e] = ap[e];
-        }
-      }
-      auxv[it] = x;
-    }
-  }
 
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < MT * 2; ++it) {
+    // 32-row chunk ck = it >> 2 of the wave's block goes through the staging area; its residual /
+    // pre-activation rows are requested together so the chunk pays one memory latency, not four
+    bf16x8 auxv[4];
     if ((it & 3) == 0) {
-      const int half = it >> 2;
+      const int ck = it >> 2;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
-          *reinterpret_cast<f32x4*>(st + (mh * 16 + c16) * ST_LD + nt * 16 + q4 * 4) = acc[nt][2 * half + mh];
+          *reinterpret_cast<f32x4*>(st + (mh * 16 + c16) * ST_LD + nt * 16 + q4 * 4) = acc[nt][2 * ck + mh];
+    }
+    if (kNeedsAux && (it & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mj = m0 + wm * WROWS + (it + j) * 8 + rsub;
+        bf16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
+        if (has_aux && mj < p.M && n < p.N) {
+          const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
+          if (nfull && p.vec_aux_ok) {
+            x = *reinterpret_cast<const bf16x8*>(ap);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e < p.N) x[e] = ap[e];
+          }
+        }
+        auxv[j] = x;
+      }
     }
     const int row = it * 8 + rsub;
     const int lrow = row & 31;
-    const int m = m0 + wm * 64 + row;
+    const int m = m0 + wm * WROWS + row;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8 + 4);
     if (m >= p.M || n >= p.N) continue;
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNt
     }
     if (kNeedsAux) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it][e]);
+      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it & 3][e]);
     }
     if (EPI == MVPTR_EPI_BIAS) {
       store_bf8(p.out0, m, v);
@@ -342,24 +365,36 @@ __global__ __launch_bounds__(512, (BK == 32 ? 4 : 2)) void gemm_nt_kernel(GemmNt
   }
 }
 
-template <int EPI, int BK>
-int launch_bk(const GemmNtArgs& a, hipStream_t s) {
-  constexpr int LDS_BYTES = Cfg<BK>::LDS_BYTES;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK>,
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_>
+int launch_bk(GemmNtArgs a, hipStream_t s) {
+  using C = Cfg<BK, STAGES, WM, WN, MT_>;
+  constexpr int LDS_BYTES = C::LDS_BYTES;
+  a.tiles_m = (a.M + C::BM - 1) / C::BM;
+  a.tiles_n = (a.N + C::BN - 1) / C::BN;
+  if ((int64_t)C::BM * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)C::BN * a.ldb * 2 >= (int64_t)0x7fffffff)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK>), dim3(nwg), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
 }
 
 template <int EPI>
 int launch(const GemmNtArgs& a, hipStream_t s) {
-  // MVPTR_GEMM_BK=64 selects the one-workgroup-per-CU variant (tuning knob, default 32)
-  const char* env = getenv("MVPTR_GEMM_BK");
-  if (env != nullptr && env[0] == '6') return launch_bk<EPI, 64>(a, s);
-  return launch_bk<EPI, 32>(a, s);
+  // Tile configurations (BK 32, 3-stage ring):
+  //   "t256"  256x256, 8 waves of 128x64, one workgroup per CU — lowest L2->LDS bytes per FLOP
+  //   "w4"    256x128, 8 waves of 64x64, two workgroups per CU — default for N < 1024
+  //   "w2"    256x128, 4 waves of 128x64, two workgroups per CU
+  // MVPTR_GEMM_CFG overrides the choice (tuning knob).
+  const char* env = getenv("MVPTR_GEMM_CFG");
+  int cfg = (a.N >= 1024 && a.N % 256 == 0) ? 2 : 0;
+  if (env != nullptr) cfg = (env[0] == 't') ? 2 : (env[0] == 'w' && env[1] == '2') ? 1 : 0;
+  if (cfg == 2) return launch_bk<EPI, 32, 3, 2, 4, 8>(a, s);
+  if (cfg == 1) return launch_bk<EPI, 32, 3, 2, 2, 8>(a, s);
+  return launch_bk<EPI, 32, 3, 4, 2, 4>(a, s);
 }
 
 }  // namespace
@@ -375,8 +410,6 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt: A and B must be 16-byte aligned");
   if (lda < K || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: lda/ldb smaller than K");
-  if ((int64_t)BM * lda * 2 >= (int64_t)0x7fffffff || (int64_t)BN * ldb * 2 >= (int64_t)0x7fffffff)
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
   if (out0 == nullptr) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: out0 is NULL");
   GemmNtArgs a;
   a.A = (const __bf16*)A;
@@ -394,8 +427,7 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.ldc = ldc;
   a.vec_out = vec_out;
   a.drop = make_dropdev(drop);
-  a.tiles_m = (M + BM - 1) / BM;
-  a.tiles_n = (N + BN - 1) / BN;
+  a.tiles_m = a.tiles_n = 0;  // set per tile configuration in launch_bk
   const int esz = (epilogue == MVPTR_EPI_F32) ? 4 : 2;
   bool vo = (ldc % 8 == 0) && (((uintptr_t)out0 & 15) == 0);
   if (out1) vo = vo && (((uintptr_t)out1 & 15) == 0);

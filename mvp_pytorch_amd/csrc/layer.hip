@@ -139,11 +139,11 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
                           g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
                           hdrop ? &dr_out : nullptr, lnws, lnws_bytes, stream));
   const char* d2 = hdrop ? bufB : bufA;
-  if (g->w_out) RUN(mvptr_gemm_tn(d2, H, s.a, I, M, H, I, g->w_out, I, stream));
+  if (g->w_out) RUN(mvptr_gemm_tn(d2, H, s.a, I, M, H, I, g->w_out, I, nullptr, stream));
   RUN(mvptr_gemm_nt(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
                     I, g->b_i, nullptr, stream));
   // intermediate.dense
-  if (g->w_i) RUN(mvptr_gemm_tn(bufU, I, s.x1, H, M, I, H, g->w_i, H, stream));
+  if (g->w_i) RUN(mvptr_gemm_tn(bufU, I, s.x1, H, M, I, H, g->w_i, H, nullptr, stream));
   RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
                     nullptr, nullptr, stream));
   // attention.output.LayerNorm / dense
@@ -151,15 +151,19 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
                           g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
                           hdrop ? &dr_o : nullptr, lnws, lnws_bytes, stream));
   const char* d1 = hdrop ? bufB : bufA;
-  if (g->w_o) RUN(mvptr_gemm_tn(d1, H, s.ctx, H, M, H, H, g->w_o, H, stream));
+  if (g->w_o) RUN(mvptr_gemm_tn(d1, H, s.ctx, H, M, H, H, g->w_o, H, nullptr, stream));
   RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
                     nullptr, nullptr, stream));
   // attention core
   RUN(mvptr_attention_bwd(s.qkv, mask_add, s.ctx, bufC, s.lse, bufU, d->B, d->L, d->heads, &dr_attn,
                           stream));
   // Q/K/V projections
-  if (g->b_qkv) RUN(mvptr_colsum(bufU, 3 * H, M, 3 * H, g->b_qkv, stream));
-  if (g->w_qkv) RUN(mvptr_gemm_tn(bufU, 3 * H, x, H, M, 3 * H, H, g->w_qkv, H, stream));
+  // the Q/K/V bias gradient (column sums of dqkv) rides on the weight-gradient kernel
+  if (g->w_qkv) {
+    RUN(mvptr_gemm_tn(bufU, 3 * H, x, H, M, 3 * H, H, g->w_qkv, H, g->b_qkv, stream));
+  } else if (g->b_qkv) {
+    RUN(mvptr_colsum(bufU, 3 * H, M, 3 * H, g->b_qkv, stream));
+  }
   RUN(mvptr_gemm_nt(bufU, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufA, H, dx,
                     nullptr, H, nullptr, nullptr, stream));
   return MVPTR_OK;

@@ -336,14 +336,14 @@ class LinearFn(torch.autograd.Function):
                 pad[:, :N] = du
                 du = pad
             dy2 = du
-        if db is not None:
-            hip.colsum(dy2, db, n=N)
         dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
         dw = None
         if ctx.needs[1]:
             dw = torch.zeros((N, x2.shape[1]), device=dev, dtype=torch.float32)
-            hip.gemm_tn(dy2, x2, dw, n=N)
+            hip.gemm_tn(dy2, x2, dw, n=N, colsum=db)   # bias gradient rides on the weight gradient
             dw = dw[:, :K]
+        elif db is not None:
+            hip.colsum(dy2, db, n=N)
         if dx is not None:
             dx = dx.view(ctx.xshape)
         return dx, dw, (db if ctx.needs[2] else None), None, None
@@ -400,11 +400,12 @@ class DecoderCEFn(torch.autograd.Function):
         H = h.shape[1]
         dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H) if ctx.needs[0] else None
         dw = db = None
-        if ctx.needs[1]:
-            dw = torch.zeros((V, H), device=h.device, dtype=torch.float32)
-            hip.gemm_tn(d, h, dw, n=V)
         if ctx.needs[2]:
             db = torch.zeros(V, device=h.device, dtype=torch.float32)
+        if ctx.needs[1]:
+            dw = torch.zeros((V, H), device=h.device, dtype=torch.float32)
+            hip.gemm_tn(d, h, dw, n=V, colsum=db)
+        elif db is not None:
             hip.colsum(d, db, n=V)
         ctx.save = None
         return dh, dw, db, None, None

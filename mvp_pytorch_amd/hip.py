@@ -72,7 +72,7 @@ def load():
     P, I64, I, F = c_void_p, c_int64, c_int, c_float
     lib.mvptr_query.argtypes = [I, POINTER(c_int64)]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
-    lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P]
+    lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
@@ -151,14 +151,14 @@ def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, v
     return (out, out1) if epilogue == EPI_BIAS_GELU else out
 
 
-def gemm_tn(dy, x, dw, n=None, k=None):
-    """dw[N,K] += dy[M,N]^T @ x[M,K]  (f32 accumulate into dw)."""
+def gemm_tn(dy, x, dw, n=None, k=None, colsum=None):
+    """dw[N,K] += dy[M,N]^T @ x[M,K]  (f32 accumulate into dw); colsum[N] += column sums of dy."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
     M = dy.shape[0]
     N = dy.shape[1] if n is None else n
     K = x.shape[1] if k is None else k
     assert x.shape[0] == M and dw.stride(1) == 1
-    _check(load().mvptr_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), M, N, K, _p(dw), dw.stride(0), _stream()))
+    _check(load().mvptr_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), M, N, K, _p(dw), dw.stride(0), _p(colsum), _stream()))
     return dw
 
 

@@ -41,7 +41,10 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
     scheduler.step()
-    optimizer.zero_grad(set_to_none=True)
+    if grad_sync is not None and hasattr(grad_sync, "zero_grad"):
+        grad_sync.zero_grad()   # keeps p.grad attached to the communication buckets
+    else:
+        optimizer.zero_grad(set_to_none=True)
     if return_losses:
         return [o.detach() for o in outputs]
     return loss.detach()

@@ -180,28 +180,34 @@ def _dp_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
-    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
-    for p in m[2].parameters():
-        pass
-    sync = dp.GradSync(m, bucket_mb=0.0002)  # tiny buckets -> several collectives
-    assert len(sync.buckets) > 1
-    g = torch.Generator().manual_seed(100 + rank)
-    grads = []
-    for i, p in enumerate(m.parameters()):
-        if i == 5 and rank == 1:
-            p.grad = None  # a rank that produced no gradient for a parameter (qa_head-like)
-            grads.append(torch.zeros_like(p))
-        else:
-            p.grad = torch.randn(p.shape, generator=g)
-            grads.append(p.grad.clone())
-    sync()
-    out = [p.grad.clone() for p in m.parameters()]
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    unused = torch.nn.Linear(3, 3)  # never touched by the loss (like qa_head, modeling_vlbert.py:1184)
+    m.add_module("unused", unused)
+    sync = dp.GradSync(m, bucket_mb=0.0002)  # tiny buckets -> several collectives, launched from hooks
+    assert len(sync.buckets) > 2
+    results = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        x = torch.randn(5, 8, generator=g)
+        out = m[3](m[2](m[1](m[0](x))))
+        # the same sub-module used twice in one graph (mul_encoder runs on the joint and the hard batch)
+        loss = (out ** 2).sum() + m[3](m[2](torch.tanh(m[0](x * 0.5)))).sum()
+        loss.backward()
+        sync()
+        results.append([None if p.grad is None else p.grad.detach().clone().numpy() for p in m.parameters()])
+        # reference: gradient of the same loss computed locally, to be averaged by the parent
+        ref = torch.autograd.grad((m[3](m[2](m[1](m[0](x)))) ** 2).sum() + m[3](m[2](torch.tanh(m[0](x * 0.5)))).sum(),
+                                  [p for n, p in m.named_parameters() if not n.startswith("unused")])
+        results[-1].append([r.numpy() for r in ref])
+        sync.zero_grad()
     vals = dp.all_reduce_metrics([float(rank + 1), 2.0, 3.0], torch.device("cpu"))
-    q.put((rank, [t.numpy() for t in grads], [t.numpy() for t in out], vals))
+    q.put((rank, results, vals))
     dist.destroy_process_group()
 
 
 def test_grad_sync_two_ranks_gloo():
+    """world_size-2 gloo run of the overlapped bucketed all-reduce: hooks launch buckets during
+    backward, gradients are averaged in place, unused parameters do not stall or desynchronise."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -209,14 +215,21 @@ def test_grad_sync_two_ranks_gloo():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, g0, o0, v0), (_, g1, o1, v1) = res
-    for a, b, x, y in zip(g0, g1, o0, o1):
-        want = (a + b) / 2
-        assert np.allclose(x, want, atol=1e-6) and np.allclose(y, want, atol=1e-6)
+    (_, r0, v0), (_, r1, v1) = res
+    for step in range(3):
+        g0, g1 = r0[step], r1[step]
+        local0, local1 = g0[-1], g1[-1]
+        used = [a for a in g0[:-1]][:len(local0)]
+        for i, (a, b) in enumerate(zip(local0, local1)):
+            want = (a + b) / 2
+            assert np.allclose(g0[i], want, atol=1e-5), (step, i)
+            assert np.allclose(g1[i], want, atol=1e-5), (step, i)
+        for extra0, extra1 in zip(g0[len(local0):-1], g1[len(local1):-1]):  # unused params: zero grads
+            assert np.all(extra0 == 0) and np.all(extra1 == 0)
     assert v0 == v1 == [3.0, 4.0, 6.0]
 
 

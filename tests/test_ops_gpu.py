@@ -1,6 +1,7 @@
 """Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 on the same
 bf16-rounded inputs.  Tolerances are for bf16 outputs with f32 accumulation."""
 import math
+import os
 
 import pytest
 import torch
@@ -25,13 +26,19 @@ def test_gemm_nt_bias(dev, M, N, K):
     a = _bf(torch.randn(M, K, generator=g)).to(dev)
     b = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
-    out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
     ref = a.float() @ b.float().t() + bias
-    err = _rel(out, ref)
-    print("gemm_nt bias", M, N, K, err)
-    assert err < 4e-3
-    out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
-    assert _rel(out32, ref) < 1e-5
+    for cfg in ("t256", "w4", "w2", None):  # every tile configuration + the default choice
+        if cfg is None:
+            os.environ.pop("MVPTR_GEMM_CFG", None)
+        else:
+            os.environ["MVPTR_GEMM_CFG"] = cfg
+        out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
+        err = _rel(out, ref)
+        print("gemm_nt bias", cfg, M, N, K, err)
+        assert err < 4e-3
+        out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
+        assert _rel(out32, ref) < 1e-5
+    os.environ.pop("MVPTR_GEMM_CFG", None)
 
 
 def test_gemm_nt_identity_layout(dev):
@@ -99,14 +106,22 @@ def test_gemm_tn(dev, M, N, K):
     dy[:, :N] = _bf(torch.randn(M, N, generator=g))
     dy = dy.to(dev)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    dw = torch.zeros(N, K, device=dev)
-    hip.gemm_tn(dy, x, dw, n=N)
-    ref = dy[:, :N].float().t() @ x.float()
-    err = _rel(dw, ref)
-    print("gemm_tn", M, N, K, err)
-    assert err < 1e-5
-    hip.gemm_tn(dy, x, dw, n=N)  # accumulates
-    assert _rel(dw, 2 * ref) < 1e-5
+    for cfg in ("32", "64", "k2", None):  # every tile configuration + the planner's own choice
+        if cfg is None:
+            os.environ.pop("MVPTR_GEMM_TN", None)
+        else:
+            os.environ["MVPTR_GEMM_TN"] = cfg
+        dw = torch.zeros(N, K, device=dev)
+        cs = torch.zeros(N, device=dev)
+        hip.gemm_tn(dy, x, dw, n=N, colsum=cs)
+        ref = dy[:, :N].float().t() @ x.float()
+        err = _rel(dw, ref)
+        print("gemm_tn", cfg, M, N, K, err)
+        assert err < 1e-5
+        assert _rel(cs, dy[:, :N].float().sum(0)) < 1e-5
+        hip.gemm_tn(dy, x, dw, n=N)  # accumulates
+        assert _rel(dw, 2 * ref) < 1e-5
+    os.environ.pop("MVPTR_GEMM_TN", None)
 
 
 def test_gemm_tn_layout_exact(dev):

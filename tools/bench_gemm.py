@@ -52,7 +52,8 @@ def main():
         for name, dy, xx in [("w_qkv", x3, x), ("w_o", x, x), ("w_i", xi, x), ("w_out", x, xi)]:
             N, K = dy.shape[1], xx.shape[1]
             dw = torch.zeros(N, K, device=dev)
-            us = timeit(lambda: hip.gemm_tn(dy, xx, dw))
+            cs = torch.zeros(N, device=dev) if name == "w_qkv" else None
+            us = timeit(lambda: hip.gemm_tn(dy, xx, dw, colsum=cs))
             print("gemm_tn M=%5d N=%4d K=%4d %-22s %8.1f us  %7.1f TFLOP/s" % (M, N, K, name, us, 2.0 * M * N * K / us / 1e6))
     for L in (75, 70, 125):
         B, heads = 256, 12
