@@ -390,7 +390,11 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   //   "w2"    256x128, 4 waves of 128x64, two workgroups per CU
   // MVPTR_GEMM_CFG overrides the choice (tuning knob).
   const char* env = getenv("MVPTR_GEMM_CFG");
-  int cfg = (a.N >= 1024 && a.N % 256 == 0) ? 2 : 0;
+  // measured on MI355X (round 1): the 256x256 tile wins (+15..25 %) when the main loop dominates
+  // (K >= 1536) and its tiles fill the 256 CUs without a ragged second round; otherwise the two
+  // co-resident 256x128 workgroups hide each other's prologue / epilogue better
+  const int t256 = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  int cfg = (a.K >= 1536 && (t256 <= 256 || t256 >= 768)) ? 2 : 0;
   if (env != nullptr) cfg = (env[0] == 't') ? 2 : (env[0] == 'w' && env[1] == '2') ? 1 : 0;
   if (cfg == 2) return launch_bk<EPI, 32, 3, 2, 4, 8>(a, s);
   if (cfg == 1) return launch_bk<EPI, 32, 3, 2, 2, 8>(a, s);
