@@ -24,6 +24,7 @@
 //    loads and 16-byte coalesced stores.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -77,7 +78,7 @@ extern __shared__ __attribute__((aligned(1024))) char lds[];
 
 // WM = 4: 8 waves of 64x64 (512 threads).  WM = 2: 4 waves of 128x64 (256 threads): 25 % fewer LDS
 // fragment reads per MFMA and half the waves per barrier, 256 registers per wave available.
-template <int EPI, int BK, int STAGES, int WM, int WN, int MT_>
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, bool PF>
 __global__ __launch_bounds__(WM * WN * 64, (Cfg<BK, STAGES, WM, WN, MT_>::WG_PER_CU * WM * WN / 4))
 void gemm_nt_kernel(GemmNtArgs p) {
   using C = Cfg<BK, STAGES, WM, WN, MT_>;
@@ -162,12 +163,63 @@ void gemm_nt_kernel(GemmNtArgs p) {
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
+  constexpr int LPS = NA + NB;  // loads per stage per thread
+  if constexpr (PF) {
+    // Fragment-prefetch schedule (KS == 1, 3-buffer ring): the fragments of K-step kt+1 are read
+    // from LDS into a second register set while the MFMAs of K-step kt run, so the LDS read
+    // latency is off the critical path; three stages are requested ahead of the consumer.
+    static_assert(KS == 1 && STAGES == 3, "prefetch schedule is written for BK = 32, 3 buffers");
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < nk) stage(s, s * BK);
+    if (nk >= 3)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (nk == 2)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    bf16x8 xa[MT], wa[4], xb[MT], wb[4];
+    auto load_frags = [&](int bufi, bf16x8(&xf)[MT], bf16x8(&wf)[4]) {
+      const char* la = lds + bufi * STAGE_BYTES;
+      const char* lb = la + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
+    };
+    load_frags(0, xa, wa);
+    int bcur = 0;
+    auto body = [&](int kt, bf16x8(&xc)[MT], bf16x8(&wc)[4], bf16x8(&xn)[MT], bf16x8(&wn_)[4]) {
+      if (kt + 1 < nk) {
+        // stage kt+1 landed (only stage kt+2 may still be in flight); this wave's reads of stage kt
+        // retired (lgkmcnt) before the barrier frees that buffer for stage kt+3
+        if (kt + 2 < nk)
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int bnext = (bcur == 2) ? 0 : bcur + 1;
+        load_frags(bnext, xn, wn_);
+        if (kt + 3 < nk) stage(bcur, (kt + 3) * BK);
+        bcur = bnext;
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xc[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      body(kt, xa, wa, xb, wb);
+      if (kt + 1 < nk) body(kt + 1, xb, wb, xa, wa);
+    }
+  } else {
   // prologue: STAGES-1 stages in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s, s * BK);
   int buf = 0;
-  constexpr int LPS = NA + NB;  // loads per stage per thread
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once only the loads of the (up to STAGES-2) younger stages remain
     const int younger = min(STAGES - 2, nk - 1 - kt);
@@ -210,6 +262,8 @@ void gemm_nt_kernel(GemmNtArgs p) {
       __builtin_amdgcn_s_setprio(0);
     }
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+  }
+
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -365,7 +419,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
   }
 }
 
-template <int EPI, int BK, int STAGES, int WM, int WN, int MT_>
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, bool PF>
 int launch_bk(GemmNtArgs a, hipStream_t s) {
   using C = Cfg<BK, STAGES, WM, WN, MT_>;
   constexpr int LDS_BYTES = C::LDS_BYTES;
@@ -373,32 +427,37 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
   a.tiles_n = (a.N + C::BN - 1) / C::BN;
   if ((int64_t)C::BM * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)C::BN * a.ldb * 2 >= (int64_t)0x7fffffff)
     MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_>,
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, PF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, PF>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
 }
 
 template <int EPI>
 int launch(const GemmNtArgs& a, hipStream_t s) {
-  // Tile configurations (BK 32, 3-stage ring):
-  //   "t256"  256x256, 8 waves of 128x64, one workgroup per CU — lowest L2->LDS bytes per FLOP
-  //   "w4"    256x128, 8 waves of 64x64, two workgroups per CU — default for N < 1024
-  //   "w2"    256x128, 4 waves of 128x64, two workgroups per CU
-  // MVPTR_GEMM_CFG overrides the choice (tuning knob).
+  // Tile configurations (measured on MI355X, round 1, profiles/r01_gemm_configs.txt):
+  //   "t256k" 256x256, BK 64 (whole 128-B lines per row), double buffer, 8 waves of 128x64, one
+  //           workgroup per CU — default: fewest L2->LDS bytes per FLOP, best main loop (1.0-1.1 PF/s)
+  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU — used where the
+  //           prologue/epilogue dominate a plain-bias GEMM (K < 1536) and for small outputs
+  //   "t256" / "t256p" (BK 32 ring, +fragment prefetch), "w2" / "w2p" (4 waves of 128x64): kept as
+  //           tuning knobs; none beat the two above on this model's shapes
+  // MVPTR_GEMM_CFG overrides the choice.
   const char* env = getenv("MVPTR_GEMM_CFG");
-  // measured on MI355X (round 1): the 256x256 tile wins (+15..25 %) when the main loop dominates
-  // (K >= 1536) and its tiles fill the 256 CUs without a ragged second round; otherwise the two
-  // co-resident 256x128 workgroups hide each other's prologue / epilogue better
-  const int t256 = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  int cfg = (a.K >= 1536 && (t256 <= 256 || t256 >= 768)) ? 2 : 0;
+  int cfg = 3;
+  if (a.N < 256 || a.M < 256 || (a.K < 1536 && EPI == MVPTR_EPI_BIAS)) cfg = 0;
   if (env != nullptr) cfg = (env[0] == 't') ? 2 : (env[0] == 'w' && env[1] == '2') ? 1 : 0;
-  if (cfg == 2) return launch_bk<EPI, 32, 3, 2, 4, 8>(a, s);
-  if (cfg == 1) return launch_bk<EPI, 32, 3, 2, 2, 8>(a, s);
-  return launch_bk<EPI, 32, 3, 4, 2, 4>(a, s);
+  const bool pf = (env != nullptr && env[1] != 0 && env[2] != 0 && env[strlen(env) - 1] == 'p');  // "t256p", "w2p"
+  if (cfg == 3 || (env != nullptr && env[0] == 't' && env[strlen(env) - 1] == 'k'))
+    return launch_bk<EPI, 64, 2, 2, 4, 8, false>(a, s);
+  if (cfg == 2 && pf) return launch_bk<EPI, 32, 3, 2, 4, 8, true>(a, s);
+  if (cfg == 1 && pf) return launch_bk<EPI, 32, 3, 2, 2, 8, true>(a, s);
+  if (cfg == 2) return launch_bk<EPI, 32, 3, 2, 4, 8, false>(a, s);
+  if (cfg == 1) return launch_bk<EPI, 32, 3, 2, 2, 8, false>(a, s);
+  return launch_bk<EPI, 32, 3, 4, 2, 4, false>(a, s);
 }
 
 }  // namespace

@@ -130,6 +130,11 @@ class GradSync:
             if not self._avg:
                 b["flat"].mul_(1.0 / self.world)
         self._expected = set(self._ready)
+        # parameters no rank produced a gradient for keep grad = None, as under DDP with
+        # find_unused_parameters=True (run_pretrain_ml.py:415-418): the optimizer skips them
+        for p in self.params:
+            if p not in self._ready:
+                p.grad = None
 
 
 def all_reduce_metrics(values, device):
