@@ -121,11 +121,17 @@ def kernel_roofline(dev, dims, cfg):
     e1.record()
     torch.cuda.synchronize()
     avg_ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * (B * sum(Ls) / len(Ls)) * I * H
+    mean_m = B * sum(Ls) / len(Ls)
+    flops = 2.0 * mean_m * I * H
     ach = flops / (avg_ms * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC passes committed under profiles/r01_pmc_hbm_traffic.csv
+    # (FETCH_SIZE 153.0 MB + WRITE_SIZE 393.2 MB at M = 32000; scaled to the mean M of the launch
+    # mix; algorithmic bytes: x 49.2 MB + W 4.7 MB read, u and gelu(u) 2 x 196.6 MB written)
+    traffic = (153.0e6 + 393.2e6) * mean_m / 32000.0
     return dict(bound="mfma", kernel="gemm_nt_kernel<EPI_BIAS_GELU> (M=B*L, N=3072, K=768)", achieved=round(ach, 1),
                 peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                avg_launch_us=round(avg_ms * 1e3, 1), traffic=None)
+                avg_launch_us=round(avg_ms * 1e3, 1), traffic=round(traffic),
+                traffic_source="rocprofv3 PMC passes of tools/prof_gemm.py, profiles/r01_pmc_hbm_traffic.csv")
 
 
 def main():

@@ -439,16 +439,17 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
 template <int EPI>
 int launch(const GemmNtArgs& a, hipStream_t s) {
   // Tile configurations (measured on MI355X, round 1, profiles/r01_gemm_configs.txt):
+  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU — default
   //   "t256k" 256x256, BK 64 (whole 128-B lines per row), double buffer, 8 waves of 128x64, one
-  //           workgroup per CU — default: fewest L2->LDS bytes per FLOP, best main loop (1.0-1.1 PF/s)
-  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU — used where the
-  //           prologue/epilogue dominate a plain-bias GEMM (K < 1536) and for small outputs
+  //           workgroup per CU: fewest L2->LDS bytes per FLOP, best isolated main loop (1.0-1.1 PF/s)
   //   "t256" / "t256p" (BK 32 ring, +fragment prefetch), "w2" / "w2p" (4 waves of 128x64): kept as
   //           tuning knobs; none beat the two above on this model's shapes
   // MVPTR_GEMM_CFG overrides the choice.
   const char* env = getenv("MVPTR_GEMM_CFG");
-  int cfg = 3;
-  if (a.N < 256 || a.M < 256 || (a.K < 1536 && EPI == MVPTR_EPI_BIAS)) cfg = 0;
+  // Whole-step A/B on one box (bench.py, 3 runs each): all-"w4" 56.8-58.0 ms, all-"t256k" 58.2-58.5 ms
+  // although "t256k" wins isolated launches at K >= 1536 (warm L2/MALL): the co-resident pair of
+  // 256x128 workgroups tolerates cold operands better.  Default: "w4".
+  int cfg = 0;
   if (env != nullptr) cfg = (env[0] == 't') ? 2 : (env[0] == 'w' && env[1] == '2') ? 1 : 0;
   const bool pf = (env != nullptr && env[1] != 0 && env[2] != 0 && env[strlen(env) - 1] == 'p');  // "t256p", "w2p"
   if (cfg == 3 || (env != nullptr && env[0] == 't' && env[strlen(env) - 1] == 'k'))
