@@ -45,9 +45,9 @@ enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
   MVPTR_EPI_BIAS = 0,        /* out0(bf16) = acc + bias                                  */
-  MVPTR_EPI_BIAS_GELU = 1,   /* out0(bf16) = u = acc + bias ; out1(bf16) = gelu_erf(u)    */
+  MVPTR_EPI_BIAS_GELU = 1,   /* u = acc + bias: out0(bf16) = gelu_erf'(u) ; out1(bf16) = gelu_erf(u) */
   MVPTR_EPI_BIAS_RESID = 2,  /* out0(bf16) = dropout(acc + bias) + aux(bf16)              */
-  MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * gelu_erf'(aux) ; colsum -> vec_out f32 */
+  MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * aux, aux = the saved gelu_erf'(u) ; colsum -> vec_out f32 */
   MVPTR_EPI_ADD = 4,         /* out0(bf16) = acc + aux(bf16)  (aux may be NULL)           */
   MVPTR_EPI_F32 = 5,         /* out0(f32)  = acc + bias                                   */
   MVPTR_EPI_BIAS_TANH = 6    /* out0(bf16) = tanh(acc + bias)                             */
@@ -76,7 +76,7 @@ const char* mvptr_last_error(void);
  * modeling_vlbert.py:71-73, and the data-gradient of the same layers (dX = dY * W, with
  * B = W^T as stored by mvptr_cast_pack).
  * lda/ldb/ldc/ld_aux in elements; K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned.
- * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual / pre-activation) or NULL.
+ * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual, or the saved gelu_erf'(u) for EPI_GELU_BWD) or NULL.
  * vec_out: f32[N] column sums (EPI_GELU_BWD), accumulated with atomics, or NULL.
  * drop: dropout on (acc + bias) for EPI_BIAS_RESID, element index = m * N + n. */
 int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -114,6 +115,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   float cdf2, e;
   gelu_parts(x, cdf2, e);
   return 0.5f * cdf2 + x * e * 0.39894228040143267794f;
+}
+
+// erf-GELU and its derivative for two values at once, written on 2-vectors so the multiplies and
+// FMAs become v_pk_*_f32 (two elements per issue slot).  The GEMM epilogues are VALU-issue bound
+// (4 cycles per instruction and wave, 16 for v_exp/v_rcp), so the forward pass evaluates BOTH
+// gelu(u) and gelu'(u) from one exp and one rcp and stores the derivative; the backward epilogue
+// is then a plain multiply.
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& act, f32x2& dact) {
+  const f32x2 xx = x * x;
+  f32x2 e, t;
+  e.x = __builtin_amdgcn_exp2f(xx.x * -0.72134752044448170368f);  // exp(-x^2/2)
+  e.y = __builtin_amdgcn_exp2f(xx.y * -0.72134752044448170368f);
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 d = ax * 0.23164189f + 1.0f;  // 1 + 0.3275911 |x| / sqrt(2)
+  t.x = __builtin_amdgcn_rcpf(d.x);
+  t.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const f32x2 m = 1.0f - poly * e;  // erf(|x| / sqrt(2))
+  f32x2 s;
+  s.x = __builtin_copysignf(m.x, x.x);
+  s.y = __builtin_copysignf(m.y, x.y);
+  const f32x2 hx = x * 0.5f;
+  act = hx * s + hx;
+  dact = (x * e) * 0.39894228040143267794f + (s * 0.5f + 0.5f);
 }
 
 // Sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (quad

@@ -72,13 +72,16 @@ struct GemmNtArgs {
   int vec_out_ok;   // 16-byte stores allowed on out0/out1
   int vec_aux_ok;   // 16-byte loads allowed on aux
   int vec_bias_ok;  // 16-byte loads allowed on bias
+  int delay_cycles;  // experiment (MVPTR_GEMM_DELAY): start delay of the second resident workgroups
+  int delay_lo, delay_hi;
+  unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
 };
 
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
 // WM = 4: 8 waves of 64x64 (512 threads).  WM = 2: 4 waves of 128x64 (256 threads): 25 % fewer LDS
 // fragment reads per MFMA and half the waves per barrier, 256 registers per wave available.
-template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, bool PF>
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
 __global__ __launch_bounds__(WM * WN * 64, (Cfg<BK, STAGES, WM, WN, MT_>::WG_PER_CU * WM * WN / 4))
 void gemm_nt_kernel(GemmNtArgs p) {
   using C = Cfg<BK, STAGES, WM, WN, MT_>;
@@ -90,6 +93,15 @@ void gemm_nt_kernel(GemmNtArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = p.tiles_m * p.tiles_n;
+#ifdef MVPTR_TIMELINE_BUILD
+  // diagnostic: wall-clock (100 MHz s_memrealtime) start / loop-end / end of every workgroup
+  unsigned long long tl_start, tl_loop, tl_end;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_start)::"memory");
+#endif
+  if (p.delay_cycles > 0 && (int)blockIdx.x >= p.delay_lo && (int)blockIdx.x < p.delay_hi) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (long long)p.delay_cycles) __builtin_amdgcn_s_sleep(16);
+  }
   const int t = xcd_remap(blockIdx.x, nwg);
   // grouped order: GROUP_M row-tiles x all column tiles, row-tile fastest
   const int gsz = GROUP_M * p.tiles_n;
@@ -164,7 +176,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
 
   const int nk = (p.K + BK - 1) / BK;
   constexpr int LPS = NA + NB;  // loads per stage per thread
-  if constexpr (PF) {
+  if constexpr (SCHED == 1) {
     // Fragment-prefetch schedule (KS == 1, 3-buffer ring): the fragments of K-step kt+1 are read
     // from LDS into a second register set while the MFMAs of K-step kt run, so the LDS read
     // latency is off the critical path; three stages are requested ahead of the consumer.
@@ -214,13 +226,70 @@ void gemm_nt_kernel(GemmNtArgs p) {
       body(kt, xa, wa, xb, wb);
       if (kt + 1 < nk) body(kt + 1, xb, wb, xa, wa);
     }
+  } else if constexpr (SCHED == 2) {
+    // Staggered halves: the MFMA pipe of a SIMD is shared by wave i and wave i + NWAVES/2.  If both
+    // run "issue loads, then MFMAs" in lockstep, the pipe idles while every wave issues its LDS-DMA
+    // and fragment reads (~400 cycles per K-step measured with s_memtime) and then serialises both
+    // waves' MFMA bursts.  The second half of the waves therefore runs one burst behind: after each
+    // barrier it first issues the MFMAs of the PREVIOUS K-step (fragments kept in registers across
+    // the barrier) while the first half issues its loads, then swaps roles.
+    static_assert(KS == 1, "stagger schedule is written for BK = 32");
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) stage(s, s * BK);
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2;
+    bf16x8 xf[MT], wf[4];
+    auto mma = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int younger = min(STAGES - 2, nk - 1 - kt);
+      if (younger >= 3)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
+      else if (younger == 2)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+      else if (younger == 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const char* la = lds + buf * STAGE_BYTES;
+      const char* lb = la + A_BYTES;
+      if (late && kt > 0) mma();  // K-step kt-1 of the late half, beside the early half's loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
+      if (kt + STAGES - 1 < nk) {
+        int nb = buf + STAGES - 1;
+        if (nb >= STAGES) nb -= STAGES;
+        stage(nb, (kt + STAGES - 1) * BK);
+      }
+      if (!late) mma();
+      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    }
+    if (late) mma();
   } else {
   // prologue: STAGES-1 stages in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s, s * BK);
   int buf = 0;
+#ifdef MVPTR_STAMP_BUILD
+  unsigned long long t_wait = 0, t_issue = 0, t_lds = 0, t_mfma = 0, ts0, ts1;
+#define STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   for (int kt = 0; kt < nk; ++kt) {
+#ifdef MVPTR_STAMP_BUILD
+    STAMP(ts0);
+#endif
     // stage kt has landed once only the loads of the (up to STAGES-2) younger stages remain
     const int younger = min(STAGES - 2, nk - 1 - kt);
     if (younger >= 3)
@@ -231,6 +300,10 @@ void gemm_nt_kernel(GemmNtArgs p) {
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef MVPTR_STAMP_BUILD
+    STAMP(ts1);
+    t_wait += ts1 - ts0;
+#endif
     const char* la = lds + buf * STAGE_BYTES;
     const char* lb = la + A_BYTES;
     // fragment reads of the first k-substep are issued before the next stage's address math and
@@ -245,6 +318,15 @@ void gemm_nt_kernel(GemmNtArgs p) {
       if (nb >= STAGES) nb -= STAGES;
       stage(nb, (kt + STAGES - 1) * BK);
     }
+#ifdef MVPTR_STAMP_BUILD
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0" : "=s"(ts0)::"memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_issue += ts0 - ts1;
+    STAMP(ts1);
+    t_lds += ts1 - ts0;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks > 0) {
@@ -261,12 +343,30 @@ void gemm_nt_kernel(GemmNtArgs p) {
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+#ifdef MVPTR_STAMP_BUILD
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // let the last MFMA drain before stamping
+    STAMP(ts0);
+    t_mfma += ts0 - ts1;
+#endif
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
-
+#ifdef MVPTR_STAMP_BUILD
+  if (p.stamps != nullptr && tid == 0) {
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+    o[0] = t_wait;
+    o[1] = t_issue;
+    o[2] = t_lds;
+    o[3] = t_mfma;
+    o[4] = (unsigned long long)nk;
+  }
+#endif
   }
 
   // ------------------------------------------------------------------ epilogue
+#ifdef MVPTR_TIMELINE_BUILD
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop)::"memory");
+#endif
   __syncthreads();  // every wave is done with the operand ring
   // the wave's 64x64 f32 block is restaged in two 32-row halves (fits the 72-KiB BK=32 ring)
   float* st = reinterpret_cast<float*>(lds) + wave * (32 * ST_LD);
@@ -361,10 +461,17 @@ void gemm_nt_kernel(GemmNtArgs p) {
     if (EPI == MVPTR_EPI_BIAS) {
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-      store_bf8(p.out0, m, v);
-      float g[8];
+      float g[8], dg[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = gelu_erf(bf2f(f2bf(v[e])));
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 a2, d2;
+        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+        g[e] = a2.x;
+        g[e + 1] = a2.y;
+        dg[e] = d2.x;
+        dg[e + 1] = d2.y;
+      }
+      store_bf8(p.out0, m, dg);
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
       if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
@@ -380,10 +487,12 @@ void gemm_nt_kernel(GemmNtArgs p) {
       for (int e = 0; e < 8; ++e) v[e] += a[e];
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_GELU_BWD) {
+      // aux = gelu'(u) saved by the forward epilogue; rows / columns outside the problem have
+      // acc = 0 (zero-filled operand rows), so the column sums need no guard
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[e] = bf2f(f2bf(v[e] * gelu_erf_grad(a[e])));
-        if (n + e < p.N) cs[e] += v[e];
+        v[e] *= a[e];
+        cs[e] += v[e];
       }
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_ADD) {
@@ -417,9 +526,20 @@ void gemm_nt_kernel(GemmNtArgs p) {
       if (rsub == 0 && n + e < p.N) atomicAdd(p.vec_out + n + e, s);
     }
   }
+#ifdef MVPTR_TIMELINE_BUILD
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_end)::"memory");
+  if (p.stamps != nullptr && tid == 0) {
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+    o[0] = tl_start;
+    o[1] = tl_loop;
+    o[2] = tl_end;
+    o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  }
+#endif
 }
 
-template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, bool PF>
+template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
 int launch_bk(GemmNtArgs a, hipStream_t s) {
   using C = Cfg<BK, STAGES, WM, WN, MT_>;
   constexpr int LDS_BYTES = C::LDS_BYTES;
@@ -427,11 +547,11 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
   a.tiles_n = (a.N + C::BN - 1) / C::BN;
   if ((int64_t)C::BM * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)C::BN * a.ldb * 2 >= (int64_t)0x7fffffff)
     MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, PF>,
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, SCHED>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, PF>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, SCHED>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
 }
@@ -439,26 +559,30 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
 template <int EPI>
 int launch(const GemmNtArgs& a, hipStream_t s) {
   // Tile configurations (measured on MI355X, round 1, profiles/r01_gemm_configs.txt):
-  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU — default
   //   "t256k" 256x256, BK 64 (whole 128-B lines per row), double buffer, 8 waves of 128x64, one
-  //           workgroup per CU: fewest L2->LDS bytes per FLOP, best isolated main loop (1.0-1.1 PF/s)
-  //   "t256" / "t256p" (BK 32 ring, +fragment prefetch), "w2" / "w2p" (4 waves of 128x64): kept as
-  //           tuning knobs; none beat the two above on this model's shapes
+  //           workgroup per CU: fewest L2->LDS bytes per FLOP (32 B/clk/CU at full MFMA rate, the
+  //           measured L2->LDS fill rate is ~30-35), loop rate 1.2-1.4 PF/s
+  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU: the second
+  //           workgroup's loop runs beside the first one's epilogue, lower loop rate (1.0-1.15 PF/s)
+  //   "t256" (BK 32 ring) / "t256g" (ring + the two wave halves staggered by one MFMA burst) /
+  //           "w4g": tuning knobs, within 5 % of the two above
+  // Rule (sweeps of tools/sweep_gemm_cfg.py at the step's shapes): "t256k" everywhere except the
+  // short-K, narrow GEMMs whose 256x256 tiles would need more than one round of the 256 CUs
+  // (attention-output projection on the big batch), where the epilogue overlap of "w4" wins.
   // MVPTR_GEMM_CFG overrides the choice.
   const char* env = getenv("MVPTR_GEMM_CFG");
-  // Whole-step A/B on one box (bench.py, 3 runs each): all-"w4" 56.8-58.0 ms, all-"t256k" 58.2-58.5 ms
-  // although "t256k" wins isolated launches at K >= 1536 (warm L2/MALL): the co-resident pair of
-  // 256x128 workgroups tolerates cold operands better.  Default: "w4".
-  int cfg = 0;
-  if (env != nullptr) cfg = (env[0] == 't') ? 2 : (env[0] == 'w' && env[1] == '2') ? 1 : 0;
-  const bool pf = (env != nullptr && env[1] != 0 && env[2] != 0 && env[strlen(env) - 1] == 'p');  // "t256p", "w2p"
-  if (cfg == 3 || (env != nullptr && env[0] == 't' && env[strlen(env) - 1] == 'k'))
-    return launch_bk<EPI, 64, 2, 2, 4, 8, false>(a, s);
-  if (cfg == 2 && pf) return launch_bk<EPI, 32, 3, 2, 4, 8, true>(a, s);
-  if (cfg == 1 && pf) return launch_bk<EPI, 32, 3, 2, 2, 8, true>(a, s);
-  if (cfg == 2) return launch_bk<EPI, 32, 3, 2, 4, 8, false>(a, s);
-  if (cfg == 1) return launch_bk<EPI, 32, 3, 2, 2, 8, false>(a, s);
-  return launch_bk<EPI, 32, 3, 4, 2, 4, false>(a, s);
+  if (env != nullptr && env[0] != 0) {
+    const size_t n = strlen(env);
+    if (env[0] == 't' && env[n - 1] == 'k') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
+    if (env[0] == 't' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 2, 4, 8, 2>(a, s);
+    if (env[0] == 't') return launch_bk<EPI, 32, 3, 2, 4, 8, 0>(a, s);
+    if (env[0] == 'w' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 4, 2, 4, 2>(a, s);
+    if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
+    MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
+  }
+  const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  if (a.N <= 768 && a.K <= 768 && tiles256 > 256) return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
+  return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
 }
 
 }  // namespace
@@ -491,6 +615,20 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.ldc = ldc;
   a.vec_out = vec_out;
   a.drop = make_dropdev(drop);
+  a.stamps = nullptr;
+  a.delay_cycles = 0;
+  a.delay_lo = 256;
+  a.delay_hi = 512;
+  {
+    const char* dp = getenv("MVPTR_GEMM_DELAY");  // "cycles[,lo,hi]"
+    if (dp != nullptr) sscanf(dp, "%d,%d,%d", &a.delay_cycles, &a.delay_lo, &a.delay_hi);
+  }
+#if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
+  {
+    const char* sp = getenv("MVPTR_GEMM_STAMPS");
+    if (sp != nullptr) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
+  }
+#endif
   a.tiles_m = a.tiles_n = 0;  // set per tile configuration in launch_bk
   const int esz = (epilogue == MVPTR_EPI_F32) ? 4 : 2;
   bool vo = (ldc % 8 == 0) && (((uintptr_t)out0 & 15) == 0);

@@ -326,15 +326,10 @@ class LinearFn(torch.autograd.Function):
             pad[:, :N] = dy2
             dy2 = pad
         if u is not None:
-            # dy2 is d(gelu(u)); d(u) = dy * gelu'(u): run it through the identity-free path
-            xg = u.float().requires_grad_(True)
-            with torch.enable_grad():
-                torch.nn.functional.gelu(xg).backward(dy2[:, :N].float())
-            du = xg.grad.to(torch.bfloat16)
-            if Np != N:
-                pad = torch.zeros((du.shape[0], Np), device=dev, dtype=torch.bfloat16)
-                pad[:, :N] = du
-                du = pad
+            # dy2 is d(gelu(u)); u holds gelu'(u) saved by the forward epilogue (head-sized rows:
+            # a torch multiply is enough here, the encoder layers use the fused GEMM epilogue)
+            du = torch.zeros((dy2.shape[0], Np), device=dev, dtype=torch.bfloat16)
+            du[:, :N] = dy2[:, :N] * u
             dy2 = du
         dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
         dw = None

@@ -242,12 +242,20 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
             hard_seqs = torch.cat([txt.index_select(0, hard_txt_full), only_vis.index_select(0, hard_img_full)], 1)
             hard_mask = torch.cat([mask_a.index_select(0, hard_txt_full), only_vis_mask.index_select(0, hard_img_full)], 1)
-            hard_out = self.mul_encoder(hard_seqs, hard_mask)[0]
-            hard_pooled = self.pooler(hard_out)
 
         joint = torch.cat([txt, only_vis], dim=1)
         joint_mask = torch.cat([mask_a, only_vis_mask], dim=-1)
-        sequence_output = self.mul_encoder(joint, joint_mask)[0]
+        if encode_hn:
+            # The reference runs mul_encoder twice (hard batch vl:567, matched batch vl:577); the two
+            # passes share weights and do not depend on each other, so they go through the layer
+            # stack as ONE 2n-row batch: at configs[1] that is 250 row tiles of 256 instead of
+            # 2 x 125, which fills whole rounds of the 256 CUs (375 tiles = 1.46 rounds before).
+            n = joint.shape[0]
+            both = self.mul_encoder(torch.cat([joint, hard_seqs], 0), torch.cat([joint_mask, hard_mask], 0))[0]
+            sequence_output, hard_out = both[:n], both[n:]
+            hard_pooled = self.pooler(hard_out)
+        else:
+            sequence_output = self.mul_encoder(joint, joint_mask)[0]
         pooled_output = self.pooler(sequence_output)
         outputs = (sequence_output, pooled_output, hard_out, hard_pooled)
         return outputs, (txt, vis, sim_mat), (hard_txt_full, hard_img_full)

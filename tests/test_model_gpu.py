@@ -145,6 +145,12 @@ def test_bi_pretrain_parity(dev, name):
                 print("   (ill-conditioned, reported only) grad-norm", pname, e)
             else:
                 assert e < (1e-1 if pname in CLIP_BRANCH else 5e-2), (pname, gn, rn)
+        else:
+            # analytically zero gradient (key bias: softmax is invariant to it); the reference holds
+            # f32 rounding noise there, the bf16 path bf16 rounding noise: absolute bound only
+            print("   (zero in exact arithmetic) grad-norm", pname, gn, "ref", rn)
+            assert gn < 2e-3, (pname, gn, rn)
+            continue
         full = "grad:" + pname
         if full in d:
             e = _rel(p.grad, torch.from_numpy(d[full]))

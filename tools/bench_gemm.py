@@ -31,7 +31,7 @@ def rnd(*s):
 
 def main():
     H, I = 768, 3072
-    for M in (32000, 19200):
+    for M in (64000, 19200):
         x, xi = rnd(M, H), rnd(M, I)
         x3 = rnd(M, 3 * H)
         shapes = [("qkv  fwd  EPI_BIAS", x, rnd(3 * H, H), hip.EPI_BIAS, None),
