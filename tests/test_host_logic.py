@@ -228,8 +228,10 @@ def test_grad_sync_two_ranks_gloo():
             want = (a + b) / 2
             assert np.allclose(g0[i], want, atol=1e-5), (step, i)
             assert np.allclose(g1[i], want, atol=1e-5), (step, i)
-        for extra0, extra1 in zip(g0[len(local0):-1], g1[len(local1):-1]):  # unused params: zero grads
-            assert np.all(extra0 == 0) and np.all(extra1 == 0)
+        # unused params: no gradient (None, as under DDP find_unused_parameters) or zeros
+        for extra0, extra1 in zip(g0[len(local0):-1], g1[len(local1):-1]):
+            assert extra0 is None or np.all(extra0 == 0)
+            assert extra1 is None or np.all(extra1 == 0)
     assert v0 == v1 == [3.0, 4.0, 6.0]
 
 
