@@ -29,6 +29,7 @@ struct GemmTnArgs {
   int tiles_n, tiles_k;
   int rows_per_split;
   float* colsum;  // optional: += column sums of A (bias gradient)
+  unsigned long long* stamps;  // -DMVPTR_TIMELINE_BUILD only (MVPTR_GEMM_STAMPS)
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MVPTR_TIMELINE_BUILD
+  unsigned long long tl_start, tl_loop, tl_end;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_start)::"memory");
+#endif
   const int nt = p.tiles_n * p.tiles_k;
   const int t = xcd_remap(blockIdx.x, nt);
   const int tn = t / p.tiles_k;
@@ -198,6 +203,9 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
 
+#ifdef MVPTR_TIMELINE_BUILD
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop)::"memory");
+#endif
   const int l31 = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int nb = 0; nb < NBLK; ++nb)
@@ -219,6 +227,15 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
       if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
     }
   }
+#ifdef MVPTR_TIMELINE_BUILD
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_end)::"memory");
+  if (p.stamps != nullptr && tid == 0) {
+    unsigned long long* o = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    o[0] = tl_start;
+    o[1] = tl_loop;
+    o[2] = tl_end;
+  }
+#endif
 }
 
 __global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float* out,
@@ -310,6 +327,13 @@ extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t 
   a.dW = dW;
   a.ldw = ldw;
   a.colsum = colsum;
+  a.stamps = nullptr;
+#ifdef MVPTR_TIMELINE_BUILD
+  {
+    const char* sp = getenv("MVPTR_GEMM_STAMPS");
+    if (sp != nullptr) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
+  }
+#endif
   a.tiles_n = (N + TN_ - 1) / TN_;
   a.tiles_k = (K + pl.ksub * 128 - 1) / (pl.ksub * 128);
   int rps = (M + pl.splits - 1) / pl.splits;

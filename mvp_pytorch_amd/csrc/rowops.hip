@@ -213,6 +213,183 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* parti
   if (b1 > b0) atomicAdd(dst + col, s);
 }
 
+// ------------------------------------------------------------ LayerNorm, H = 256 * J fast path
+// H = 768 is 1.5 sixteen-byte chunks per lane in the generic kernels above (a quarter of the lane
+// slots idle, one or two loads in flight per wave).  Here lane l owns the 4 consecutive columns
+// 4l + 256j of each of the J column groups (8-byte accesses, every lane busy, 512 contiguous
+// bytes per wave instruction) and a wave keeps RPW rows in flight, so the loads of the next row
+// are outstanding while the statistics of the previous one are reduced.
+template <int J, int RPW>
+__global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const float* gamma,
+                                                        const float* beta, float eps, __bf16* y,
+                                                        float* mean, float* rstd, int M, int rpg,
+                                                        int gstride, int roff, DropDev drop) {
+  constexpr int H = 256 * J;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gm[J], bt[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    gm[j] = (gamma != nullptr) ? *reinterpret_cast<const f32x4*>(gamma + 256 * j + 4 * lane) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bt[j] = (gamma != nullptr) ? *reinterpret_cast<const f32x4*>(beta + 256 * j + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < M; r0 += gridDim.x * 4 * RPW) {
+    bf16x4 x[RPW][J];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = min(r0 + i, M - 1);
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        x[i][j] = *reinterpret_cast<const bf16x4*>(z + (int64_t)r * H + 256 * j + 4 * lane);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = r0 + i;
+      if (r >= M) break;
+      float v[J][4];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][e] = bf2f(x[i][j][e]);
+          s += v[j][e];
+        }
+      // identity mode (gamma == NULL: dropout only) passes the values through untouched
+      const float mu = (gamma != nullptr || mean != nullptr) ? wave_sum(s) * (1.0f / (float)H) : 0.f;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][e] -= mu;
+          q += v[j][e] * v[j][e];
+        }
+      const float var = wave_sum(q) * (1.0f / (float)H);
+      const float rs = 1.0f / sqrtf(var + eps);
+      if (lane == 0) {
+        if (mean) mean[r] = mu;
+        if (rstd) rstd[r] = rs;
+      }
+      const int64_t orow = remap_row(r, rpg, gstride, roff);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (gamma != nullptr) ? v[j][e] * rs * gm[j][e] + bt[j][e] : v[j][e] + mu;
+        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
+        drop_apply2(drop, idx, t[0], t[1]);
+        drop_apply2(drop, idx + 2, t[2], t[3]);
+        const bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+        *reinterpret_cast<bf16x4*>(y + orow * H + 256 * j + 4 * lane) = o;
+      }
+    }
+  }
+}
+
+template <int J, int RPW>
+__global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, const __bf16* z,
+                                                        const float* mean, const float* rstd,
+                                                        const float* gamma, __bf16* dz, __bf16* dd,
+                                                        float* partial, int M, int rpg, int gstride,
+                                                        int roff, DropDev ydrop, DropDev ddrop) {
+  constexpr int H = 256 * J;
+  __shared__ float red[3][3][H];  // waves 1..3 publish, wave 0 sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool ident = (gamma == nullptr);
+  float ag[J][4], ab[J][4], abias[J][4];
+  f32x4 gm[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    gm[j] = ident ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + 256 * j + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ag[j][e] = ab[j][e] = abias[j][e] = 0.f;
+  }
+  for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < M; r0 += gridDim.x * 4 * RPW) {
+    bf16x4 a[RPW][J], x[RPW][J];
+    float mu[RPW], rs[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = min(r0 + i, M - 1);
+      const int64_t irow = remap_row(r, rpg, gstride, roff);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        a[i][j] = *reinterpret_cast<const bf16x4*>(dy + irow * H + 256 * j + 4 * lane);
+        x[i][j] = *reinterpret_cast<const bf16x4*>(z + (int64_t)r * H + 256 * j + 4 * lane);
+      }
+      mu[i] = ident ? 0.f : mean[r];
+      rs[i] = ident ? 1.f : rstd[r];
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = r0 + i;
+      if (r >= M) break;
+      float xh[J][4], g[J][4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = bf2f(a[i][j][e]);
+        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
+        drop_apply2(ydrop, idx, d[0], d[1]);
+        drop_apply2(ydrop, idx + 2, d[2], d[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (bf2f(x[i][j][e]) - mu[i]) * rs[i];
+          g[j][e] = d[e] * gm[j][e];
+          s1 += g[j][e];
+          s2 += g[j][e] * xh[j][e];
+          ag[j][e] += d[e] * xh[j][e];
+          ab[j][e] += d[e];
+        }
+      }
+      const float c1 = ident ? 0.f : wave_sum(s1) * (1.0f / (float)H);
+      const float c2 = ident ? 0.f : wave_sum(s2) * (1.0f / (float)H);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = rs[i] * (g[j][e] - c1 - xh[j][e] * c2);
+        const bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+        *reinterpret_cast<bf16x4*>(dz + (int64_t)r * H + 256 * j + 4 * lane) = o;
+        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
+        drop_apply2(ddrop, idx, t[0], t[1]);
+        drop_apply2(ddrop, idx + 2, t[2], t[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) abias[j][e] += t[e];
+        if (dd != nullptr) {
+          const bf16x4 od = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+          *reinterpret_cast<bf16x4*>(dd + (int64_t)r * H + 256 * j + 4 * lane) = od;
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 256 * j + 4 * lane + e;
+        red[0][wave - 1][col] = ag[j][e];
+        red[1][wave - 1][col] = ab[j][e];
+        red[2][wave - 1][col] = abias[j][e];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pp = partial + (int64_t)blockIdx.x * 3 * H;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 256 * j + 4 * lane + e;
+        pp[col] = ag[j][e] + red[0][0][col] + red[0][1][col] + red[0][2][col];
+        pp[H + col] = ab[j][e] + red[1][0][col] + red[1][1][col] + red[1][2][col];
+        pp[2 * H + col] = abias[j][e] + red[2][0][col] + red[2][1][col] + red[2][2][col];
+      }
+  }
+}
+
 // --------------------------------------------------------------------------------- embeddings
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, const int64_t* pids,
                                                          const int64_t* tids, const float* word,
@@ -463,6 +640,16 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_fwd: rows_per_group must be > 0");
   if (((uintptr_t)z & 15) || ((uintptr_t)y & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "layernorm_fwd: z,y must be 16-byte aligned");
+  if (H == 768 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
+    constexpr int RPW = 2;
+    int g = (M + 4 * RPW - 1) / (4 * RPW);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((ln_fwd_j_kernel<3, RPW>), dim3(g), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)z, gamma, beta, eps, (__bf16*)y, mean, rstd, M, rows_per_group,
+                       group_stride, row_offset, make_dropdev(drop));
+    MVPTR_CHECK_LAUNCH("layernorm_fwd");
+    return MVPTR_OK;
+  }
   int grid = (M + 3) / 4;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
@@ -495,10 +682,20 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
   if (!ws || ws_bytes < mvptr_layernorm_bwd_ws_bytes(M, H))
     MVPTR_FAIL(MVPTR_WORKSPACE_TOO_SMALL, "layernorm_bwd: workspace %ld < %ld bytes", (long)ws_bytes,
                (long)mvptr_layernorm_bwd_ws_bytes(M, H));
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                     (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,
-                     (__bf16*)dd, (float*)ws, M, H, rows_per_group, group_stride,
-                     row_offset, make_dropdev(y_drop), make_dropdev(dense_drop));
+  if (H == 768 && ((uintptr_t)gamma & 15) == 0) {
+    constexpr int RPW = 2;
+    int g = (M + 4 * RPW - 1) / (4 * RPW);
+    if (g < grid) grid = g;  // every block writes its partial row: the finalize pass reads `grid` of them
+    hipLaunchKernelGGL((ln_bwd_j_kernel<3, RPW>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
+                       (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
+                       make_dropdev(dense_drop));
+  } else {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,
+                       (__bf16*)dd, (float*)ws, M, H, rows_per_group, group_stride,
+                       row_offset, make_dropdev(y_drop), make_dropdev(dense_drop));
+  }
   MVPTR_CHECK_LAUNCH("layernorm_bwd");
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32), dim3(256), 0,
                      (hipStream_t)stream, (const float*)ws, grid, H, dgamma, dbeta, dbias);

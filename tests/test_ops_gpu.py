@@ -225,10 +225,11 @@ def test_layernorm(dev, M, H):
     assert _rel(dbias, dz.float().sum(0)) < 5e-3
 
 
-def test_layernorm_remap_and_dropout(dev):
+@pytest.mark.parametrize("H", [128, 768])
+def test_layernorm_remap_and_dropout(dev, H):
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(8)
-    B, R, G, H = 3, 10, 6, 128
+    B, R, G = 3, 10, 6
     z = _bf(torch.randn(B * R, H, generator=g)).to(dev)
     gamma = torch.ones(H, device=dev)
     beta = torch.zeros(H, device=dev)
@@ -241,6 +242,41 @@ def test_layernorm_remap_and_dropout(dev):
     o = out.reshape(B, G + R, H)
     assert torch.all(o[:, :G] == 0)
     assert _rel(o[:, G:].reshape(B * R, H), ref) < 4e-3
+
+
+@pytest.mark.parametrize("H", [128, 768])
+def test_layernorm_bwd_dropout_outputs(dev, H):
+    """Backward with (a) dropout on the LayerNorm output (embeddings: mb:276) regenerated from the
+    counter hash, (b) the masked copy for the preceding dense layer (mb:350,409), (c) remapped
+    gradient rows, (d) identity mode (gamma = NULL: dropout only)."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(18)
+    B, R, G = 5, 9, 4
+    M = B * R
+    z = _bf(torch.randn(M, H, generator=g) * 1.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    ydrop, ddrop = hip.make_dropout(0.2, 77), hip.make_dropout(0.1, 99)
+    y, mean, rstd = hip.layernorm_fwd(z, gamma, beta, 1e-12)
+    dy_full = _bf(torch.randn(B * (G + R), H, generator=g)).to(dev)       # gradient in the remapped layout
+    dy_rows = dy_full.reshape(B, G + R, H)[:, G:].reshape(M, H)
+    ky = hip.dropout_mask(ydrop, M * H, dev).reshape(M, H).float() * (65536.0 / (65536.0 - ydrop.thresh16))
+    kd = hip.dropout_mask(ddrop, M * H, dev).reshape(M, H).float() * (65536.0 / (65536.0 - ddrop.thresh16))
+    zr = z.float().clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(zr, (H,), gamma, beta, 1e-12)
+    ref.backward(dy_rows.float() * ky)
+    dg, db, dbias = (torch.zeros(H, device=dev) for _ in range(3))
+    dz, dd = hip.layernorm_bwd(dy_full, z, mean, rstd, gamma, dg, db, dbias, rows_per_group=R, group_stride=G + R,
+                               row_offset=G, y_drop=ydrop, dense_drop=ddrop)
+    assert _rel(dz, zr.grad) < 6e-3
+    assert _rel(dd, zr.grad * kd) < 6e-3
+    assert _rel(dbias, (zr.grad * kd).sum(0)) < 5e-3
+    assert _rel(db, (dy_rows.float() * ky).sum(0)) < 1e-3
+    # identity mode: y = dropout(z), dz = dy * mask
+    yi, _, _ = hip.layernorm_fwd(z, None, None, 0.0, drop=ydrop, save_stats=False)
+    assert _rel(yi, z.float() * ky) < 4e-3
+    dzi, _ = hip.layernorm_bwd(dy_rows.contiguous(), z, None, None, None, None, None, None, y_drop=ydrop)
+    assert _rel(dzi, dy_rows.float() * ky) < 4e-3
 
 
 def test_embed(dev):
