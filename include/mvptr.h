@@ -94,6 +94,23 @@ int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M,
 int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                   float* dW, int64_t ldw, float* colsum, void* stream);
 
+/* Several weight gradients in ONE launch (the four nn.Linear of an encoder layer at the end of its
+ * backward pass): same operation as mvptr_gemm_tn per problem.  Consecutive problems with equal M
+ * share a launch (at most MVPTR_TN_MAX_GROUP each), so the atomic write-out of one problem overlaps
+ * the MFMA loop of the next instead of ending every launch with an idle tail. */
+#define MVPTR_TN_MAX_GROUP 4
+typedef struct {
+  const void* A;   /* dY bf16 [M, lda] */
+  int64_t lda;
+  const void* B;   /* X bf16 [M, ldb] */
+  int64_t ldb;
+  int M, N, K;
+  float* dW;       /* f32 [N, ldw], accumulated */
+  int64_t ldw;
+  float* colsum;   /* optional f32[N] */
+} mvptr_tn_problem;
+int mvptr_gemm_tn_multi(const mvptr_tn_problem* problems, int count, void* stream);
+
 /* Column sums: out[n] += sum_m X[m,n] (X bf16 [M, ldx]); bias gradients. */
 int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream);
 

@@ -98,9 +98,18 @@ void gemm_nt_kernel(GemmNtArgs p) {
   unsigned long long tl_start, tl_loop, tl_end;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_start)::"memory");
 #endif
-  if (p.delay_cycles > 0 && (int)blockIdx.x >= p.delay_lo && (int)blockIdx.x < p.delay_hi) {
+  if (p.delay_cycles > 0) {
+    // experiment: hi >= 0: workgroups lo <= id < hi start `cycles` late; hi < 0: the first `lo`
+    // workgroups start (id / 8 % P) / P * cycles late, P = -hi (phases spread inside each XCD)
+    long long d = 0;
+    if (p.delay_hi >= 0) {
+      if ((int)blockIdx.x >= p.delay_lo && (int)blockIdx.x < p.delay_hi) d = p.delay_cycles;
+    } else if ((int)blockIdx.x < p.delay_lo) {
+      const int P = -p.delay_hi;
+      d = (long long)p.delay_cycles * (((int)blockIdx.x >> 3) % P) / P;
+    }
     const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < (long long)p.delay_cycles) __builtin_amdgcn_s_sleep(16);
+    while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(16);
   }
   const int t = xcd_remap(blockIdx.x, nwg);
   // grouped order: GROUP_M row-tiles x all column tiles, row-tile fastest

@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int TN_ = 256, STAGES = 3;
+constexpr int TN_ = 256;
 // TM_ token rows per pipeline step: 64 -> 3 x 48 KiB ring (one workgroup per CU),
 // 32 -> 3 x 24 KiB ring (two workgroups per CU)
 
@@ -30,6 +30,15 @@ struct GemmTnArgs {
   int rows_per_split;
   float* colsum;  // optional: += column sums of A (bias gradient)
   unsigned long long* stamps;  // -DMVPTR_TIMELINE_BUILD only (MVPTR_GEMM_STAMPS)
+};
+
+// Up to MVPTR_TN_MAX_GROUP independent problems served by one launch: workgroup ids
+// [base[i], base[i+1]) belong to problem i.  The workgroups of a problem that finish early hand
+// their CU to the next problem's, so only the last problem's atomic write-out is an exposed tail.
+struct GemmTnGroup {
+  GemmTnArgs prob[MVPTR_TN_MAX_GROUP];
+  int base[MVPTR_TN_MAX_GROUP + 1];
+  int count;
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -52,8 +61,8 @@ extern __shared__ __attribute__((aligned(1024))) char lds[];
 //   KSUB 1: 256(n) x 128(k) tile, waves 4(n) x 2(k), each 64x64   (TM_ 32: 2 workgroups/CU, TM_ 64: 1)
 //   KSUB 2: 256(n) x 256(k) tile, waves 2(n) x 4(k), each 128x64  (TM_ 32, 1 workgroup/CU) — a third
 //           fewer L2->LDS bytes per FLOP, for outputs with enough tiles to fill the chip
-template <int TM_, int KSUB>
-__global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_tn_kernel(GemmTnArgs p) {
+template <int TM_, int KSUB, int STAGES>
+__global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_tn_kernel(GemmTnGroup grp) {
   constexpr int SUB_B = TM_ * 256;              // one TM_ x 128 bf16 sub-tile
   constexpr int STAGE_B = (2 + KSUB) * SUB_B;   // A = 2 sub-tiles (256 n), B = KSUB sub-tiles
   constexpr int GROUPS = TM_ / 4;               // 4-row wave instructions per sub-tile
@@ -68,12 +77,24 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
   unsigned long long tl_start, tl_loop, tl_end;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_start)::"memory");
 #endif
+  // 1-D grid over (split, tile).  Workgroups are dealt to the 8 XCDs round-robin by their linear
+  // id; the bijective remap hands each XCD a CONTIGUOUS run of (split, tile) pairs, split-major,
+  // so the workgroups that share an XCD's L2 sweep the same token rows at the same time: the dY
+  // panel is shared by the tiles_k tiles of a row of tiles, the X panel by the tiles_n of a column.
+  const int gidx = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
+    if (i < grp.count && gidx >= grp.base[i]) pi = i;
+  const GemmTnArgs& p = grp.prob[pi];
   const int nt = p.tiles_n * p.tiles_k;
-  const int t = xcd_remap(blockIdx.x, nt);
+  const int idx = gidx - grp.base[pi];
+  const int split = idx / nt;
+  const int t = idx - split * nt;
   const int tn = t / p.tiles_k;
   const int tk = t - tn * p.tiles_k;
   const int n0 = tn * TN_, k0 = tk * TKW;
-  const int m_begin = blockIdx.y * p.rows_per_split;
+  const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const int rows = m_end - m_begin;
   if (rows <= 0) return;
@@ -128,23 +149,23 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
   const int ncol_w = wn * NBLK * 32, kcol_w = wk * 64;     // wave's first n / k column in the tile
   const uint32_t a_sub = (uint32_t)(ncol_w / 128) * SUB_B;  // 128-column sub-tile of A / B
   const uint32_t b_sub = (uint32_t)(kcol_w / 128) * SUB_B;
-  uint32_t ta[NS][NBLK][2], tb[NS][2][2];
+  // transposed-read offsets of sub-step 0; sub-step s adds 16 rows = s * 4096 bytes (the swizzle
+  // only depends on row bits 0-3, which the 16-row step leaves alone)
+  uint32_t ta[NBLK][2], tb[2][2];
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int hl = 0; hl < 2; ++hl) {
+    const int row = 8 * h + 4 * hl + q;
 #pragma unroll
-    for (int hl = 0; hl < 2; ++hl) {
-      const int row = 16 * s + 8 * h + 4 * hl + q;
-#pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        const int cha = (ncol_w % 128) / 8 + b * 4 + 2 * cb + (pp >> 1);
-        ta[s][b][hl] = a_sub + row * 256 + ((cha ^ swz256(row)) << 4) + 8 * (pp & 1);
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int chb = (kcol_w % 128) / 8 + b * 4 + 2 * cb + (pp >> 1);
-        tb[s][b][hl] = b_sub + row * 256 + ((chb ^ swz256(row)) << 4) + 8 * (pp & 1);
-      }
+    for (int b = 0; b < NBLK; ++b) {
+      const int cha = (ncol_w % 128) / 8 + b * 4 + 2 * cb + (pp >> 1);
+      ta[b][hl] = a_sub + row * 256 + ((cha ^ swz256(row)) << 4) + 8 * (pp & 1);
     }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int chb = (kcol_w % 128) / 8 + b * 4 + 2 * cb + (pp >> 1);
+      tb[b][hl] = b_sub + row * 256 + ((chb ^ swz256(row)) << 4) + 8 * (pp & 1);
+    }
+  }
 
   f32x16 acc[NBLK][2];
 #pragma unroll
@@ -161,19 +182,21 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
   for (int i = 0; i < NBLK; ++i) bsum[i] = 0.f;
 
   const int nsteps = (rows + TM_ - 1) / TM_;
-  stage(0, 0);
-  if (nsteps > 1) stage(1, TM_);
+  constexpr int LPS = NA + NB, AHEAD = STAGES - 1;
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < nsteps) stage(i, i * TM_);
   int buf = 0;
-  constexpr int LPS = NA + NB;
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps)
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    // step st has landed once only the loads of the (up to AHEAD-1) younger steps remain
+    if (AHEAD >= 2 && st + 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((AHEAD - 1) * LPS) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (st + 2 < nsteps) {
-      int nb = buf + 2;
+    if (st + AHEAD < nsteps) {
+      int nb = buf + AHEAD;
       if (nb >= STAGES) nb -= STAGES;
-      stage(nb, (st + 2) * TM_);
+      stage(nb, (st + AHEAD) * TM_);
     }
     const char* la = lds + buf * STAGE_B;
     const char* lb = la + 2 * SUB_B;
@@ -181,9 +204,9 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
     for (int s = 0; s < NS; ++s) {
       bf16x8 af[NBLK], bfr[2];
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) af[b] = tr_frag(la, ta[s][b][0], ta[s][b][1]);
+      for (int b = 0; b < NBLK; ++b) af[b] = tr_frag(la + s * 4096, ta[b][0], ta[b][1]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(lb, tb[s][b][0], tb[s][b][1]);
+      for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(lb + s * 4096, tb[b][0], tb[b][1]);
 #pragma unroll
       for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 #ifdef MVPTR_TIMELINE_BUILD
   asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_end)::"memory");
   if (p.stamps != nullptr && tid == 0) {
-    unsigned long long* o = p.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
     o[0] = tl_start;
     o[1] = tl_loop;
     o[2] = tl_end;
@@ -260,13 +283,13 @@ __global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float*
 
 namespace {
 
-template <int TM_, int KSUB>
-int launch_tn(GemmTnArgs a, int splits, hipStream_t stream) {
+template <int TM_, int KSUB, int STAGES>
+int launch_tn(const GemmTnGroup& g, hipStream_t stream) {
   const int lds_b = STAGES * (2 + KSUB) * TM_ * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<TM_, KSUB>,
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<TM_, KSUB, STAGES>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((gemm_tn_kernel<TM_, KSUB>), dim3(a.tiles_n * a.tiles_k, splits), dim3(512), lds_b, stream, a);
+  hipLaunchKernelGGL((gemm_tn_kernel<TM_, KSUB, STAGES>), dim3(g.base[g.count]), dim3(512), lds_b, stream, g);
   MVPTR_CHECK_LAUNCH("gemm_tn");
   return MVPTR_OK;
 }
@@ -276,19 +299,19 @@ struct TnPlan {
   double cost;
 };
 
-// Estimated time of one configuration: whole rounds of workgroups x steps per split, plus the f32
-// atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
-TnPlan plan_tn(int M, int N, int K, int tm, int ksub) {
-  const int tiles = ((N + TN_ - 1) / TN_) * ((K + ksub * 128 - 1) / (ksub * 128));
+// Estimated time of one configuration for `tiles` output tiles of one launch (all problems of a
+// group share M, so they share the split count): whole rounds of workgroups x steps per split,
+// plus the f32 atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
+TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
   // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1)
-  const double t64 = (ksub == 2) ? 3.1 : (tm == 64 ? 1.7 : 2.7);
+  const double t64 = (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
   TnPlan best{tm, ksub, 1, 1e30};
   const int max_splits = (M + 255) / 256;
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
     const double rounds = (double)((tiles * sp + slots - 1) / slots);
     const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
-    const double cost = rounds * steps * t64 + (double)sp * (double)N * (double)K * 4.0 / 1.3e6 * 0.7;
+    const double cost = rounds * steps * t64 + (double)sp * (double)out_elems * 4.0 / 1.3e6 * 0.7;
     if (cost < best.cost) {
       best.cost = cost;
       best.splits = sp;
@@ -297,55 +320,121 @@ TnPlan plan_tn(int M, int N, int K, int tm, int ksub) {
   return best;
 }
 
-}  // namespace
+int check_problem(const mvptr_tn_problem& q) {
+  if (q.M <= 0 || q.N <= 0 || q.K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: M,N,K must be > 0");
+  if ((q.lda & 7) || (q.ldb & 7)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: lda, ldb must be multiples of 8");
+  if (q.lda < q.N || q.ldb < q.K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: lda/ldb smaller than N/K");
+  if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: A and B must be 16-byte aligned");
+  if (!q.A || !q.B || !q.dW) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_tn: NULL argument");
+  return MVPTR_OK;
+}
 
-extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,
-                             int K, float* dW, int64_t ldw, float* colsum, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: M,N,K must be > 0");
-  if ((lda & 7) || (ldb & 7))
-    MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: lda, ldb must be multiples of 8");
-  if (lda < N || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn: lda/ldb smaller than N/K");
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15))
-    MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_tn: A and B must be 16-byte aligned");
-  // three configurations (see gemm_tn_kernel); pick the cheapest plan.  MVPTR_GEMM_TN = "64" |
-  // "32" | "k2" forces one (tuning knob).
-  TnPlan plans[3] = {plan_tn(M, N, K, 32, 1), plan_tn(M, N, K, 64, 1), plan_tn(M, N, K, 32, 2)};
-  // the 256x256 tile ("k2") measured 10-15 % slower than 256x128 at two workgroups per CU for every
-  // shape of this model, so only the first two compete by default
+// one launch for `count` problems with the same M
+int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
+  const int M = probs[0].M;
+  // four configurations (see gemm_tn_kernel); MVPTR_GEMM_TN = "32" | "64" | "k2" | "K" forces one
+  // (tuning knob).  The 256x256 tiles measured no faster than 256x128 at two workgroups per CU on
+  // this model's shapes, so only the 256x128 tiles compete by default.
+  const int cfg_tm[4] = {32, 64, 32, 64}, cfg_ks[4] = {1, 1, 2, 2};
+  TnPlan plans[4];
+  for (int c = 0; c < 4; ++c) {
+    int tiles = 0;
+    int64_t out_elems = 0;
+    for (int i = 0; i < count; ++i) {
+      tiles += ((probs[i].N + TN_ - 1) / TN_) * ((probs[i].K + cfg_ks[c] * 128 - 1) / (cfg_ks[c] * 128));
+      out_elems += (int64_t)probs[i].N * probs[i].K;
+    }
+    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c]);
+  }
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
   const char* env = getenv("MVPTR_GEMM_TN");
-  if (env != nullptr) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : 0;
+  if (env != nullptr) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : 0;
   const TnPlan pl = plans[pick];
-  GemmTnArgs a;
-  a.A = (const __bf16*)A;
-  a.B = (const __bf16*)B;
-  a.lda = lda;
-  a.ldb = ldb;
-  a.M = M;
-  a.N = N;
-  a.K = K;
-  a.dW = dW;
-  a.ldw = ldw;
-  a.colsum = colsum;
-  a.stamps = nullptr;
-#ifdef MVPTR_TIMELINE_BUILD
-  {
-    const char* sp = getenv("MVPTR_GEMM_STAMPS");
-    if (sp != nullptr) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
-  }
-#endif
-  a.tiles_n = (N + TN_ - 1) / TN_;
-  a.tiles_k = (K + pl.ksub * 128 - 1) / (pl.ksub * 128);
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
   // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)
-  const int64_t ldmax = lda > ldb ? lda : ldb;
+  int64_t ldmax = 8;
+  for (int i = 0; i < count; ++i) {
+    if (probs[i].lda > ldmax) ldmax = probs[i].lda;
+    if (probs[i].ldb > ldmax) ldmax = probs[i].ldb;
+  }
   while ((int64_t)rps * ldmax * 2 >= (int64_t)0x7fffffff && rps > pl.tm) rps = (rps / 2 + pl.tm - 1) / pl.tm * pl.tm;
   const int splits = (M + rps - 1) / rps;
-  a.rows_per_split = rps;
-  if (pl.ksub == 2) return launch_tn<32, 2>(a, splits, (hipStream_t)stream);
-  if (pl.tm == 64) return launch_tn<64, 1>(a, splits, (hipStream_t)stream);
-  return launch_tn<32, 1>(a, splits, (hipStream_t)stream);
+  GemmTnGroup g;
+  g.count = count;
+  g.base[0] = 0;
+  for (int i = 0; i < count; ++i) {
+    GemmTnArgs& a = g.prob[i];
+    a.A = (const __bf16*)probs[i].A;
+    a.B = (const __bf16*)probs[i].B;
+    a.lda = probs[i].lda;
+    a.ldb = probs[i].ldb;
+    a.M = M;
+    a.N = probs[i].N;
+    a.K = probs[i].K;
+    a.dW = probs[i].dW;
+    a.ldw = probs[i].ldw;
+    a.colsum = probs[i].colsum;
+    a.stamps = nullptr;
+    a.tiles_n = (a.N + TN_ - 1) / TN_;
+    a.tiles_k = (a.K + pl.ksub * 128 - 1) / (pl.ksub * 128);
+    a.rows_per_split = rps;
+    g.base[i + 1] = g.base[i] + a.tiles_n * a.tiles_k * splits;
+  }
+  for (int i = count; i < MVPTR_TN_MAX_GROUP; ++i) {
+    g.prob[i] = g.prob[0];
+    g.base[i + 1] = g.base[count];
+  }
+#ifdef MVPTR_TIMELINE_BUILD
+  {
+    const char* sp = getenv("MVPTR_GEMM_STAMPS");
+    if (sp != nullptr)
+      for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
+  }
+#endif
+  if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
+  if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
+  if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);
+  return launch_tn<32, 1, 3>(g, stream);
+}
+
+}  // namespace
+
+extern "C" int mvptr_gemm_tn_multi(const mvptr_tn_problem* probs, int count, void* stream) {
+  if (!probs || count <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_tn_multi: no problems");
+  for (int i = 0; i < count; ++i) {
+    const int rc = check_problem(probs[i]);
+    if (rc != MVPTR_OK) return rc;
+  }
+  // problems are grouped while they share M (one split plan per launch); MVPTR_TN_GROUP=0 issues
+  // them one by one (A/B knob)
+  const char* genv = getenv("MVPTR_TN_GROUP");
+  const int max_group = (genv != nullptr && genv[0] == '0') ? 1 : MVPTR_TN_MAX_GROUP;
+  int i = 0;
+  while (i < count) {
+    int j = i + 1;
+    while (j < count && j - i < max_group && probs[j].M == probs[i].M) ++j;
+    const int rc = run_group(probs + i, j - i, (hipStream_t)stream);
+    if (rc != MVPTR_OK) return rc;
+    i = j;
+  }
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,
+                             int K, float* dW, int64_t ldw, float* colsum, void* stream) {
+  mvptr_tn_problem q;
+  q.A = A;
+  q.lda = lda;
+  q.B = B;
+  q.ldb = ldb;
+  q.M = M;
+  q.N = N;
+  q.K = K;
+  q.dW = dW;
+  q.ldw = ldw;
+  q.colsum = colsum;
+  return mvptr_gemm_tn_multi(&q, 1, stream);
 }
 
 extern "C" int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream) {

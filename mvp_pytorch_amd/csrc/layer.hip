@@ -78,7 +78,11 @@ extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   if (check_desc("layer_workspace_bytes", d)) return -1;
   const int64_t M = (int64_t)d->B * d->L, H = d->H;
   const int64_t W = d->I > 3 * H ? d->I : 3 * H;
-  return 3 * al256(M * H * 2) + al256(M * W * 2) + al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H));
+  // backward: five [M,H] buffers, dU [M,I], dqkv [M,3H] (every weight-gradient operand stays alive
+  // until the grouped weight-gradient launch at the end of the layer) + LayerNorm partials
+  (void)W;
+  return 5 * al256(M * H * 2) + al256(M * d->I * 2) + al256(M * 3 * H * 2) +
+         al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H));
 }
 
 extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
@@ -122,49 +126,72 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   const int M = d->B * d->L, H = d->H, I = d->I;
   Stash s = carve(d, const_cast<void*>(saved));
   char* p = (char*)ws;
-  char* bufA = p;
-  char* bufB = bufA + al256((int64_t)M * H * 2);
-  char* bufC = bufB + al256((int64_t)M * H * 2);
-  char* bufU = bufC + al256((int64_t)M * H * 2);
-  const int64_t W_ = I > 3 * H ? I : 3 * H;
-  char* lnws = bufU + al256((int64_t)M * W_ * 2);
+  char* bufA = p;                                       // LN2 dz (residual branch)
+  char* bufB = bufA + al256((int64_t)M * H * 2);        // LN2 dz, dropout-masked (dense branch)
+  char* bufC = bufB + al256((int64_t)M * H * 2);        // gradient flowing down the residual stream
+  char* bufD = bufC + al256((int64_t)M * H * 2);        // LN1 dz
+  char* bufE = bufD + al256((int64_t)M * H * 2);        // LN1 dz, dropout-masked
+  char* bufU = bufE + al256((int64_t)M * H * 2);        // dU [M, I]
+  char* bufQ = bufU + al256((int64_t)M * I * 2);        // dqkv [M, 3H]
+  char* lnws = bufQ + al256((int64_t)M * 3 * H * 2);
   const int64_t lnws_bytes = mvptr_layernorm_bwd_ws_bytes(M, H);
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
   const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
   const bool hdrop = dr_o.thresh16 != 0;
+  // Weight gradients are collected and issued as grouped launches (FFN pair, attention pair): the
+  // atomic write-out of one problem overlaps the MFMA loop of the next.
+  mvptr_tn_problem wg[4];
+  int nwg = 0;
+  auto add_wgrad = [&](const void* dyp, int64_t lda, const void* xp, int64_t ldb, int N, int K, float* dw,
+                       float* colsum) {
+    mvptr_tn_problem& q = wg[nwg++];
+    q.A = dyp;
+    q.lda = lda;
+    q.B = xp;
+    q.ldb = ldb;
+    q.M = M;
+    q.N = N;
+    q.K = K;
+    q.dW = dw;
+    q.ldw = K;
+    q.colsum = colsum;
+  };
 
   // output.LayerNorm / output.dense
   RUN(mvptr_layernorm_bwd(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
                           g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
                           hdrop ? &dr_out : nullptr, lnws, lnws_bytes, stream));
   const char* d2 = hdrop ? bufB : bufA;
-  if (g->w_out) RUN(mvptr_gemm_tn(d2, H, s.a, I, M, H, I, g->w_out, I, nullptr, stream));
+  if (g->w_out) add_wgrad(d2, H, s.a, I, H, I, g->w_out, nullptr);
   RUN(mvptr_gemm_nt(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
                     I, g->b_i, nullptr, stream));
-  // intermediate.dense
-  if (g->w_i) RUN(mvptr_gemm_tn(bufU, I, s.x1, H, M, I, H, g->w_i, H, nullptr, stream));
+  // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
+  // in the Infinity Cache
+  if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, nullptr);
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
+  nwg = 0;
   RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
                     nullptr, nullptr, stream));
   // attention.output.LayerNorm / dense
-  RUN(mvptr_layernorm_bwd(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufA, hdrop ? bufB : nullptr,
+  RUN(mvptr_layernorm_bwd(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
                           g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
                           hdrop ? &dr_o : nullptr, lnws, lnws_bytes, stream));
-  const char* d1 = hdrop ? bufB : bufA;
-  if (g->w_o) RUN(mvptr_gemm_tn(d1, H, s.ctx, H, M, H, H, g->w_o, H, nullptr, stream));
+  const char* d1 = hdrop ? bufE : bufD;
+  if (g->w_o) add_wgrad(d1, H, s.ctx, H, H, H, g->w_o, nullptr);
   RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
                     nullptr, nullptr, stream));
   // attention core
-  RUN(mvptr_attention_bwd(s.qkv, mask_add, s.ctx, bufC, s.lse, bufU, d->B, d->L, d->heads, &dr_attn,
+  RUN(mvptr_attention_bwd(s.qkv, mask_add, s.ctx, bufC, s.lse, bufQ, d->B, d->L, d->heads, &dr_attn,
                           stream));
-  // Q/K/V projections
-  // the Q/K/V bias gradient (column sums of dqkv) rides on the weight-gradient kernel
+  // Q/K/V projections: the bias gradient (column sums of dqkv) rides on the weight-gradient kernel
   if (g->w_qkv) {
-    RUN(mvptr_gemm_tn(bufU, 3 * H, x, H, M, 3 * H, H, g->w_qkv, H, g->b_qkv, stream));
+    add_wgrad(bufQ, 3 * H, x, H, 3 * H, H, g->w_qkv, g->b_qkv);
   } else if (g->b_qkv) {
-    RUN(mvptr_colsum(bufU, 3 * H, M, 3 * H, g->b_qkv, stream));
+    RUN(mvptr_colsum(bufQ, 3 * H, M, 3 * H, g->b_qkv, stream));
   }
-  RUN(mvptr_gemm_nt(bufU, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufA, H, dx,
+  RUN(mvptr_gemm_nt(bufQ, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufD, H, dx,
                     nullptr, H, nullptr, nullptr, stream));
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
   return MVPTR_OK;
 }

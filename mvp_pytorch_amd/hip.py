@@ -21,7 +21,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_colsum",
+    "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
@@ -43,6 +43,11 @@ class LayerWeights(Structure):
     _fields_ = [(n, c_void_p) for n in (
         "w_qkv", "w_qkv_t", "b_qkv", "w_o", "w_o_t", "b_o", "ln1_g", "ln1_b", "w_i", "w_i_t", "b_i",
         "w_out", "w_out_t", "b_out", "ln2_g", "ln2_b")]
+
+
+class TnProblem(Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("dW", c_void_p), ("ldw", c_int64), ("colsum", c_void_p)]
 
 
 class LayerGrads(Structure):
@@ -73,6 +78,7 @@ def load():
     lib.mvptr_query.argtypes = [I, POINTER(c_int64)]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
+    lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
     lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
@@ -160,6 +166,18 @@ def gemm_tn(dy, x, dw, n=None, k=None, colsum=None):
     assert x.shape[0] == M and dw.stride(1) == 1
     _check(load().mvptr_gemm_tn(_p(dy), dy.stride(0), _p(x), x.stride(0), M, N, K, _p(dw), dw.stride(0), _p(colsum), _stream()))
     return dw
+
+
+def gemm_tn_multi(problems):
+    """problems: list of (dy, x, dw, colsum-or-None); one grouped launch per run of equal M."""
+    arr = (TnProblem * len(problems))()
+    for q, (dy, x, dw, cs) in zip(arr, problems):
+        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+        assert x.shape[0] == dy.shape[0] and dw.stride(1) == 1 and dw.shape == (dy.shape[1], x.shape[1])
+        q.A, q.lda, q.B, q.ldb = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        q.M, q.N, q.K = dy.shape[0], dy.shape[1], x.shape[1]
+        q.dW, q.ldw, q.colsum = dw.data_ptr(), dw.stride(0), (cs.data_ptr() if cs is not None else None)
+    _check(load().mvptr_gemm_tn_multi(arr, len(problems), _stream()))
 
 
 def colsum(x, out, n=None):

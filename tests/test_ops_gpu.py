@@ -109,7 +109,7 @@ def test_gemm_tn(dev, M, N, K):
     dy[:, :N] = _bf(torch.randn(M, N, generator=g))
     dy = dy.to(dev)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    for cfg in ("32", "64", "k2", None):  # every tile configuration + the planner's own choice
+    for cfg in ("32", "64", "k2", "K", None):  # every tile configuration + the planner's own choice
         if cfg is None:
             os.environ.pop("MVPTR_GEMM_TN", None)
         else:
@@ -124,6 +124,43 @@ def test_gemm_tn(dev, M, N, K):
         assert _rel(cs, dy[:, :N].float().sum(0)) < 1e-5
         hip.gemm_tn(dy, x, dw, n=N)  # accumulates
         assert _rel(dw, 2 * ref) < 1e-5
+    os.environ.pop("MVPTR_GEMM_TN", None)
+
+
+def test_gemm_tn_multi(dev):
+    """Grouped launch: four problems sharing M (an encoder layer's weight gradients) and one with a
+    different M (split into its own launch) give the same results as separate calls."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(14)
+    M = 700
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs, refs = [], []
+    for N, K in shapes:
+        dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+        x = _bf(torch.randn(M, K, generator=g)).to(dev)
+        dw = torch.zeros(N, K, device=dev)
+        cs = torch.zeros(N, device=dev) if N == 2304 else None
+        probs.append((dy, x, dw, cs))
+        refs.append(dy.float().t() @ x.float())
+    dy5 = _bf(torch.randn(130, 100 + 4, generator=g)).to(dev)
+    x5 = _bf(torch.randn(130, 72, generator=g)).to(dev)
+    dw5 = torch.zeros(104, 72, device=dev)
+    probs.append((dy5, x5, dw5, None))
+    refs.append(dy5.float().t() @ x5.float())
+    for cfg in ("32", "K", None):
+        if cfg is None:
+            os.environ.pop("MVPTR_GEMM_TN", None)
+        else:
+            os.environ["MVPTR_GEMM_TN"] = cfg
+        for _, _, dw, cs in probs:
+            dw.zero_()
+            if cs is not None:
+                cs.zero_()
+        hip.gemm_tn_multi(probs)
+        for (dy, x, dw, cs), ref in zip(probs, refs):
+            assert _rel(dw, ref) < 1e-5
+            if cs is not None:
+                assert _rel(cs, dy.float().sum(0)) < 1e-5
     os.environ.pop("MVPTR_GEMM_TN", None)
 
 

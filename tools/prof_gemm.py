@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvp_pytorch_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
-M, H, I = 32000, 768, 3072
+M, H, I = 64000, 768, 3072
 
 
 def rnd(*s):
@@ -25,8 +25,12 @@ for _ in range(3):
     hip.gemm_nt(xi, w_out, hip.EPI_BIAS_RESID, bias=b_out, aux=x)  # gemm_nt<2>: K=3072, N=768
     hip.gemm_nt(x, w_i, hip.EPI_BIAS_GELU, bias=b_i)           # gemm_nt<1>: K=768, N=3072
     dw = torch.zeros(I, H, device=dev)
-    hip.gemm_tn(xi, x, dw)                                     # gemm_tn: N=3072, K=768
-B, L, heads = 256, 125, 12
+    os.environ["MVPTR_GEMM_TN"] = "32"
+    hip.gemm_tn(xi, x, dw)                                     # gemm_tn<32,1,3>: N=3072, K=768
+    os.environ["MVPTR_GEMM_TN"] = "K"
+    hip.gemm_tn(xi, x, dw)                                     # gemm_tn<64,2,2>
+    os.environ.pop("MVPTR_GEMM_TN")
+B, L, heads = 512, 125, 12
 qkv = rnd(B * L, 3 * H)
 mask = torch.zeros(B, L, device=dev)
 dctx = rnd(B * L, H)

@@ -38,7 +38,7 @@ def run(M, N, K, name):
     print("   in write-out per %.0f-us bin: %s" % (width, " ".join("%3d" % int(((loop <= b + width / 2) & (b + width / 2 < end)).sum()) for b in bins)))
 
 
-for cfg in (None, "64", "k2"):
+for cfg in ("32", "K"):
     if cfg is None:
         os.environ.pop("MVPTR_GEMM_TN", None)
     else:
