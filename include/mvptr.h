@@ -183,6 +183,25 @@ int mvptr_embed_bwd(const int64_t* ids, const int64_t* pos_ids, const int64_t* t
 int mvptr_cast_pack(const float* src, int64_t ld_src, int rows, int cols, void* dst,
                     int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int col_off_t, void* stream);
 
+/* Many mvptr_cast_pack jobs in one launch (all working copies of an encoder's weights after an
+ * optimizer step).  `tasks` and `tile_base` live in DEVICE memory: tile_base[i] = first 32x32 tile
+ * of task i, tile_base[n_tasks] = total_tiles; tiles_x = ceil(max(cols, ld_dst) / 32).
+ * dst_f32 (optional) receives an unconverted f32 copy [rows, cols] (packed Q|K|V bias). */
+typedef struct {
+  const float* src;
+  int64_t ld_src;
+  int rows, cols;
+  void* dst;        /* bf16 [rows, ld_dst] or NULL */
+  int64_t ld_dst;
+  void* dst_t;      /* bf16 [cols, ld_dst_t] or NULL */
+  int64_t ld_dst_t;
+  int col_off_t;
+  int tiles_x;
+  float* dst_f32;   /* f32 [rows, cols] or NULL */
+} mvptr_cast_task;
+int mvptr_cast_multi(const mvptr_cast_task* tasks, const int* tile_base, int n_tasks,
+                     int total_tiles, void* stream);
+
 /* bf16 -> f32 strided copy (grad hand-back / outputs) */
 int mvptr_cast_f32(const void* src, int64_t ld_src, int rows, int cols, float* dst,
                    int64_t ld_dst, void* stream);

@@ -480,6 +480,41 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const float* src, int64_
   }
 }
 
+// many cast_pack jobs in one launch: block -> (task, 32x32 tile) through the prefix array tile_base
+__global__ __launch_bounds__(256) void cast_multi_kernel(const mvptr_cast_task* tasks, const int* tile_base,
+                                                          int n_tasks) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_tasks - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {  // last task whose first tile is <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_base[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const mvptr_cast_task t = tasks[lo];
+  const int local = b - tile_base[lo];
+  const int bx = local % t.tiles_x, by = local / t.tiles_x;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = bx * 32, r0 = by * 32;
+  __bf16* dst = (__bf16*)t.dst;
+  __bf16* dst_t = (__bf16*)t.dst_t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (r < t.rows && c < t.cols) v = t.src[(int64_t)r * t.ld_src + c];
+    tile[ty + 8 * k][tx] = v;
+    if (dst != nullptr && r < t.rows && c < t.ld_dst) dst[(int64_t)r * t.ld_dst + c] = f2bf(v);
+    if (t.dst_f32 != nullptr && r < t.rows && c < t.cols) t.dst_f32[(int64_t)r * t.cols + c] = v;
+  }
+  if (dst_t == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < t.cols && r < t.rows) dst_t[(int64_t)c * t.ld_dst_t + t.col_off_t + r] = f2bf(tile[tx][ty + 8 * k]);
+  }
+}
+
 __global__ void cast_f32_kernel(const __bf16* src, int64_t ld_src, int rows, int cols, float* dst,
                                 int64_t ld_dst) {
   const int64_t n = (int64_t)rows * cols;
@@ -742,6 +777,16 @@ extern "C" int mvptr_cast_pack(const float* src, int64_t ld_src, int rows, int c
   hipLaunchKernelGGL(cast_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, rows,
                      cols, (__bf16*)dst, ld_dst, (__bf16*)dst_t, ld_dst_t, col_off_t);
   MVPTR_CHECK_LAUNCH("cast_pack");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_cast_multi(const mvptr_cast_task* tasks, const int* tile_base, int n_tasks,
+                                int total_tiles, void* stream) {
+  if (!tasks || !tile_base || n_tasks <= 0 || total_tiles <= 0)
+    MVPTR_FAIL(MVPTR_BAD_ARG, "cast_multi: empty task table");
+  hipLaunchKernelGGL(cast_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tasks,
+                     tile_base, n_tasks);
+  MVPTR_CHECK_LAUNCH("cast_multi");
   return MVPTR_OK;
 }
 

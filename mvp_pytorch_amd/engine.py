@@ -62,7 +62,8 @@ def cast_weight(w, want_t=True, kpad=None):
     N, K = w.shape
     Kp = pad8(K) if kpad is None else kpad
     dst = torch.empty((N, Kp), device=w.device, dtype=torch.bfloat16)
-    dst_t = torch.zeros((K, pad8(N)), device=w.device, dtype=torch.bfloat16) if want_t else None
+    alloc_t = torch.empty if N % 8 == 0 else torch.zeros  # only pad columns need the zeros
+    dst_t = alloc_t((K, pad8(N)), device=w.device, dtype=torch.bfloat16) if want_t else None
     hip.cast_pack(w, dst=dst, dst_t=dst_t)
     return dst, dst_t
 
@@ -114,11 +115,81 @@ class LayerPack:
         return lw
 
 
+class PackList(list):
+    """The LayerPack objects of one encoder stack + their shared EncoderPacks refresher."""
+
+    def __init__(self, it):
+        super().__init__(it)
+        self.group = EncoderPacks(self)
+
+
+class EncoderPacks:
+    """bf16 working copies of ALL layers of one encoder stack, refreshed with one mvptr_cast_multi
+    launch when any parameter version changes (after every optimizer step): buffers and the device
+    task table are built once, so a refresh is a single kernel instead of 6 casts + 4 fills per
+    layer.  Falls back to the per-layer LayerPack path for parameters that are not contiguous f32."""
+
+    def __init__(self, packs):
+        self.packs = packs          # per-layer LayerPack objects (fallback path, and owners of .w)
+        self.cache = WeightCache()
+        self.ptr_key = None
+        self.plan = None
+
+    def _build(self, params):
+        n = len(self.packs)
+        dev = params[0].device
+        bf = torch.bfloat16
+        plan = hip.CastPlan(dev)
+        for li in range(n):
+            (qw, qb, kw, kb, vw, vb, ow, ob, g1, b1, iw, ib, pw, pb, g2, b2) = params[16 * li:16 * (li + 1)]
+            H, I = qw.shape[1], iw.shape[0]
+            assert H % 8 == 0 and I % 8 == 0
+            w_qkv = torch.empty((3 * H, H), device=dev, dtype=bf)
+            w_qkv_t = torch.empty((H, 3 * H), device=dev, dtype=bf)
+            b_qkv = torch.empty(3 * H, device=dev, dtype=torch.float32)
+            for i, (w, b) in enumerate(((qw, qb), (kw, kb), (vw, vb))):
+                plan.add(w.data, dst=w_qkv[i * H:(i + 1) * H], dst_t=w_qkv_t, col_off_t=i * H)
+                plan.add(b.data, dst_f32=b_qkv[i * H:(i + 1) * H])
+            w_o, w_o_t = torch.empty((H, H), device=dev, dtype=bf), torch.empty((H, H), device=dev, dtype=bf)
+            w_i, w_i_t = torch.empty((I, H), device=dev, dtype=bf), torch.empty((H, I), device=dev, dtype=bf)
+            w_out, w_out_t = torch.empty((H, I), device=dev, dtype=bf), torch.empty((I, H), device=dev, dtype=bf)
+            plan.add(ow.data, dst=w_o, dst_t=w_o_t)
+            plan.add(iw.data, dst=w_i, dst_t=w_i_t)
+            plan.add(pw.data, dst=w_out, dst_t=w_out_t)
+            lw = hip.LayerWeights()
+            lw.w_qkv, lw.w_qkv_t, lw.b_qkv = w_qkv.data_ptr(), w_qkv_t.data_ptr(), b_qkv.data_ptr()
+            lw.w_o, lw.w_o_t, lw.b_o = w_o.data_ptr(), w_o_t.data_ptr(), ob.data_ptr()
+            lw.ln1_g, lw.ln1_b = g1.data_ptr(), b1.data_ptr()
+            lw.w_i, lw.w_i_t, lw.b_i = w_i.data_ptr(), w_i_t.data_ptr(), ib.data_ptr()
+            lw.w_out, lw.w_out_t, lw.b_out = w_out.data_ptr(), w_out_t.data_ptr(), pb.data_ptr()
+            lw.ln2_g, lw.ln2_b = g2.data_ptr(), b2.data_ptr()
+            pk = self.packs[li]
+            pk.keep = [w_qkv, w_qkv_t, b_qkv, w_o, w_o_t, w_i, w_i_t, w_out, w_out_t]
+            pk.w = lw
+            pk.dims = (H, I)
+            pk.cache._key = None
+        plan.build()
+        self.plan = plan
+
+    def refresh(self, params):
+        """-> list of LayerWeights, one per layer."""
+        if not all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            return [self.packs[li].refresh(params[16 * li:16 * (li + 1)]) for li in range(len(self.packs))]
+        if self.cache.stale(params):
+            ptr_key = tuple(p.data_ptr() for p in params)
+            if ptr_key != self.ptr_key:
+                self._build(params)
+                self.ptr_key = ptr_key
+            self.plan.run()
+        return [pk.w for pk in self.packs]
+
+
 class EncoderMeta:
     """Static description handed to EncoderFn (not a tensor)."""
 
     def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn):
         self.packs, self.B, self.L, self.H, self.heads, self.I = packs, B, L, H, heads, I
+        self.group = getattr(packs, "group", None)
         self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
 
 
@@ -139,8 +210,12 @@ class EncoderFn(torch.autograd.Function):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         cur = x
         scratch = None
+        if meta.group is not None:
+            lws = meta.group.refresh(params)
+        else:
+            lws = [meta.packs[li].refresh(params[16 * li:16 * (li + 1)]) for li in range(n)]
         for li in range(n):
-            lw = meta.packs[li].refresh(params[16 * li:16 * (li + 1)])
+            lw = lws[li]
             d = hip.LayerDesc(meta.B, meta.L, meta.H, meta.heads, meta.I, meta.eps,
                               1 if meta.training else 0, _thresh(meta.p_hidden), _thresh(meta.p_attn),
                               next_seed() if meta.training else 0)

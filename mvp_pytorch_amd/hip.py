@@ -23,7 +23,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 SYMBOLS = [
     "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
-    "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_f32", "mvptr_ce_fwd",
+    "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
 ]
@@ -80,6 +80,7 @@ def load():
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
     lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
+    lib.mvptr_cast_multi.argtypes = [P, P, I, I, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_layernorm_fwd.argtypes = [P, P, P, F, P, P, P, I, I, I, I, I, POINTER(Dropout), P]
@@ -236,6 +237,41 @@ def embed_fwd(ids, pos_ids, type_ids, word, pos, typ):
 def embed_bwd(ids, pos_ids, type_ids, dz, dword, dpos, dtype_):
     rows, H = dz.shape
     _check(load().mvptr_embed_bwd(_p(ids), _p(pos_ids), _p(type_ids), _p(dz), _p(dword), _p(dpos), _p(dtype_), rows, H, _stream()))
+
+
+CAST_TASK_DTYPE = [("src", "<u8"), ("ld_src", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("dst", "<u8"), ("ld_dst", "<i8"),
+                   ("dst_t", "<u8"), ("ld_dst_t", "<i8"), ("col_off_t", "<i4"), ("tiles_x", "<i4"), ("dst_f32", "<u8")]
+
+
+class CastPlan:
+    """Device-resident task table for mvptr_cast_multi.  add() jobs, build() once, run() per refresh."""
+
+    def __init__(self, device):
+        self.device, self.jobs, self.table, self.base, self.total = device, [], None, None, 0
+
+    def add(self, src, dst=None, dst_t=None, col_off_t=0, dst_f32=None):
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        src2 = src if src.dim() == 2 else src.view(1, -1)
+        rows, cols = src2.shape
+        ld_dst = dst.stride(0) if dst is not None else cols
+        self.jobs.append((src2, rows, cols, dst, ld_dst, dst_t, col_off_t, dst_f32))
+
+    def build(self):
+        import numpy as np
+        tab = np.zeros(len(self.jobs), dtype=CAST_TASK_DTYPE)
+        base = np.zeros(len(self.jobs) + 1, dtype=np.int32)
+        for i, (src, rows, cols, dst, ld_dst, dst_t, col_off_t, dst_f32) in enumerate(self.jobs):
+            tx = (max(cols, ld_dst if dst is not None else cols) + 31) // 32
+            tab[i] = (src.data_ptr(), src.stride(0), rows, cols, dst.data_ptr() if dst is not None else 0, ld_dst,
+                      dst_t.data_ptr() if dst_t is not None else 0, dst_t.stride(0) if dst_t is not None else 0,
+                      col_off_t, tx, dst_f32.data_ptr() if dst_f32 is not None else 0)
+            base[i + 1] = base[i] + tx * ((rows + 31) // 32)
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+        self.base = torch.from_numpy(base).to(self.device)
+        self.total = int(base[-1])
+
+    def run(self):
+        _check(load().mvptr_cast_multi(_p(self.table), _p(self.base), len(self.jobs), self.total, _stream()))
 
 
 def cast_pack(src, dst=None, dst_t=None, col_off_t=0):

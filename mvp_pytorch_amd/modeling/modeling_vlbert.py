@@ -77,7 +77,7 @@ class CaptionBertEncoder(nn.Module):
         self.output_hidden_states = config.output_hidden_states
         self.num_layers = config.num_hidden_layers
         self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
-        self._packs = [engine.LayerPack() for _ in range(config.num_hidden_layers)]
+        self._packs = engine.PackList(engine.LayerPack() for _ in range(config.num_hidden_layers))
         self._dims = (config.hidden_size, config.num_attention_heads, config.intermediate_size, config.layer_norm_eps)
 
     def _flat_params(self):
