@@ -79,6 +79,191 @@ struct GemmNtArgs {
 
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
+// Epilogue of one output tile: the wave's accumulators (MFMA layout: a lane holds 4 consecutive
+// columns of one row per 16x16 block) are restaged through the wave's private LDS area `st` in
+// CHUNK-row pieces and finished in row-chunk form (8 consecutive columns per lane): 16-byte bias /
+// residual loads, 16-byte coalesced stores.  CHUNK 32: 32 x ST_LD floats per wave (inside the
+// operand ring); CHUNK 16: 16 x 64 floats, XOR-swizzled (4 KiB per wave, beside the ring).
+template <int EPI, int MT, int CHUNK>
+__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4][MT], float* st, int m0, int n0,
+                                            int wm, int wn, int lane) {
+  constexpr int WROWS = MT * 16;
+  const int c16 = lane & 15, q4 = lane >> 4;
+
+  const int ch = lane & 7, rsub = lane >> 3;
+  const int n = n0 + wn * 64 + ch * 8;
+  const bool nfull = (n + 7 < p.N);
+  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr && n < p.N) {
+    if (nfull && p.vec_bias_ok) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        b8[e] = b0[e];
+        b8[4 + e] = b1[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) b8[e] = p.bias[n + e];
+    }
+  }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto store_bf8 = [&](void* base, int m, const float v[8]) {
+    __bf16* op = (__bf16*)base + (int64_t)m * p.ldc + n;
+    if (nfull && p.vec_out_ok) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      *reinterpret_cast<bf16x8*>(op) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) op[e] = f2bf(v[e]);
+    }
+  };
+
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+  const bool has_aux = kNeedsAux && p.aux != nullptr;
+
+#pragma unroll
+  for (int it = 0; it < MT * 2; ++it) {
+    // 32-row chunk ck = it >> 2 of the wave's block goes through the staging area; its residual /
+    // pre-activation rows are requested together so the chunk pays one memory latency, not four
+    bf16x8 auxv[4];
+    if constexpr (CHUNK == 32) {
+      if ((it & 3) == 0) {
+        const int ck = it >> 2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+            *reinterpret_cast<f32x4*>(st + (mh * 16 + c16) * ST_LD + nt * 16 + q4 * 4) = acc[nt][2 * ck + mh];
+      }
+    } else {
+      // 16-row chunks, unpadded 64-float rows, 16-byte chunk index XOR row: conflict free for the
+      // 4x4-block writes and for the row reads below
+      if ((it & 1) == 0) {
+        const int ck = it >> 1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          *reinterpret_cast<f32x4*>(st + c16 * 64 + (((nt * 4 + q4) ^ c16) << 2)) = acc[nt][ck];
+      }
+    }
+    if (kNeedsAux && (it & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mj = m0 + wm * WROWS + (it + j) * 8 + rsub;
+        bf16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
+        if (has_aux && mj < p.M && n < p.N) {
+          const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
+          if (nfull && p.vec_aux_ok) {
+            x = *reinterpret_cast<const bf16x8*>(ap);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e < p.N) x[e] = ap[e];
+          }
+        }
+        auxv[j] = x;
+      }
+    }
+    const int row = it * 8 + rsub;
+    const int lrow = row & (CHUNK - 1);
+    const int m = m0 + wm * WROWS + row;
+    f32x4 v0, v1;
+    if constexpr (CHUNK == 32) {
+      v0 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8);
+      v1 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8 + 4);
+    } else {
+      v0 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch) ^ lrow) << 2));
+      v1 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch + 1) ^ lrow) << 2));
+    }
+    if (m >= p.M || n >= p.N) continue;
+    float v[8], a[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = v0[e] + b8[e];
+      v[4 + e] = v1[e] + b8[4 + e];
+    }
+    if (kNeedsAux) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it & 3][e]);
+    }
+    if (EPI == MVPTR_EPI_BIAS) {
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_BIAS_GELU) {
+      float g[8], dg[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 a2, d2;
+        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+        g[e] = a2.x;
+        g[e + 1] = a2.y;
+        dg[e] = d2.x;
+        dg[e + 1] = d2.y;
+      }
+      store_bf8(p.out0, m, dg);
+      store_bf8(p.out1, m, g);
+    } else if (EPI == MVPTR_EPI_BIAS_RESID) {
+      if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
+#pragma unroll
+        for (int e = 0; e < 8; e += 2)
+          drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_GELU_BWD) {
+      // aux = gelu'(u) saved by the forward epilogue; rows / columns outside the problem have
+      // acc = 0 (zero-filled operand rows), so the column sums need no guard
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] *= a[e];
+        cs[e] += v[e];
+      }
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
+      store_bf8(p.out0, m, v);
+    } else if (EPI == MVPTR_EPI_F32) {
+      float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
+      if (nfull && p.vec_out_ok) {
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) op[e] = v[e];
+      }
+    } else if (EPI == MVPTR_EPI_BIAS_TANH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      store_bf8(p.out0, m, v);
+    }
+  }
+  if (EPI == MVPTR_EPI_GELU_BWD && p.vec_out != nullptr) {
+    // sum the 8 row-lanes (lane>>3) that share a column chunk, then one atomic per column
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = cs[e];
+      s += __shfl_xor(s, 8);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (rsub == 0 && n + e < p.N) atomicAdd(p.vec_out + n + e, s);
+    }
+  }
+}
+
 // WM = 4: 8 waves of 64x64 (512 threads).  WM = 2: 4 waves of 128x64 (256 threads): 25 % fewer LDS
 // fragment reads per MFMA and half the waves per barrier, 256 registers per wave available.
 template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
@@ -185,57 +370,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
 
   const int nk = (p.K + BK - 1) / BK;
   constexpr int LPS = NA + NB;  // loads per stage per thread
-  if constexpr (SCHED == 1) {
-    // Fragment-prefetch schedule (KS == 1, 3-buffer ring): the fragments of K-step kt+1 are read
-    // from LDS into a second register set while the MFMAs of K-step kt run, so the LDS read
-    // latency is off the critical path; three stages are requested ahead of the consumer.
-    static_assert(KS == 1 && STAGES == 3, "prefetch schedule is written for BK = 32, 3 buffers");
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (s < nk) stage(s, s * BK);
-    if (nk >= 3)
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
-    else if (nk == 2)
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    bf16x8 xa[MT], wa[4], xb[MT], wb[4];
-    auto load_frags = [&](int bufi, bf16x8(&xf)[MT], bf16x8(&wf)[4]) {
-      const char* la = lds + bufi * STAGE_BYTES;
-      const char* lb = la + A_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
-    };
-    load_frags(0, xa, wa);
-    int bcur = 0;
-    auto body = [&](int kt, bf16x8(&xc)[MT], bf16x8(&wc)[4], bf16x8(&xn)[MT], bf16x8(&wn_)[4]) {
-      if (kt + 1 < nk) {
-        // stage kt+1 landed (only stage kt+2 may still be in flight); this wave's reads of stage kt
-        // retired (lgkmcnt) before the barrier frees that buffer for stage kt+3
-        if (kt + 2 < nk)
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int bnext = (bcur == 2) ? 0 : bcur + 1;
-        load_frags(bnext, xn, wn_);
-        if (kt + 3 < nk) stage(bcur, (kt + 3) * BK);
-        bcur = bnext;
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[nt], xc[mt], acc[nt][mt], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-      body(kt, xa, wa, xb, wb);
-      if (kt + 1 < nk) body(kt + 1, xb, wb, xa, wa);
-    }
-  } else if constexpr (SCHED == 2) {
+  if constexpr (SCHED == 2) {
     // Staggered halves: the MFMA pipe of a SIMD is shared by wave i and wave i + NWAVES/2.  If both
     // run "issue loads, then MFMAs" in lockstep, the pipe idles while every wave issues its LDS-DMA
     // and fragment reads (~400 cycles per K-step measured with s_memtime) and then serialises both
@@ -377,164 +512,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop)::"memory");
 #endif
   __syncthreads();  // every wave is done with the operand ring
-  // the wave's 64x64 f32 block is restaged in two 32-row halves (fits the 72-KiB BK=32 ring)
-  float* st = reinterpret_cast<float*>(lds) + wave * (32 * ST_LD);
-
-  const int ch = lane & 7, rsub = lane >> 3;
-  const int n = n0 + wn * 64 + ch * 8;
-  const bool nfull = (n + 7 < p.N);
-  float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr && n < p.N) {
-    if (nfull && p.vec_bias_ok) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        b8[e] = b0[e];
-        b8[4 + e] = b1[e];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (n + e < p.N) b8[e] = p.bias[n + e];
-    }
-  }
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  auto store_bf8 = [&](void* base, int m, const float v[8]) {
-    __bf16* op = (__bf16*)base + (int64_t)m * p.ldc + n;
-    if (nfull && p.vec_out_ok) {
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      *reinterpret_cast<bf16x8*>(op) = o;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (n + e < p.N) op[e] = f2bf(v[e]);
-    }
-  };
-
-  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
-  const bool has_aux = kNeedsAux && p.aux != nullptr;
-
-#pragma unroll
-  for (int it = 0; it < MT * 2; ++it) {
-    // 32-row chunk ck = it >> 2 of the wave's block goes through the staging area; its residual /
-    // pre-activation rows are requested together so the chunk pays one memory latency, not four
-    bf16x8 auxv[4];
-    if ((it & 3) == 0) {
-      const int ck = it >> 2;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-          *reinterpret_cast<f32x4*>(st + (mh * 16 + c16) * ST_LD + nt * 16 + q4 * 4) = acc[nt][2 * ck + mh];
-    }
-    if (kNeedsAux && (it & 3) == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int mj = m0 + wm * WROWS + (it + j) * 8 + rsub;
-        bf16x8 x;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
-        if (has_aux && mj < p.M && n < p.N) {
-          const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
-          if (nfull && p.vec_aux_ok) {
-            x = *reinterpret_cast<const bf16x8*>(ap);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (n + e < p.N) x[e] = ap[e];
-          }
-        }
-        auxv[j] = x;
-      }
-    }
-    const int row = it * 8 + rsub;
-    const int lrow = row & 31;
-    const int m = m0 + wm * WROWS + row;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + lrow * ST_LD + ch * 8 + 4);
-    if (m >= p.M || n >= p.N) continue;
-    float v[8], a[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = v0[e] + b8[e];
-      v[4 + e] = v1[e] + b8[4 + e];
-    }
-    if (kNeedsAux) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it & 3][e]);
-    }
-    if (EPI == MVPTR_EPI_BIAS) {
-      store_bf8(p.out0, m, v);
-    } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-      float g[8], dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        f32x2 a2, d2;
-        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-        g[e] = a2.x;
-        g[e + 1] = a2.y;
-        dg[e] = d2.x;
-        dg[e + 1] = d2.y;
-      }
-      store_bf8(p.out0, m, dg);
-      store_bf8(p.out1, m, g);
-    } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-      if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
-#pragma unroll
-        for (int e = 0; e < 8; e += 2)
-          drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += a[e];
-      store_bf8(p.out0, m, v);
-    } else if (EPI == MVPTR_EPI_GELU_BWD) {
-      // aux = gelu'(u) saved by the forward epilogue; rows / columns outside the problem have
-      // acc = 0 (zero-filled operand rows), so the column sums need no guard
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] *= a[e];
-        cs[e] += v[e];
-      }
-      store_bf8(p.out0, m, v);
-    } else if (EPI == MVPTR_EPI_ADD) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += a[e];
-      store_bf8(p.out0, m, v);
-    } else if (EPI == MVPTR_EPI_F32) {
-      float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
-      if (nfull && p.vec_out_ok) {
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) op[e] = v[e];
-      }
-    } else if (EPI == MVPTR_EPI_BIAS_TANH) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-      store_bf8(p.out0, m, v);
-    }
-  }
-  if (EPI == MVPTR_EPI_GELU_BWD && p.vec_out != nullptr) {
-    // sum the 8 row-lanes (lane>>3) that share a column chunk, then one atomic per column
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float s = cs[e];
-      s += __shfl_xor(s, 8);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (rsub == 0 && n + e < p.N) atomicAdd(p.vec_out + n + e, s);
-    }
-  }
+  nt_epilogue<EPI, MT, 32>(p, acc, reinterpret_cast<float*>(lds) + wave * (32 * ST_LD), m0, n0, wm, wn, lane);
 #ifdef MVPTR_TIMELINE_BUILD
   asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_end)::"memory");
   if (p.stamps != nullptr && tid == 0) {
@@ -546,6 +524,184 @@ void gemm_nt_kernel(GemmNtArgs p) {
     o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
   }
 #endif
+}
+
+// Persistent form of the 256x256 / BK 64 configuration: one workgroup per CU walks over its tiles.
+// The 2 x 64 KiB operand ring and a separate 32-KiB epilogue staging area fill the 160-KiB LDS, so
+// after the last K-step of a tile both ring stages are free: the LDS-DMA loads of the NEXT tile's
+// first two K-steps are issued before the epilogue starts and land while it runs (pipeline-fill
+// latency and the workgroup hand-over gap, ~3 us of a 26-32 us tile at K = 768, leave the critical
+// path).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNtArgs p) {
+  using C = Cfg<64, 2, 2, 4, 8>;
+  constexpr int BM = C::BM, BN = C::BN, BK = 64, WN = 4;
+  constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, ROW_B = C::ROW_B, CHUNKS = C::CHUNKS;
+  constexpr int RPI = C::ROWS_PER_INSTR, NA = C::NA, NB = C::NB, KS = C::KS;
+  constexpr int NWAVES = C::NWAVES, MT = C::MT, WROWS = C::MT * 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = gridDim.x;
+
+  // With 128-byte rows (8 chunks) the swizzle (row >> 1) & 7 of staging instruction i and of
+  // fragment row-block i does not depend on i (their row offsets are multiples of 16), so one
+  // per-lane offset serves every instruction; the per-instruction part is a uniform constant.
+  static_assert(CHUNKS == 8 && RPI == 8, "persistent kernel is written for BK = 64");
+  const int srow = wave * RPI + lane / CHUNKS;                       // staging row of instruction 0
+  const int kc = ((lane % CHUNKS) ^ swz_row(srow, CHUNKS)) * 8;      // first k of this lane's chunk
+  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
+  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
+  const uint32_t stepA = (uint32_t)(NWAVES * RPI) * (uint32_t)p.lda * 2u;  // 64 rows further
+  const uint32_t stepB = (uint32_t)(NWAVES * RPI) * (uint32_t)p.ldb * 2u;
+  const int wm = wave / WN, wn = wave % WN;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  uint32_t fx0[KS], fw0[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int rx = wm * WROWS + c16, rw = wn * 64 + c16;
+    fx0[ks] = rx * ROW_B + (((ks * 4 + q4) ^ swz_row(rx, CHUNKS)) << 4);
+    fw0[ks] = rw * ROW_B + (((ks * 4 + q4) ^ swz_row(rw, CHUNKS)) << 4);
+  }
+  float* st = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * (16 * 64);
+  const int nk = (p.K + BK - 1) / BK;
+
+  // round r: workgroup w takes logical tile r * grid + remap(w) (bijective inside the round, the
+  // workgroups of one XCD get neighbouring tiles), grouped GROUP_M row-tiles x all column tiles
+  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
+    const int base = round * grid;
+    const int left = ntiles - base;
+    if (left <= 0) return false;
+    const int nthis = min(left, grid);
+    if ((int)blockIdx.x >= nthis) return false;
+    const int t = base + xcd_remap(blockIdx.x, nthis);
+    const int gsz = GROUP_M * p.tiles_n;
+    const int grp = t / gsz;
+    const int first_m = grp * GROUP_M;
+    const int gm = min(GROUP_M, p.tiles_m - first_m);
+    const int in_g = t - grp * gsz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+    return true;
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int buf, int k0) {
+    char* la = lds + buf * STAGE_BYTES;
+    char* lb = la + A_BYTES;
+    const bool in_k = (k0 + kc < p.K);
+    // opaque copies: keeps the compiler from hoisting the eight per-instruction offsets out of the
+    // K loop as loop invariants (they would be spilled; one v_add each is cheaper)
+    uint32_t oa = offA0, ob = offB0;
+    asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const uint32_t va = in_k ? oa + (uint32_t)i * stepA + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const uint32_t vb = in_k ? ob + (uint32_t)i * stepB + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+  auto rsrc_a = [&](int m0) {
+    const int rows_a = min(BM, p.M - m0);
+    return make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+  };
+  auto rsrc_b = [&](int n0) {
+    const int rows_b = min(BN, p.N - n0);
+    return make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
+  };
+
+  int m0 = 0, n0 = 0;
+  if (!tile_origin(0, m0, n0)) return;
+  __amdgpu_buffer_rsrc_t rsA = rsrc_a(m0), rsB = rsrc_b(n0);
+  bool prefetched = false;
+  for (int round = 0;; ++round) {
+    f32x4 acc[4][MT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!prefetched) stage(rsA, rsB, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // double buffer: K-step kt has landed when nothing is outstanding (the epilogue's stores of
+      // the previous tile included); the barrier also frees the other buffer for K-step kt + 1
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      const int buf = kt & 1;
+      const char* la = lds + buf * STAGE_BYTES;
+      const char* lb = la + A_BYTES;
+      bf16x8 xf[MT], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[0] + i * 16 * ROW_B);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[0] + i * 16 * ROW_B);
+      if (kt + 1 < nk && !(prefetched && kt == 0)) stage(rsA, rsB, buf ^ 1, (kt + 1) * BK);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[ks] + i * 16 * ROW_B);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[ks] + i * 16 * ROW_B);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    __syncthreads();  // every wave is done with the operand ring
+    int m1 = 0, n1 = 0;
+    const bool more = tile_origin(round + 1, m1, n1);
+    __amdgpu_buffer_rsrc_t rsA1 = rsA, rsB1 = rsB;
+    if (more) {
+      rsA1 = rsrc_a(m1);
+      rsB1 = rsrc_b(n1);
+      stage(rsA1, rsB1, 0, 0);
+      if (nk > 1) stage(rsA1, rsB1, 1, BK);
+    }
+    // the epilogue's lane-derived constants are recomputed per tile (opaque lane copy) instead of
+    // living in registers across the MFMA loop
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    nt_epilogue<EPI, MT, 16>(p, acc, st, m0, n0, wm, wn, lane_e);
+    if (!more) break;
+    m0 = m1;
+    n0 = n1;
+    rsA = rsA1;
+    rsB = rsB1;
+    prefetched = true;
+  }
+}
+
+template <int EPI>
+int launch_persist(GemmNtArgs a, hipStream_t s) {
+  using C = Cfg<64, 2, 2, 4, 8>;
+  constexpr int LDS_BYTES = C::LDS_BYTES + 8 * 16 * 64 * 4;  // ring + 32 KiB staging = 160 KiB
+  a.tiles_m = (a.M + C::BM - 1) / C::BM;
+  a.tiles_n = (a.N + C::BN - 1) / C::BN;
+  if ((int64_t)C::BM * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)C::BN * a.ldb * 2 >= (int64_t)0x7fffffff)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<EPI>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
+    num_cu = prop.multiProcessorCount;
+  }
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = ntiles < num_cu ? ntiles : num_cu;
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
 }
 
 template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
@@ -582,6 +738,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const char* env = getenv("MVPTR_GEMM_CFG");
   if (env != nullptr && env[0] != 0) {
     const size_t n = strlen(env);
+    if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
     if (env[0] == 't' && env[n - 1] == 'k') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
     if (env[0] == 't' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 2, 4, 8, 2>(a, s);
     if (env[0] == 't') return launch_bk<EPI, 32, 3, 2, 4, 8, 0>(a, s);

@@ -44,6 +44,11 @@ struct GemmTnGroup {
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, uint32_t off_lo, uint32_t off_hi) {
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 1
+  // speed experiment only (wrong values): one 16-byte read instead of two transposed 8-byte reads
+  (void)off_hi;
+  return *reinterpret_cast<const bf16x8*>(tile + (off_lo & ~15u));
+#endif
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + off_lo));
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -200,25 +205,35 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
     }
     const char* la = lds + buf * STAGE_B;
     const char* lb = la + 2 * SUB_B;
+    // software pipeline over the 16-row sub-steps: the transposed reads of sub-step s+1 are issued
+    // before the MFMAs of sub-step s (two 8-byte reads per fragment: twice the LDS instructions of a
+    // row-major operand, and a wave can only keep 15 of them in flight)
+    bf16x8 af[2][NBLK], bfr[2][2];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) af[0][b] = tr_frag(la, ta[b][0], ta[b][1]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bfr[0][b] = tr_frag(lb, tb[b][0], tb[b][1]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      bf16x8 af[NBLK], bfr[2];
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < NS) {
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) af[b] = tr_frag(la + s * 4096, ta[b][0], ta[b][1]);
+        for (int b = 0; b < NBLK; ++b) af[nxt][b] = tr_frag(la + (s + 1) * 4096, ta[b][0], ta[b][1]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(lb + s * 4096, tb[b][0], tb[b][1]);
+        for (int b = 0; b < 2; ++b) bfr[nxt][b] = tr_frag(lb + (s + 1) * 4096, tb[b][0], tb[b][1]);
+      }
 #pragma unroll
       for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
-          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[nb], bfr[kb], acc[nb][kb], 0, 0, 0);
+          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][nb], bfr[cur][kb], acc[nb][kb], 0, 0, 0);
       if (do_bias) {  // 4 x v_dot2c_f32_bf16 against (1, 1) per fragment
         const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bf16x2 pr = {af[nb][2 * j], af[nb][2 * j + 1]};
+            const bf16x2 pr = {af[cur][nb][2 * j], af[cur][nb][2 * j + 1]};
             bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
           }
       }
