@@ -96,42 +96,106 @@ def cpu_baseline(seconds_budget=20.0):
                        % (len(steady), med))
 
 
-def kernel_roofline(dev, dims, cfg):
-    """Dominant kernel = gemm_nt_kernel<EPI_BIAS_GELU> (BertIntermediate, 768->3072): replay
-    its per-step launch mix (6 layers x {txt, vis, joint, hard}) and time it with HIP events on
-    the launch stream."""
-    from mvp_pytorch_amd import hip
-    H, I = cfg["hidden_size"], cfg["intermediate_size"]
-    B = dims["B"]
-    Ls = [dims["T"] + dims["P"], dims["G"] + dims["R"], dims["T"] + dims["P"] + dims["R"], dims["T"] + dims["P"] + dims["R"]]
-    w = torch.randn(I, H, device=dev).to(torch.bfloat16)
-    bias = torch.zeros(I, device=dev)
-    xs = [torch.randn(B * L, H, device=dev).to(torch.bfloat16) for L in Ls]
-    outs = [(torch.empty(B * L, I, device=dev, dtype=torch.bfloat16), torch.empty(B * L, I, device=dev, dtype=torch.bfloat16)) for L in Ls]
-    for x, (u, a) in zip(xs, outs):
-        hip.gemm_nt(x, w, hip.EPI_BIAS_GELU, bias=bias, out=u, out1=a)
+class DominantMix:
+    """Per-step launch mix of the two kernels that lead the rocprofv3 kernel summary
+    (profiles/r01_bench_kernel_stats_*.csv): gemm_tn_kernel (grouped weight gradients) and
+    gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward).  Row counts of a configs[1] step: text B*75, visual
+    B*70, joint + hard-negative batch 2B*125; six layers each."""
+
+    def __init__(self, dev, dims, cfg):
+        from mvp_pytorch_amd import hip
+        self.hip = hip
+        H, I = cfg["hidden_size"], cfg["intermediate_size"]
+        self.H, self.I = H, I
+        B = dims["B"]
+        self.Ms = [B * (dims["T"] + dims["P"]), B * (dims["G"] + dims["R"]), 2 * B * (dims["T"] + dims["P"] + dims["R"])]
+        r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)  # noqa: E731
+        self.tn = []
+        for M in self.Ms:
+            d2, a, dU, x1 = r(M, H), r(M, I), r(M, I), r(M, H)
+            d1, ctx, dqkv, x = r(M, H), r(M, H), r(M, 3 * H), r(M, H)
+            z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+            self.tn.append(([(d2, a, z(H, I), None), (dU, x1, z(I, H), None)], 2.0 * M * 2 * H * I))
+            self.tn.append(([(d1, ctx, z(H, H), None), (dqkv, x, z(3 * H, H), z(3 * H))], 2.0 * M * 4 * H * H))
+        self.w = r(I, H)
+        self.bias = torch.zeros(I, device=dev)
+        self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.bfloat16),
+                    torch.empty(M, I, device=dev, dtype=torch.bfloat16), 2.0 * M * I * H) for M in self.Ms]
+
+    def run_tn(self):
+        for probs, _ in self.tn:
+            self.hip.gemm_tn_multi(probs)
+        return len(self.tn), sum(f for _, f in self.tn)
+
+    def run_nt(self):
+        for x, u, a, _ in self.nt:
+            self.hip.gemm_nt(x, self.w, self.hip.EPI_BIAS_GELU, bias=self.bias, out=u, out1=a)
+        return len(self.nt), sum(f for _, _, _, f in self.nt)
+
+    # algorithmic HBM bytes per launch (mean over the mix): operands read once, output written /
+    # accumulated once
+    def tn_bytes(self):
+        H, I = self.H, self.I
+        per = []
+        for M in self.Ms:
+            per.append(2.0 * M * (H + I) * 2 + 2 * H * I * 4)           # FFN pair: d2, a, dU, x1 ; dW_out, dW_i
+            per.append(2.0 * M * (H + H + 3 * H + H) + 4 * H * H * 4)   # attention pair
+        return sum(per) / len(per)
+
+    def nt_bytes(self):
+        H, I = self.H, self.I
+        return sum(2.0 * M * H + 2.0 * I * H + 2 * 2.0 * M * I for M in self.Ms) / len(self.Ms)
+
+
+def _time_launches(fn, reps):
+    fn()
     torch.cuda.synchronize()
-    reps, n = 6, 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    n, flops = 0, 0.0
+    e0.record()  # the kernels are launched on torch's current stream: the events see them
     for _ in range(reps):
-        for x, (u, a) in zip(xs, outs):
-            hip.gemm_nt(x, w, hip.EPI_BIAS_GELU, bias=bias, out=u, out1=a)
-            n += 1
+        k, f = fn()
+        n += k
+        flops += f
     e1.record()
     torch.cuda.synchronize()
-    avg_ms = e0.elapsed_time(e1) / n
-    mean_m = B * sum(Ls) / len(Ls)
-    flops = 2.0 * mean_m * I * H
-    ach = flops / (avg_ms * 1e-3) / 1e12
-    # HBM bytes per launch from the PMC passes committed under profiles/r01_pmc_hbm_traffic.csv
-    # (FETCH_SIZE 153.0 MB + WRITE_SIZE 393.2 MB at M = 32000; scaled to the mean M of the launch
-    # mix; algorithmic bytes: x 49.2 MB + W 4.7 MB read, u and gelu(u) 2 x 196.6 MB written)
-    traffic = (153.0e6 + 393.2e6) * mean_m / 32000.0
-    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI_BIAS_GELU> (M=B*L, N=3072, K=768)", achieved=round(ach, 1),
-                peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                avg_launch_us=round(avg_ms * 1e3, 1), traffic=round(traffic),
-                traffic_source="rocprofv3 PMC passes of tools/prof_gemm.py, profiles/r01_pmc_hbm_traffic.csv")
+    ms = e0.elapsed_time(e1)
+    return ms / n, flops / n
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_dominant_traffic.json, made
+    by tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def kernel_roofline(dev, dims, cfg):
+    """Dominant kernel by total time = gemm_tn_kernel (grouped weight gradients, 36 launches/step).
+    achieved = algorithmic FLOPs per launch / mean launch duration of the step's launch mix, timed
+    with HIP events on the launch stream; the FFN1 forward GEMM (second by time) rides along."""
+    mix = DominantMix(dev, dims, cfg)
+    tn_ms, tn_flops = _time_launches(mix.run_tn, 4)
+    nt_ms, nt_flops = _time_launches(mix.run_nt, 4)
+    tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
+    nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
+    t_tn, t_nt = _pmc_traffic("gemm_tn_kernel"), _pmc_traffic("gemm_nt_kernel<EPI_BIAS_GELU>")
+    return dict(bound="mfma", kernel="gemm_tn_kernel<32,1,3> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and "
+                                     "attention pair per layer; M = 19200 / 17920 / 64000)",
+                achieved=round(tn_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
+                flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
+                traffic=(t_tn or {}).get("bytes_per_launch"),
+                traffic_source="profiles/r01_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                               "tools/prof_dominant.py; FETCH_SIZE doubled for the 16-B/lane streaming reads, gfx950 rule)",
+                second_kernel=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu and gelu')",
+                                   achieved=round(nt_ach, 1), frac=round(nt_ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                   avg_launch_us=round(nt_ms * 1e3, 1), algorithmic_bytes_per_launch=round(mix.nt_bytes()),
+                                   traffic=(t_nt or {}).get("bytes_per_launch")))
 
 
 def main():

@@ -74,6 +74,7 @@ struct GemmNtArgs {
   int vec_bias_ok;  // 16-byte loads allowed on bias
   int delay_cycles;  // experiment (MVPTR_GEMM_DELAY): start delay of the second resident workgroups
   int delay_lo, delay_hi;
+  int exp_flags;  // experiments (MVPTR_NT_EXP): bit 0 = persistent kernel without next-tile prefetch
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
 };
 
@@ -657,10 +658,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNtArgs p) {
     __syncthreads();  // every wave is done with the operand ring
     int m1 = 0, n1 = 0;
     const bool more = tile_origin(round + 1, m1, n1);
+    const bool pf = more && !(p.exp_flags & 1);
     __amdgpu_buffer_rsrc_t rsA1 = rsA, rsB1 = rsB;
     if (more) {
       rsA1 = rsrc_a(m1);
       rsB1 = rsrc_b(n1);
+    }
+    if (pf) {
       stage(rsA1, rsB1, 0, 0);
       if (nk > 1) stage(rsA1, rsB1, 1, BK);
     }
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNtArgs p) {
     n0 = n1;
     rsA = rsA1;
     rsB = rsB1;
-    prefetched = true;
+    prefetched = pf;
   }
 }
 
@@ -783,6 +787,11 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.drop = make_dropdev(drop);
   a.stamps = nullptr;
   a.delay_cycles = 0;
+  a.exp_flags = 0;
+  {
+    const char* xp = getenv("MVPTR_NT_EXP");
+    if (xp != nullptr) a.exp_flags = atoi(xp);
+  }
   a.delay_lo = 256;
   a.delay_hi = 512;
   {

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Replay of the dominant kernel's per-step launch mix for rocprofv3 passes: the grouped
+weight-gradient launches (gemm_tn_kernel) of the encoder layers — FFN pair (dW_out, dW_i) and
+attention pair (dW_o, dW_qkv + b_qkv) at the three row counts of a configs[1] step — plus the
+second kernel by time (FFN1 forward GEMM with the GELU epilogue).  bench.py times the same mix."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+dims = dict(B=256, T=70, P=5, G=20, R=50)
+mix = bench.DominantMix(dev, dims, bench.BASE_CFG)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
+    mix.run_tn()
+    mix.run_nt()
+torch.cuda.synchronize()
+print("done")
