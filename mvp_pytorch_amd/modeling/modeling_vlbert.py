@@ -269,6 +269,50 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         return self._globals(txt, vis)
 
 
+    # -- two-stage retrieval with cached uni-modal outputs ------------------------
+    # The reference's evaluation (run_retrieval.py:694-826) re-runs txt_encoder and vis_encoder for
+    # every (caption, image) pair of the re-ranking stage; their outputs only depend on the caption
+    # or on the image, so they are computed once here and the pair stage runs mul_encoder alone
+    # (9.1 of the 20.9 GFLOP per pair at the README's retrieval shapes).  Same kernels on the same
+    # rows: the scores equal forward(..., encode_hn=False) on the materialised pairs.
+    @torch.no_grad()
+    def encode_text(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, position_ids_a=None):
+        """-> dict(seq bf16 [N, La, H], mask additive f32 [N, La], glob f32 [N, H] unit norm)."""
+        if attention_mask_a is None:
+            attention_mask_a = torch.ones_like(input_ids_a)
+        if token_type_ids_a is None:
+            token_type_ids_a = torch.zeros_like(input_ids_a)
+        mask_a = additive_mask(attention_mask_a)
+        xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
+        txt = self.txt_encoder(xa, mask_a)[0]
+        glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
+        return dict(seq=txt, mask=mask_a, glob=glob)
+
+    @torch.no_grad()
+    def encode_image(self, input_ids_b, img_feats, token_type_ids_b=None, attention_mask_b=None, position_ids_b=None,
+                     max_tag_length=20, use_b=False):
+        """-> dict(seq bf16 [N, R', H] (tag rows cut as in vl:516-519), mask [N, R'], glob f32 [N, H])."""
+        if attention_mask_b is None:
+            attention_mask_b = torch.ones((input_ids_b.shape[0], input_ids_b.shape[1] + img_feats.shape[1]),
+                                          dtype=torch.long, device=input_ids_b.device)
+        if token_type_ids_b is None:
+            token_type_ids_b = torch.zeros_like(input_ids_b)
+        mask_b = additive_mask(attention_mask_b)
+        xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self)
+        vis = self.vis_encoder(xb, mask_b)[0]
+        cut = 1 if use_b else max_tag_length
+        glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj, p=2, dim=-1)
+        return dict(seq=vis[:, cut:, :].contiguous(), mask=mask_b[:, cut:].contiguous(), glob=glob)
+
+    @torch.no_grad()
+    def fuse_pairs(self, text, image, txt_idx, img_idx):
+        """mul_encoder + pooler on the pairs (text[txt_idx[i]], image[img_idx[i]]) -> (seq, pooled)."""
+        joint = torch.cat([text["seq"].index_select(0, txt_idx), image["seq"].index_select(0, img_idx)], dim=1)
+        mask = torch.cat([text["mask"].index_select(0, txt_idx), image["mask"].index_select(0, img_idx)], dim=-1)
+        seq = self.mul_encoder(joint, mask)[0]
+        return seq, self.pooler(seq)
+
+
 # ------------------------------------------------------------------------------------------ heads
 class BertPreTrainingHeads(nn.Module):
     """vl:970-980."""
@@ -591,6 +635,29 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
     def forward_fine(self, **kw):
         outputs, _, _ = self.bert(encode_hn=False, **_bi_kwargs(kw))
         return self.classifier(outputs[1])
+
+    # cached two-stage evaluation (SURVEY §8 f4): encode every caption / image once, then score pairs
+    def encode_text(self, **kw):
+        return self.bert.encode_text(**kw)
+
+    def encode_image(self, **kw):
+        return self.bert.encode_image(**kw)
+
+    @torch.no_grad()
+    def coarse_scores(self, text, image):
+        """[n_text, n_image] cosine similarities of the global embeddings (forward_mod 'coarse' +
+        the matrix product of run_retrieval.py:741-745)."""
+        return text["glob"] @ image["glob"].t()
+
+    @torch.no_grad()
+    def rerank(self, text, image, txt_idx, img_idx, chunk=4096):
+        """ITM logits [n_pairs, num_labels] of forward_mod 'fine' for the listed pairs, computed from
+        the cached uni-modal outputs."""
+        out = []
+        for s0 in range(0, txt_idx.numel(), chunk):
+            _, pooled = self.bert.fuse_pairs(text, image, txt_idx[s0:s0 + chunk], img_idx[s0:s0 + chunk])
+            out.append(self.classifier(pooled))
+        return torch.cat(out, 0)
 
 
 def _cls_loss(self, logits, labels, soft_label):

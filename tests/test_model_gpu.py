@@ -227,6 +227,41 @@ def test_finetune_parity(dev):
     assert _rel(o[1], torch.from_numpy(d["ve_logits"])) < 2e-2
 
 
+def test_retrieval_cached_rerank_equals_fine(dev):
+    """Two-stage retrieval with cached uni-modal outputs: every (caption, image) pair
+    of a small cross product scores exactly as forward_mod='fine' on the materialised pair batch, the
+    golden 'fine' logits are reproduced on the matched pairs, and the coarse similarity matrix equals
+    forward_mod='coarse'."""
+    d = gu.load("tiny_finetune")
+    cfg, dims, seed = d["config"], d["dims"], int(d["seed"])
+    kw = _bi_inputs(d, dev)
+    model, _ = _build("BiImageBertForRetrieval", dict(cfg, loss_type="ce", num_labels=2), seed + 1, dev)
+    n = kw["input_ids_a"].shape[0]
+    text = model.encode_text(input_ids_a=kw["input_ids_a"], token_type_ids_a=kw["token_type_ids_a"],
+                             attention_mask_a=kw["attention_mask_a"])
+    image = model.encode_image(input_ids_b=kw["input_ids_b"], img_feats=kw["img_feats"],
+                               token_type_ids_b=kw["token_type_ids_b"], attention_mask_b=kw["attention_mask_b"],
+                               max_tag_length=dims["G"])
+    ti, ii = torch.meshgrid(torch.arange(n, device=dev), torch.arange(n, device=dev), indexing="ij")
+    ti, ii = ti.reshape(-1), ii.reshape(-1)
+    got = model.rerank(text, image, ti, ii, chunk=5)            # ragged chunks on purpose
+    model.forward_mod = "fine"
+    pair_kw = {k: v.index_select(0, ti if k.endswith("_a") else ii) for k, v in kw.items()}
+    with torch.no_grad():
+        ref = model(max_tag_length=dims["G"], **pair_kw)
+    print("cached rerank vs fine: max abs diff", (got - ref).abs().max().item())
+    assert torch.equal(got, ref)
+    diag = torch.arange(n, device=dev) * (n + 1)
+    assert _rel(got.index_select(0, diag), torch.from_numpy(d["ret_fine_logits"])) < 2e-2
+    model.forward_mod = "coarse"
+    with torch.no_grad():
+        gt, gi = model(max_tag_length=dims["G"], **kw)
+    assert torch.equal(model.coarse_scores(text, image), gt @ gi.t())
+    # ranking of the images per caption from the cached scores == ranking from the pair-wise scores
+    p_match = torch.softmax(got.float(), -1)[:, 1].view(n, n)
+    assert torch.equal(p_match.argsort(1, descending=True), torch.softmax(ref.float(), -1)[:, 1].view(n, n).argsort(1, descending=True))
+
+
 def test_bi_pretrain_parity_b64_vs_oracle(dev):
     """BERT-base, BASELINE configs[0] lengths but 64 pairs: every loss within 1e-3 of the oracle
     (the oracle itself is pinned to the reference by tests/test_oracle_golden.py)."""
