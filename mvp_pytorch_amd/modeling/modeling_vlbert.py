@@ -402,16 +402,17 @@ def _segment_top3_mean(sims, row_owner, col_start, col_count, picks, n):
     return sums / cnt.clamp(min=1.0)
 
 
-def get_pos_neg_sims(sims, text_index, img_index):
+def get_pos_neg_sims(sims, text_index, img_index, draws=None):
     """vl:1553-1596, vectorised: per sample the mean top-3-pick similarity of its phrases against
-    its own regions (pos) and against one randomly chosen other image (neg)."""
+    its own regions (pos) and against one randomly chosen other image (neg).  draws: optional
+    (pos_pick, neg_pick, neg_img) in the stacked-phrase order instead of fresh host draws."""
     dev = sims.device
     n = text_index.shape[0]
     _, owner, _, tcounts = _flat_rows(text_index, 1 << 20)
     _, _, istarts, icounts = _flat_rows(img_index, 1 << 20)
     if any(c < 3 for c in icounts) and len(owner):
         raise RuntimeError("selected index k out of range: every image needs >= 3 valid regions (topk(3), vl:1547)")
-    pos_pick, neg_pick, neg_img = _draw_top3_picks(tcounts)
+    pos_pick, neg_pick, neg_img = _draw_top3_picks(tcounts) if draws is None else draws
     owner_t = torch.tensor(owner, dtype=torch.long, device=dev)
     istarts_t = torch.tensor(istarts, dtype=torch.long, device=dev)
     icounts_t = torch.tensor(icounts, dtype=torch.long, device=dev)
@@ -419,6 +420,46 @@ def get_pos_neg_sims(sims, text_index, img_index):
     pos = _segment_top3_mean(sims, owner_t, istarts_t[owner_t], icounts_t[owner_t], pos_pick, n)
     nj = neg_t[owner_t]
     neg = _segment_top3_mean(sims, owner_t, istarts_t[nj], icounts_t[nj], neg_pick, n)
+    return pos, neg
+
+
+def wra_sample_on_device(seq32, phrase_index, img_index, text_len, draws=None):
+    """The phrase_mod='sample' branch of vl:1285-1300 + get_pos_neg_sims (vl:1553-1596) with every
+    shape fixed by the tensor shapes — no `.tolist()`, no host loops, no device->host copy: the
+    host version costs ~2 ms of Python per 256-pair step during which the GPU queue runs dry.
+    Phrase rows are the text rows [p0, p1) (all `text_len` text rows are scored and the others
+    masked), region rows the `Lj - text_len` rows from i0.  The random draws (one of the top-3
+    regions per phrase, vl:1547-1549; one other image per sample, vl:1572-1573) come from the device
+    generator: same distributions as the reference, different stream.  draws: optional
+    (pos_pick [B, text_len], neg_pick [B, text_len], neg_img [B]) for tests.
+    -> pos_sims [B], neg_sims [B] (0 where a sample has no phrase, as the reference)."""
+    B, Lj, H = seq32.shape
+    dev = seq32.device
+    Rw = Lj - text_len
+    p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
+    ar_t = torch.arange(text_len, device=dev)
+    valid_p = (ar_t[None, :] >= p0[:, None]) & (ar_t[None, :] < p1[:, None])            # [B, La]
+    ar_r = torch.arange(Rw, device=dev)
+    rows_r = (i0[:, None] + ar_r[None, :]).clamp(max=Lj - 1)                              # [B, Rw]
+    valid_r = ar_r[None, :] < (i1 - i0)[:, None]
+    txt_n = F.normalize(seq32[:, :text_len, :], p=2, dim=-1)
+    reg_n = F.normalize(seq32.gather(1, rows_r[:, :, None].expand(-1, -1, H)), p=2, dim=-1)
+    if draws is None:
+        pos_pick = torch.randint(0, 3, (B, text_len), device=dev)
+        neg_pick = torch.randint(0, 3, (B, text_len), device=dev)
+        neg_img = (torch.arange(B, device=dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
+    else:
+        pos_pick, neg_pick, neg_img = (d.to(dev) for d in draws)
+    cnt = valid_p.sum(1).clamp(min=1).to(seq32.dtype)
+
+    def mean_top3(regions, rvalid, pick):
+        sims = torch.bmm(txt_n, regions.transpose(1, 2)).masked_fill(~rvalid[:, None, :], float("-inf"))
+        top = sims.topk(3, dim=2)[0]                                                      # [B, La, 3]
+        picked = top.gather(2, pick[:, :, None]).squeeze(2)
+        return torch.where(valid_p, picked, torch.zeros_like(picked)).sum(1) / cnt
+
+    pos = mean_top3(reg_n, valid_r, pos_pick)
+    neg = mean_top3(reg_n.index_select(0, neg_img), valid_r.index_select(0, neg_img), neg_pick)
     return pos, neg
 
 
@@ -495,6 +536,9 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         self.num_seq_relations = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
         self.max_text_seq_length = config.max_text_seq_length if hasattr(config, "max_text_seq_length") else None
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        # WRA random draws on the device (no host round trip); False = host draws in the reference's
+        # order, which the parity tests replay from the golden fixtures
+        self.wra_on_device = True
         self.apply(self.init_weights)
         self.tie_weights()
 
@@ -547,13 +591,18 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 valid = ((phrase_index[:, 1] - phrase_index[:, 0]) > 0) & ((hard_phrase_index[:, 1] - hard_phrase_index[:, 0]) > 0)
             elif phrase_mod == "sample":
                 seq32 = sequence_output.float()
-                valid_phrases = F.normalize(mask_slice_and_stack(seq32, phrase_index), p=2, dim=-1)
-                valid_images = F.normalize(mask_slice_and_stack(seq32, img_index), p=2, dim=-1)
-                pos_sims, neg_sims = get_pos_neg_sims(valid_phrases @ valid_images.t(), phrase_index, img_index)
+                if self.wra_on_device:
+                    pos_sims, neg_sims = wra_sample_on_device(seq32, phrase_index, img_index, input_ids_a.shape[1])
+                else:  # host draws in the reference's order (replayable: parity tests)
+                    valid_phrases = F.normalize(mask_slice_and_stack(seq32, phrase_index), p=2, dim=-1)
+                    valid_images = F.normalize(mask_slice_and_stack(seq32, img_index), p=2, dim=-1)
+                    pos_sims, neg_sims = get_pos_neg_sims(valid_phrases @ valid_images.t(), phrase_index, img_index)
                 valid = (phrase_index[:, 1] - phrase_index[:, 0]) > 0
             else:
                 raise NotImplementedError
-            wra_loss = torch.mean(torch.masked_select(torch.clamp(neg_sims + 0.2 - pos_sims, min=0), valid))
+            hinge = torch.clamp(neg_sims + 0.2 - pos_sims, min=0)
+            # mean over the samples that have phrases (vl:1298-1300) without a data-dependent shape
+            wra_loss = torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype)
             total_loss = total_loss + wra_loss
             return (total_loss,) + outs + (wra_loss,)
         return (total_loss,) + outs

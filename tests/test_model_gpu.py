@@ -81,6 +81,8 @@ def _build(cls_name, cfg, seed, dev, train=False):
     model.load_state_dict(sd)
     model.to(dev)
     model.train(train)
+    if hasattr(model, "wra_on_device"):
+        model.wra_on_device = False  # parity runs replay the reference's host draws
     return model, sd
 
 
@@ -225,6 +227,40 @@ def test_finetune_parity(dev):
     o = model(labels=torch.from_numpy(d["ve_labels"]).to(dev), **kw)
     assert abs(o[0].item() - float(d["ve_loss"])) / float(d["ve_loss"]) < LOSS_RTOL
     assert _rel(o[1], torch.from_numpy(d["ve_logits"])) < 2e-2
+
+
+def test_wra_device_path_equals_host_path(dev):
+    """wra_sample_on_device (fixed shapes, no host round trip) against the host-index version of
+    vl:1553-1596 with the same draws, forward and gradient; includes samples without phrases."""
+    from mvp_pytorch_amd.modeling import modeling_vlbert as mv
+    g = torch.Generator().manual_seed(21)
+    B, La, R, H = 9, 14, 11, 64
+    Lj = La + R
+    seq = torch.randn(B, Lj, H, generator=g)
+    n_t = torch.randint(2, La - 6, (B,), generator=g)
+    n_p = torch.randint(0, 5, (B,), generator=g)
+    n_p[0] = 0                                      # a sample without phrases
+    phrase_index = torch.stack([1 + n_t, 1 + n_t + n_p], 1)
+    n_r = torch.randint(3, R + 1, (B,), generator=g)
+    img_index = torch.stack([torch.full((B,), La), La + n_r], 1)
+    pos_grid = torch.randint(0, 3, (B, La), generator=g)
+    neg_grid = torch.randint(0, 3, (B, La), generator=g)
+    neg_img = (torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B
+    assert (neg_img != torch.arange(B)).all()
+    flat = lambda grid: torch.cat([grid[t, phrase_index[t, 0]:phrase_index[t, 1]] for t in range(B)])  # noqa: E731
+    a = seq.to(dev).requires_grad_(True)
+    pos_d, neg_d = mv.wra_sample_on_device(a, phrase_index.to(dev), img_index.to(dev), La, draws=(pos_grid, neg_grid, neg_img))
+    b = seq.to(dev).requires_grad_(True)
+    vp = torch.nn.functional.normalize(mv.mask_slice_and_stack(b, phrase_index.to(dev)), p=2, dim=-1)
+    vi = torch.nn.functional.normalize(mv.mask_slice_and_stack(b, img_index.to(dev)), p=2, dim=-1)
+    pos_h, neg_h = mv.get_pos_neg_sims(vp @ vi.t(), phrase_index.to(dev), img_index.to(dev),
+                                       draws=(flat(pos_grid), flat(neg_grid), neg_img.tolist()))
+    assert torch.allclose(pos_d, pos_h, atol=1e-5) and torch.allclose(neg_d, neg_h, atol=1e-5)
+    assert pos_d[0] == 0 and neg_d[0] == 0
+    w = torch.randn(B, generator=g).to(dev)
+    ((pos_d - neg_d) * w).sum().backward()
+    ((pos_h - neg_h) * w).sum().backward()
+    assert _rel(a.grad, b.grad) < 1e-5
 
 
 def test_retrieval_cached_rerank_equals_fine(dev):
