@@ -18,8 +18,11 @@ Design
     all-reduce of S bytes costs ~2*(7/8)*S / link rate, ~11 ms for the 0.98 GB of f32 gradients of
     BiBertImgForPreTraining if not overlapped);
   * parameters that produced no gradient in the previous step (qa_head when qa_ans is None,
-    modeling_vlbert.py:1184) are not waited for; finish() reduces whatever is left, so every rank
-    always issues the same collectives in the same order.
+    modeling_vlbert.py:1184) are not waited for;
+  * buckets are launched strictly in index order (a ready bucket waits for its predecessors, as
+    DDP does): which parameters receive a gradient can differ between ranks (a shard without a
+    masked tag row skips half_mlm), and collectives on one communicator must be issued in the
+    same order everywhere; finish() launches whatever is left, again in index order.
 """
 import torch
 import torch.distributed as dist
@@ -78,6 +81,7 @@ class GradSync:
             b["pending"] = n_exp
         self._ready = set()
         self._launched = []
+        self._next = 0            # buckets [0, _next) have been launched this step
 
     def _hook(self, p):
         if self.world == 1:
@@ -92,10 +96,17 @@ class GradSync:
         if p in self._ready:
             return
         self._ready.add(p)
+        if idx < self._next:
+            # its bucket is already being reduced in place: the parameter never produced a gradient
+            # before, so nobody was waiting for it.  Failing loudly beats a silently unsynchronised
+            # gradient; construct GradSync(..., overlap=False) for models whose set of used
+            # parameters grows during training.
+            raise RuntimeError("GradSync: a parameter produced its first gradient after its bucket was launched")
         if self._expected is None or p in self._expected:
             b["pending"] -= 1
-            if self.overlap and b["pending"] == 0 and b["work"] is None:
-                self._launch(idx)
+            if self.overlap:
+                while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+                    self._launch(self._next)
 
     def _span(self, p):
         for q, off, n in self.buckets[self.where[p]]["items"]:
@@ -109,31 +120,36 @@ class GradSync:
     def _launch(self, idx):
         b = self.buckets[idx]
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        assert idx == self._next, "buckets are launched in index order"
         b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._launched.append(idx)
+        self._next = idx + 1
 
     def __call__(self):
         """Finish the step's exchange: launch the buckets that are still waiting (in index order on
         every rank), wait for all of them, scale if the backend summed."""
         if self.world == 1:
             return
-        if self._expected is not None:
-            # a parameter expected to arrive did not (or an unexpected one did): buckets whose
-            # launch decision could differ between ranks are exactly the not-yet-launched ones,
-            # and those are launched here in a fixed order on every rank
-            pass
-        for idx, b in enumerate(self.buckets):
-            if b["work"] is None:
-                self._launch(idx)
+        for idx in range(self._next, len(self.buckets)):
+            self._launch(idx)
+        # which parameters produced a gradient on ANY rank (DDP's used-parameter bitmap): those keep
+        # the averaged gradient on every rank, the others keep grad = None everywhere, so replicas
+        # apply identical updates even when a shard skipped a head
+        dev = self.buckets[0]["flat"].device
+        used = torch.tensor([1 if p in self._ready else 0 for p in self.params], dtype=torch.int32).to(dev)
+        used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             b["work"].wait()
             if not self._avg:
                 b["flat"].mul_(1.0 / self.world)
-        self._expected = set(self._ready)
+        # wait for every parameter that has EVER produced a gradient on this rank: one that is missing
+        # in some step only delays launches to finish(), it cannot reorder them
+        self._expected = set(self._ready) if self._expected is None else (self._expected | self._ready)
         # parameters no rank produced a gradient for keep grad = None, as under DDP with
         # find_unused_parameters=True (run_pretrain_ml.py:415-418): the optimizer skips them
-        for p in self.params:
-            if p not in self._ready:
+        used_work.wait()
+        for p, u in zip(self.params, used.tolist()):
+            if not u:
                 p.grad = None
 
 

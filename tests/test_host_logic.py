@@ -183,22 +183,33 @@ def _dp_worker(rank, world, port, q):
     m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
     unused = torch.nn.Linear(3, 3)  # never touched by the loss (like qa_head, modeling_vlbert.py:1184)
     m.add_module("unused", unused)
+    # a head that every rank uses at first and that rank 1 skips in the last step (a shard without
+    # masked tag rows skips half_mlm): launch ORDER must stay identical on both ranks
+    sometimes = torch.nn.Linear(2, 2)
+    m.add_module("sometimes", sometimes)
     sync = dp.GradSync(m, bucket_mb=0.0002)  # tiny buckets -> several collectives, launched from hooks
     assert len(sync.buckets) > 2
     results = []
-    for step in range(3):
-        g = torch.Generator().manual_seed(100 * step + rank)
-        x = torch.randn(5, 8, generator=g)
+    used = [p for n, p in m.named_parameters() if not n.startswith("unused")]
+
+    def loss_fn(x, with_head):
         out = m[3](m[2](m[1](m[0](x))))
         # the same sub-module used twice in one graph (mul_encoder runs on the joint and the hard batch)
         loss = (out ** 2).sum() + m[3](m[2](torch.tanh(m[0](x * 0.5)))).sum()
-        loss.backward()
+        if with_head:
+            loss = loss + sometimes(out).pow(2).sum()
+        return loss
+
+    for step in range(4):
+        g = torch.Generator().manual_seed(100 * step + rank)
+        x = torch.randn(5, 8, generator=g)
+        with_head = not (step == 3 and rank == 1)
+        loss_fn(x, with_head).backward()
         sync()
         results.append([None if p.grad is None else p.grad.detach().clone().numpy() for p in m.parameters()])
         # reference: gradient of the same loss computed locally, to be averaged by the parent
-        ref = torch.autograd.grad((m[3](m[2](m[1](m[0](x)))) ** 2).sum() + m[3](m[2](torch.tanh(m[0](x * 0.5)))).sum(),
-                                  [p for n, p in m.named_parameters() if not n.startswith("unused")])
-        results[-1].append([r.numpy() for r in ref])
+        ref = torch.autograd.grad(loss_fn(x, with_head), used, allow_unused=True)
+        results[-1].append([np.zeros(tuple(p.shape), dtype=np.float32) if r is None else r.numpy() for r, p in zip(ref, used)])
         sync.zero_grad()
     vals = dp.all_reduce_metrics([float(rank + 1), 2.0, 3.0], torch.device("cpu"))
     q.put((rank, results, vals))
@@ -220,18 +231,24 @@ def test_grad_sync_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, r0, v0), (_, r1, v1) = res
-    for step in range(3):
+    names = [n for n, _ in torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2),
+                                              ).named_parameters()] + ["unused.weight", "unused.bias", "sometimes.weight", "sometimes.bias"]
+    used_idx = [i for i, n in enumerate(names) if not n.startswith("unused")]
+    for step in range(4):
         g0, g1 = r0[step], r1[step]
         local0, local1 = g0[-1], g1[-1]
-        used = [a for a in g0[:-1]][:len(local0)]
-        for i, (a, b) in enumerate(zip(local0, local1)):
-            want = (a + b) / 2
-            assert np.allclose(g0[i], want, atol=1e-5), (step, i)
-            assert np.allclose(g1[i], want, atol=1e-5), (step, i)
+        for j, i in enumerate(used_idx):
+            want = (local0[j] + local1[j]) / 2
+            # a head one rank's shard skipped still gets the averaged gradient on BOTH ranks (the
+            # skipping rank contributes zeros), so the replicas apply identical updates
+            assert g0[i] is not None and g1[i] is not None, (step, names[i])
+            assert np.allclose(g0[i], want, atol=1e-5), (step, names[i])
+            assert np.allclose(g1[i], want, atol=1e-5), (step, names[i])
         # unused params: no gradient (None, as under DDP find_unused_parameters) or zeros
-        for extra0, extra1 in zip(g0[len(local0):-1], g1[len(local1):-1]):
-            assert extra0 is None or np.all(extra0 == 0)
-            assert extra1 is None or np.all(extra1 == 0)
+        for i, n in enumerate(names):
+            if n.startswith("unused"):
+                assert g0[i] is None or np.all(g0[i] == 0)
+                assert g1[i] is None or np.all(g1[i] == 0)
     assert v0 == v1 == [3.0, 4.0, 6.0]
 
 
