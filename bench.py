@@ -280,6 +280,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        fence()  # rank 0 is still timing the dominant-kernel replay: leave the group together
         torch.distributed.destroy_process_group()
 
 
