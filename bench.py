@@ -213,12 +213,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP encoder has no CPU fallback")
+    # test-only knobs to exercise the N > 1 path on a one-GPU box: every rank on one device, gloo
+    # instead of RCCL (which refuses two ranks on one GPU)
+    if "MVPTR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MVPTR_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MVPTR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mvp_pytorch_amd import dp, hip, modeling, train
     from mvp_pytorch_amd.synthetic import synthetic_batch
