@@ -52,6 +52,29 @@ def flops_per_pair(dims, cfg, masked_text_rows, masked_tag_rows):
     return fwd, 3 * fwd
 
 
+def flops_executed(batch, dims, cfg, masked_text_rows, masked_tag_rows):
+    """Algorithmic FLOPs of one step on THIS batch when padded slots are not computed (the encoder
+    stacks run row-packed): same formula as flops_per_pair, evaluated per sample on the valid lengths.
+    The hard-negative joint batch pairs each text with another sample's image; it is counted like the
+    matched batch (same texts, a permutation-like choice of images).  Returns (fwd, fwd+bwd) for the
+    whole batch."""
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    nl = cfg["num_hidden_layers"] // 2
+    per_tok = 2 * (4 * H * H + 2 * H * I)
+    la = batch["input_mask_a"].sum(1).double()
+    lb = batch["input_mask_b"].sum(1).double()
+    nr = batch["input_mask_b"][:, dims["G"]:].sum(1).double()
+    lj = la + nr
+
+    def enc(lens):
+        return float((nl * (lens * per_tok + 4 * lens * lens * H)).sum())
+
+    fwd = enc(la) + enc(lb) + 2 * enc(lj)
+    fwd += float(nr.sum()) * 2 * cfg["img_feature_dim"] * H
+    fwd += (masked_text_rows + masked_tag_rows) * (2 * H * H + 2 * H * cfg["only_word_size"])
+    return fwd, 3 * fwd
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Oracle (CPU restatement of the reference, kind='port') timed on this host at
     BASELINE.json configs[0] shapes: B=4, 35 tok (+5 phrase slots), 20 tags, 10 regions."""
@@ -102,13 +125,18 @@ class DominantMix:
     gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward).  Row counts of a configs[1] step: text B*75, visual
     B*70, joint + hard-negative batch 2B*125; six layers each."""
 
-    def __init__(self, dev, dims, cfg):
+    def __init__(self, dev, dims, cfg, batch=None):
         from mvp_pytorch_amd import hip
         self.hip = hip
         H, I = cfg["hidden_size"], cfg["intermediate_size"]
         self.H, self.I = H, I
         B = dims["B"]
-        self.Ms = [B * (dims["T"] + dims["P"]), B * (dims["G"] + dims["R"]), 2 * B * (dims["T"] + dims["P"] + dims["R"])]
+        if batch is None:   # every slot valid
+            self.Ms = [B * (dims["T"] + dims["P"]), B * (dims["G"] + dims["R"]), 2 * B * (dims["T"] + dims["P"] + dims["R"])]
+        else:               # the row-packed encoder passes of this batch: valid rows only
+            na, nb = int(batch["input_mask_a"].sum()), int(batch["input_mask_b"].sum())
+            nr = int(batch["input_mask_b"][:, dims["G"]:].sum())
+            self.Ms = [na, nb, 2 * (na + nr)]
         r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)  # noqa: E731
         self.tn = []
         for M in self.Ms:
@@ -163,29 +191,30 @@ def _time_launches(fn, reps):
     return ms / n, flops / n
 
 
-def _pmc_traffic(kernel):
+def _pmc_traffic(kernel, packed=True):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_dominant_traffic.json, made
     by tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE), or None."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)[kernel]
+            return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
     except (OSError, KeyError, ValueError):
         return None
 
 
-def kernel_roofline(dev, dims, cfg):
+def kernel_roofline(dev, dims, cfg, batch=None):
     """Dominant kernel by total time = gemm_tn_kernel (grouped weight gradients, 36 launches/step).
-    achieved = algorithmic FLOPs per launch / mean launch duration of the step's launch mix, timed
-    with HIP events on the launch stream; the FFN1 forward GEMM (second by time) rides along."""
-    mix = DominantMix(dev, dims, cfg)
+    achieved = algorithmic FLOPs per launch / mean launch duration of the step's launch mix (row
+    counts of the timed batch), timed with HIP events on the launch stream; the FFN1 forward GEMM
+    (second by time) rides along."""
+    mix = DominantMix(dev, dims, cfg, batch)
     tn_ms, tn_flops = _time_launches(mix.run_tn, 4)
     nt_ms, nt_flops = _time_launches(mix.run_nt, 4)
     tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
     nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
-    t_tn, t_nt = _pmc_traffic("gemm_tn_kernel"), _pmc_traffic("gemm_nt_kernel<EPI_BIAS_GELU>")
+    t_tn, t_nt = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>"))
     return dict(bound="mfma", kernel="gemm_tn_kernel<32,1,3> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and "
-                                     "attention pair per layer; M = 19200 / 17920 / 64000)",
+                                     "attention pair per layer; M = %d / %d / %d rows)" % tuple(mix.Ms),
                 achieved=round(tn_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
                 flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
@@ -241,8 +270,8 @@ def main():
     n_text = int((batch["lm_label_ids_a"] > -1).sum().item())
     n_tag = int((batch["lm_label_ids_b"] > -1).sum().item())
 
-    def step():
-        return train.pretrain_step(model, batch, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+    def step(b=None):
+        return train.pretrain_step(model, batch if b is None else b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
 
     for _ in range(args.warmup):
         step()
@@ -265,13 +294,34 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
+    # the same step with every token / region slot valid (nothing to skip), outside the timed region:
+    # reported beside `value` because the encoder stacks run row-packed (padded slots of the
+    # variable-length batch are not computed; results equal the padded execution)
+    full = None
+    if world == 1 and not args.fixed_length:
+        fb_batch = synthetic_batch(dims, BASE_CFG, 1234 + rank, fixed_length=True, device=dev)
+        for _ in range(2):
+            step(fb_batch)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step(fb_batch)
+        fence()
+        full_ms = (time.perf_counter() - t1) / 5 * 1e3
+        full = {"ms_per_step": round(full_ms, 2), "value": round(args.batch / (full_ms * 1e-3), 1),
+                "note": "every one of the 70+5 / 20 / 50 slots valid: nothing to skip"}
+
     if rank == 0:
         fwd, fb = flops_per_pair(dims, BASE_CFG, n_text / args.batch, n_tag / args.batch)
-        step_tflops = fb * args.batch / (ms_per_step * 1e-3) / 1e12
-        roof = kernel_roofline(dev, dims, BASE_CFG)
+        _, fb_exec = flops_executed(batch, dims, BASE_CFG, n_text, n_tag)
+        step_tflops = fb_exec / (ms_per_step * 1e-3) / 1e12
+        roof = kernel_roofline(dev, dims, BASE_CFG, None if args.fixed_length else batch)
         roof["step_achieved"] = round(step_tflops, 1)
         roof["step_frac"] = round(step_tflops / MFMA_BF16_PEAK_TFLOPS, 4)
-        roof["flops_per_pair_fwd_bwd"] = fb
+        roof["flops_per_step_executed"] = fb_exec
+        roof["flops_per_pair_fwd_bwd_full_shape"] = fb
+        valid = {"text": round(float(batch["input_mask_a"].float().mean()), 3),
+                 "tags+regions": round(float(batch["input_mask_b"].float().mean()), 3)}
         out = {
             "metric": "image-text pairs/s (pre-train step, BERT-base, 70tok+50region)",
             "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
@@ -281,7 +331,11 @@ def main():
                                    "70 tok + 5 phrase slots, 20 tag slots, 50 regions x 2054-d, MLM+MCP+ITM+contrastive+WRA, "
                                    "dropout 0.1, AdamW, bf16 MFMA / f32 master weights" % args.batch,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "final_loss": round(float(loss.item()), 4)},
+                       "final_loss": round(float(loss.item()), 4),
+                       "lengths": "fixed (all slots valid)" if args.fixed_length else
+                                  "variable (SURVEY 8d: tokens U{8..68}, phrases U{0..5}, tags U{3..18}, regions U{10..50})",
+                       "valid_slot_fraction": valid, "padded_slots_computed": False,
+                       "all_slots_valid": full},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -40,7 +40,7 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 1
+#define MVPTR_ABI_VERSION 2
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
@@ -130,6 +130,22 @@ int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float
 int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
                         const void* dctx, const float* lse, void* dqkv, int B, int L, int heads,
                         const mvptr_dropout* drop, void* stream);
+
+/* Row-packed ("unpadded") form of the two calls above: the reference runs every padded slot of
+ * every sequence through the encoder (modeling_vlbert.py:430-460 only masks them as keys); here the
+ * valid rows of all sequences are packed back to back and sequence b occupies rows
+ * [seq_start[b], seq_start[b] + seq_len[b]) of qkv / ctx / dctx / dqkv (device int32 arrays).
+ * L is the MAXIMUM length (LDS tile size, lse stride: lse stays f32 [B, heads, L]); mask_add may be
+ * NULL (all packed rows are valid keys) or f32 [total_rows].  seq_start == seq_len == NULL is the
+ * dense layout.  Results equal the dense call on the valid rows: a key masked with -10000
+ * contributes exp(-10000 + ...) = 0 in f32 either way. */
+int mvptr_attention_fwd_packed(const void* qkv, const float* mask_add, void* ctx, float* lse,
+                               const int* seq_start, const int* seq_len, int B, int L, int heads,
+                               const mvptr_dropout* drop, void* stream);
+int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add, const void* ctx,
+                               const void* dctx, const float* lse, void* dqkv, const int* seq_start,
+                               const int* seq_len, int B, int L, int heads,
+                               const mvptr_dropout* drop, void* stream);
 
 /* y = LayerNorm(z) * gamma + beta (TF style, eps inside sqrt), optional dropout on y.
  * Replaces BertLayerNorm.forward modeling_bert.py:242-246 (+ nn.Dropout where the reference
@@ -250,6 +266,13 @@ typedef struct {
   uint32_t p_hidden16; /* dropout threshold (p*65536) for dense outputs        */
   uint32_t p_attn16;   /* dropout threshold for attention probabilities        */
   uint64_t seed;       /* per-layer-call seed                                  */
+  /* row-packed mode (see mvptr_attention_fwd_packed): M > 0 rows in total instead of B*L, sequence b
+   * at rows [seq_start[b], +seq_len[b]); L = maximum length; mask_add may then be NULL.
+   * M == 0 / NULL arrays: dense [B, L] layout. */
+  int M;
+  int pad_;
+  const int* seq_start;
+  const int* seq_len;
 } mvptr_layer_desc;
 
 typedef struct {

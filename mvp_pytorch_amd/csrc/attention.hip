@@ -26,7 +26,9 @@ struct AttnArgs {
   const __bf16* dctx; // bwd
   float* lse;         // fwd: out (may be null) ; bwd: in
   __bf16* dqkv;       // bwd out
-  int B, L, heads, Lp;
+  int B, L, heads, Lp;      // L / Lp: (maximum) sequence length and its multiple-of-32 tile rows
+  const int* seq_start;     // packed mode: first row of sequence b in the row-packed buffers
+  const int* seq_len;       //              its length (<= L); NULL => dense [B, L] layout
   DropDev drop;
 };
 
@@ -121,18 +123,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int L = p.L, Lp = p.Lp, H = p.heads * 64;
+  // LT / LpT: table strides (lse, dropout index, LDS tile placement); L / Lp: this sequence
+  const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
+  if (L <= 0) return;
+  const int64_t row0 = (p.seq_start != nullptr) ? (int64_t)p.seq_start[b] : (int64_t)b * LT;
+  const int Lp = (L + 31) & ~31;
   const int64_t ldq = 3 * (int64_t)H;
   char* tQ = smem;
-  char* tK = tQ + Lp * 128;
-  char* tV = tK + Lp * 128;
-  float* maskv = reinterpret_cast<float*>(tV + Lp * 128);
+  char* tK = tQ + LpT * 128;
+  char* tV = tK + LpT * 128;
+  float* maskv = reinterpret_cast<float*>(tV + LpT * 128);
 
-  const __bf16* base = p.qkv + (int64_t)b * L * ldq + hd * 64;
+  const __bf16* base = p.qkv + row0 * ldq + hd * 64;
   stage_tile(tQ, base, ldq, L, Lp, wave, lane);
   stage_tile(tK, base + H, ldq, L, Lp, wave, lane);
   stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
-  for (int i = tid; i < Lp; i += 256) maskv[i] = (i < L) ? p.mask[(int64_t)b * L + i] : -INFINITY;
+  for (int i = tid; i < Lp; i += 256)
+    maskv[i] = (i < L) ? (p.mask != nullptr ? p.mask[row0 + i] : 0.f) : -INFINITY;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
     const float lse = m_run + __logf(l_run);
     const int q = 32 * qb + l31;
-    if (p.lse != nullptr && hh == 0 && q < L) p.lse[(int64_t)bh * L + q] = lse;
+    if (p.lse != nullptr && hh == 0 && q < L) p.lse[(int64_t)bh * LT + q] = lse;
 
     // pass 2: P^T = exp(S^T - lse) (dropout), O^T += V^T · P^T
     f32x16 o[2] = {zero16(), zero16()};
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = __expf(st[r] * 0.125f + mk[r] - lse);
       if (p.drop.thresh16 != 0) {
-        const uint64_t rowbase = ((uint64_t)bh * L + q) * (uint64_t)Lp + 32 * kb + 4 * hh;
+        const uint64_t rowbase = ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {  // registers r, r+1 hold adjacent keys (even, odd)
           float a0 = st[r], a1 = st[r + 1];
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       }
     }
     if (q < L) {
-      __bf16* dst = p.ctx + ((int64_t)b * L + q) * H + hd * 64;
+      __bf16* dst = p.ctx + (row0 + q) * H + hd * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -222,19 +230,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int L = p.L, Lp = p.Lp, H = p.heads * 64;
+  const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
+  if (L <= 0) return;
+  const int64_t row0 = (p.seq_start != nullptr) ? (int64_t)p.seq_start[b] : (int64_t)b * LT;
+  const int Lp = (L + 31) & ~31;
   const int64_t ldq = 3 * (int64_t)H;
   char* tQ = smem;
-  char* tK = tQ + Lp * 128;
-  char* tV = tK + Lp * 128;
-  char* tD = tV + Lp * 128;  // dO
-  float* maskv = reinterpret_cast<float*>(tD + Lp * 128);
-  float* lsev = maskv + Lp;
-  float* deltav = lsev + Lp;
+  char* tK = tQ + LpT * 128;
+  char* tV = tK + LpT * 128;
+  char* tD = tV + LpT * 128;  // dO
+  float* maskv = reinterpret_cast<float*>(tD + LpT * 128);
+  float* lsev = maskv + LpT;
+  float* deltav = lsev + LpT;
 
-  const __bf16* base = p.qkv + (int64_t)b * L * ldq + hd * 64;
-  const __bf16* dob = p.dctx + (int64_t)b * L * H + hd * 64;
-  const __bf16* ob = p.ctx + (int64_t)b * L * H + hd * 64;
+  const __bf16* base = p.qkv + row0 * ldq + hd * 64;
+  const __bf16* dob = p.dctx + row0 * H + hd * 64;
+  const __bf16* ob = p.ctx + row0 * H + hd * 64;
   stage_tile(tQ, base, ldq, L, Lp, wave, lane);
   stage_tile(tK, base + H, ldq, L, Lp, wave, lane);
   stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
@@ -242,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   for (int i = tid; i < Lp; i += 256) {
     float mk = -INFINITY, ls = 0.f, dl = 0.f;
     if (i < L) {
-      mk = p.mask[(int64_t)b * L + i];
-      ls = p.lse[(int64_t)bh * L + i];
+      mk = (p.mask != nullptr) ? p.mask[row0 + i] : 0.f;
+      ls = p.lse[(int64_t)bh * LT + i];
       const bf16x8* a = reinterpret_cast<const bf16x8*>(dob + (int64_t)i * H);
       const bf16x8* c = reinterpret_cast<const bf16x8*>(ob + (int64_t)i * H);
 #pragma unroll
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int nb = Lp >> 5;
   const LaneOffs lo_ = make_lane_offs(lane);
-  __bf16* dq_base = p.dqkv + (int64_t)b * L * ldq + hd * 64;
+  __bf16* dq_base = p.dqkv + row0 * ldq + hd * 64;
 
   // ---------------- pass A: waves own key blocks; key on lane, query in registers
   for (int kb = wave; kb < nb; kb += 4) {
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
         for (int r0 = 0; r0 < 16; r0 += 2) {
           const int rm = r0 + par;  // the query register this lane hashes
           const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
-          const uint64_t idx = ((uint64_t)bh * L + qm) * (uint64_t)Lp + (key & ~1);
+          const uint64_t idx = ((uint64_t)bh * LT + qm) * (uint64_t)LpT + (key & ~1);
           const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
           const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
           const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       float mk16[16];
       load_rows16(maskv, kb, hh, mk16);
       if (p.drop.thresh16 != 0) {
-        const uint64_t rowbase = ((uint64_t)bh * L + q) * (uint64_t)Lp + 32 * kb + 4 * hh;
+        const uint64_t rowbase = ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           float a0 = dp[r], a1 = dp[r + 1];
@@ -402,12 +414,14 @@ int check_common(const char* who, const void* qkv, int B, int L, int heads) {
 
 }  // namespace
 
-extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse,
-                                   int B, int L, int heads, const mvptr_dropout* drop,
-                                   void* stream) {
+extern "C" int mvptr_attention_fwd_packed(const void* qkv, const float* mask_add, void* ctx, float* lse,
+                                          const int* seq_start, const int* seq_len, int B, int L,
+                                          int heads, const mvptr_dropout* drop, void* stream) {
   int rc = check_common("attention_fwd", qkv, B, L, heads);
   if (rc) return rc;
-  if (!mask_add || !ctx) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask/ctx");
+  if (!ctx) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL ctx");
+  if ((seq_start == nullptr) != (seq_len == nullptr)) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: seq_start and seq_len go together");
+  if (!mask_add && !seq_len) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask (only allowed in packed mode)");
   AttnArgs a{};
   a.qkv = (const __bf16*)qkv;
   a.mask = mask_add;
@@ -417,6 +431,8 @@ extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void*
   a.L = L;
   a.heads = heads;
   a.Lp = (L + 31) & ~31;
+  a.seq_start = seq_start;
+  a.seq_len = seq_len;
   a.drop = make_dropdev(drop);
   const size_t lds = (size_t)a.Lp * 128 * 3 + (size_t)a.Lp * 4;
   hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -426,12 +442,22 @@ extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void*
   return MVPTR_OK;
 }
 
-extern "C" int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
-                                   const void* dctx, const float* lse, void* dqkv, int B, int L,
-                                   int heads, const mvptr_dropout* drop, void* stream) {
+extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse,
+                                   int B, int L, int heads, const mvptr_dropout* drop,
+                                   void* stream) {
+  if (!mask_add) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask/ctx");
+  return mvptr_attention_fwd_packed(qkv, mask_add, ctx, lse, nullptr, nullptr, B, L, heads, drop, stream);
+}
+
+extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add, const void* ctx,
+                                          const void* dctx, const float* lse, void* dqkv,
+                                          const int* seq_start, const int* seq_len, int B, int L,
+                                          int heads, const mvptr_dropout* drop, void* stream) {
   int rc = check_common("attention_bwd", qkv, B, L, heads);
   if (rc) return rc;
-  if (!mask_add || !ctx || !dctx || !lse || !dqkv) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL argument");
+  if (!ctx || !dctx || !lse || !dqkv) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL argument");
+  if ((seq_start == nullptr) != (seq_len == nullptr)) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: seq_start and seq_len go together");
+  if (!mask_add && !seq_len) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL mask (only allowed in packed mode)");
   if (((uintptr_t)dctx & 15) || ((uintptr_t)ctx & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "attention_bwd: ctx/dctx must be 16-byte aligned");
   AttnArgs a{};
   a.qkv = (const __bf16*)qkv;
@@ -444,6 +470,8 @@ extern "C" int mvptr_attention_bwd(const void* qkv, const float* mask_add, const
   a.L = L;
   a.heads = heads;
   a.Lp = (L + 31) & ~31;
+  a.seq_start = seq_start;
+  a.seq_len = seq_len;
   a.drop = make_dropdev(drop);
   const size_t lds = (size_t)a.Lp * 128 * 4 + (size_t)a.Lp * 12;
   hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -451,4 +479,11 @@ extern "C" int mvptr_attention_bwd(const void* qkv, const float* mask_add, const
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
   MVPTR_CHECK_LAUNCH("attention_bwd");
   return MVPTR_OK;
+}
+
+extern "C" int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
+                                   const void* dctx, const float* lse, void* dqkv, int B, int L,
+                                   int heads, const mvptr_dropout* drop, void* stream) {
+  if (!mask_add) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL argument");
+  return mvptr_attention_bwd_packed(qkv, mask_add, ctx, dctx, lse, dqkv, nullptr, nullptr, B, L, heads, drop, stream);
 }

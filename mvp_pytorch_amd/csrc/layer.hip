@@ -17,7 +17,7 @@ struct Stash {
 };
 
 Stash carve(const mvptr_layer_desc* d, void* base) {
-  const int64_t M = (int64_t)d->B * d->L, H = d->H, I = d->I;
+  const int64_t M = (d->M > 0 ? (int64_t)d->M : (int64_t)d->B * d->L), H = d->H, I = d->I;
   char* p = (char*)base;
   int64_t off = 0;
   Stash s;
@@ -42,6 +42,9 @@ Stash carve(const mvptr_layer_desc* d, void* base) {
   return s;
 }
 
+// token rows of a layer call: packed mode carries them in d->M, the dense layout has B * L
+int64_t layer_rows(const mvptr_layer_desc* d) { return d->M > 0 ? (int64_t)d->M : (int64_t)d->B * d->L; }
+
 mvptr_dropout site_drop(const mvptr_layer_desc* d, int site, uint32_t thresh) {
   mvptr_dropout r;
   r.seed_lo = (uint32_t)(d->seed & 0xffffffffu) ^ (0x9E3779B9u * (uint32_t)(site + 1));
@@ -58,6 +61,9 @@ int check_desc(const char* who, const mvptr_layer_desc* d) {
   if (d->H != d->heads * 64) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: head_dim must be 64 (H=%d heads=%d)", who, d->H, d->heads);
   if ((d->H & 7) || (d->I & 7) || d->H > 1024) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: H,I must be multiples of 8, H <= 1024", who);
   if (d->L > 256) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: L=%d > 256", who, d->L);
+  if (d->M < 0 || (int64_t)d->M > (int64_t)d->B * d->L) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: M=%d outside [0, B*L]", who, d->M);
+  if ((d->M > 0) != (d->seq_start != nullptr) || (d->M > 0) != (d->seq_len != nullptr))
+    MVPTR_FAIL(MVPTR_BAD_ARG, "%s: M, seq_start and seq_len go together (row-packed mode)", who);
   return MVPTR_OK;
 }
 
@@ -76,7 +82,7 @@ extern "C" int64_t mvptr_layer_saved_bytes(const mvptr_layer_desc* d) {
 
 extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   if (check_desc("layer_workspace_bytes", d)) return -1;
-  const int64_t M = (int64_t)d->B * d->L, H = d->H;
+  const int64_t M = layer_rows(d), H = d->H;
   const int64_t W = d->I > 3 * H ? d->I : 3 * H;
   // backward: five [M,H] buffers, dU [M,I], dqkv [M,3H] (every weight-gradient operand stays alive
   // until the grouped weight-gradient launch at the end of the layer) + LayerNorm partials
@@ -91,15 +97,16 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
   (void)ws;
   (void)ws_bytes;
   RUN(check_desc("encoder_layer_fwd", d));
-  if (!w || !x || !mask_add || !y || !saved) MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_fwd: NULL argument");
-  const int M = d->B * d->L, H = d->H, I = d->I;
+  if (!w || !x || !y || !saved || (!mask_add && d->M == 0)) MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_fwd: NULL argument");
+  const int M = (int)layer_rows(d), H = d->H, I = d->I;
   Stash s = carve(d, saved);
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
   const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
   RUN(mvptr_gemm_nt(x, H, w->w_qkv, H, M, 3 * H, H, MVPTR_EPI_BIAS, w->b_qkv, nullptr, 0, s.qkv,
                     nullptr, 3 * H, nullptr, nullptr, stream));
-  RUN(mvptr_attention_fwd(s.qkv, mask_add, s.ctx, s.lse, d->B, d->L, d->heads, &dr_attn, stream));
+  RUN(mvptr_attention_fwd_packed(s.qkv, mask_add, s.ctx, s.lse, d->seq_start, d->seq_len, d->B, d->L, d->heads,
+                                 &dr_attn, stream));
   RUN(mvptr_gemm_nt(s.ctx, H, w->w_o, H, M, H, H, MVPTR_EPI_BIAS_RESID, w->b_o, x, H, s.z1, nullptr,
                     H, nullptr, &dr_o, stream));
   RUN(mvptr_layernorm_fwd(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
@@ -118,12 +125,12 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
                                        const void* dy, void* dx, const mvptr_layer_grads* g,
                                        void* ws, int64_t ws_bytes, void* stream) {
   RUN(check_desc("encoder_layer_bwd", d));
-  if (!w || !x || !mask_add || !saved || !dy || !dx || !g || !ws)
+  if (!w || !x || !saved || !dy || !dx || !g || !ws || (!mask_add && d->M == 0))
     MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd: NULL argument");
   if (ws_bytes < mvptr_layer_workspace_bytes(d))
     MVPTR_FAIL(MVPTR_WORKSPACE_TOO_SMALL, "encoder_layer_bwd: workspace %ld < %ld", (long)ws_bytes,
                (long)mvptr_layer_workspace_bytes(d));
-  const int M = d->B * d->L, H = d->H, I = d->I;
+  const int M = (int)layer_rows(d), H = d->H, I = d->I;
   Stash s = carve(d, const_cast<void*>(saved));
   char* p = (char*)ws;
   char* bufA = p;                                       // LN2 dz (residual branch)
@@ -182,8 +189,8 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
                     nullptr, nullptr, stream));
   // attention core
-  RUN(mvptr_attention_bwd(s.qkv, mask_add, s.ctx, bufC, s.lse, bufQ, d->B, d->L, d->heads, &dr_attn,
-                          stream));
+  RUN(mvptr_attention_bwd_packed(s.qkv, mask_add, s.ctx, bufC, s.lse, bufQ, d->seq_start, d->seq_len, d->B,
+                                 d->L, d->heads, &dr_attn, stream));
   // Q/K/V projections: the bias gradient (column sums of dqkv) rides on the weight-gradient kernel
   if (g->w_qkv) {
     add_wgrad(bufQ, 3 * H, x, H, 3 * H, H, g->w_qkv, g->b_qkv);

@@ -187,8 +187,11 @@ class EncoderPacks:
 class EncoderMeta:
     """Static description handed to EncoderFn (not a tensor)."""
 
-    def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn):
+    def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn, seq_start=None, seq_len=None, rows=0):
+        """seq_start / seq_len (device int32 [B]) + rows: row-packed mode — x holds `rows` valid token
+        rows, sequence b at [seq_start[b], +seq_len[b]), L = the longest sequence."""
         self.packs, self.B, self.L, self.H, self.heads, self.I = packs, B, L, H, heads, I
+        self.seq_start, self.seq_len, self.rows = seq_start, seq_len, rows
         self.group = getattr(packs, "group", None)
         self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
 
@@ -218,7 +221,9 @@ class EncoderFn(torch.autograd.Function):
             lw = lws[li]
             d = hip.LayerDesc(meta.B, meta.L, meta.H, meta.heads, meta.I, meta.eps,
                               1 if meta.training else 0, _thresh(meta.p_hidden), _thresh(meta.p_attn),
-                              next_seed() if meta.training else 0)
+                              next_seed() if meta.training else 0, meta.rows, 0,
+                              meta.seq_start.data_ptr() if meta.rows else None,
+                              meta.seq_len.data_ptr() if meta.rows else None)
             nbytes = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
             if nbytes < 0:
                 hip._check(-1)

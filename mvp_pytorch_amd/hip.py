@@ -22,7 +22,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
-    "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
+    "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
@@ -36,7 +36,8 @@ class Dropout(Structure):
 class LayerDesc(Structure):
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("heads", c_int), ("I", c_int),
                 ("eps", c_float), ("training", c_int), ("p_hidden16", c_uint32),
-                ("p_attn16", c_uint32), ("seed", c_uint64)]
+                ("p_attn16", c_uint32), ("seed", c_uint64),
+                ("M", c_int), ("pad_", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p)]
 
 
 class LayerWeights(Structure):
@@ -83,6 +84,8 @@ def load():
     lib.mvptr_cast_multi.argtypes = [P, P, I, I, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_attention_fwd_packed.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_attention_bwd_packed.argtypes = [P, P, P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_layernorm_fwd.argtypes = [P, P, P, F, P, P, P, I, I, I, I, I, POINTER(Dropout), P]
     lib.mvptr_layernorm_bwd.argtypes = [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, POINTER(Dropout), POINTER(Dropout), P, I64, P]
     lib.mvptr_layernorm_bwd_ws_bytes.restype = c_int64
@@ -197,6 +200,23 @@ def attention_fwd(qkv, mask_add, B, L, heads, drop=None, need_lse=True):
 def attention_bwd(qkv, mask_add, ctx, dctx, lse, B, L, heads, drop=None):
     dqkv = torch.empty_like(qkv)
     _check(load().mvptr_attention_bwd(_p(qkv), _p(mask_add), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, L, heads, _dp(drop), _stream()))
+    return dqkv
+
+
+def attention_fwd_packed(qkv, seq_start, seq_len, B, Lmax, heads, mask_add=None, drop=None, need_lse=True):
+    """Row-packed sequences: qkv [total_rows, 3H]; sequence b = rows [seq_start[b], +seq_len[b])."""
+    H = heads * 64
+    ctx = torch.empty((qkv.shape[0], H), device=qkv.device, dtype=torch.bfloat16)
+    lse = torch.empty((B, heads, Lmax), device=qkv.device, dtype=torch.float32) if need_lse else None
+    _check(load().mvptr_attention_fwd_packed(_p(qkv), _p(mask_add), _p(ctx), _p(lse), _p(seq_start), _p(seq_len), B, Lmax, heads,
+                                             _dp(drop), _stream()))
+    return ctx, lse
+
+
+def attention_bwd_packed(qkv, seq_start, seq_len, ctx, dctx, lse, B, Lmax, heads, mask_add=None, drop=None):
+    dqkv = torch.empty_like(qkv)
+    _check(load().mvptr_attention_bwd_packed(_p(qkv), _p(mask_add), _p(ctx), _p(dctx), _p(lse), _p(dqkv), _p(seq_start), _p(seq_len),
+                                             B, Lmax, heads, _dp(drop), _stream()))
     return dqkv
 
 

@@ -79,6 +79,9 @@ class CaptionBertEncoder(nn.Module):
         self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
         self._packs = engine.PackList(engine.LayerPack() for _ in range(config.num_hidden_layers))
         self._dims = (config.hidden_size, config.num_attention_heads, config.intermediate_size, config.layer_norm_eps)
+        # skip padded rows (see forward): "train" (default) = in training mode only, where nothing but
+        # the losses is consumed; True = always; False = never (the reference's padded execution)
+        self.unpad = getattr(config, "unpad", "train")
 
     def _flat_params(self):
         out = []
@@ -100,10 +103,29 @@ class CaptionBertEncoder(nn.Module):
         B, L, H = hidden_states.shape
         Hc, heads, I, eps = self._dims
         l0 = self.layer[0]
+        x = hidden_states.to(torch.bfloat16).contiguous().view(B * L, H)
+        mask = attention_mask.contiguous()
+        if self.unpad is True or (self.unpad == "train" and self.training):
+            # Row-packed execution: the reference pushes every padded slot through all layers and
+            # only masks it as a key (vl:430-460).  A padded row influences nothing that reaches a loss
+            # (its output is read by nobody, as a key it weighs exp(-10000) = 0), so only the valid
+            # rows are gathered, run through the stack and scattered back; padded rows of the returned
+            # tensor are zero instead of the reference's unused values (hence off in eval mode by
+            # default: inference outputs stay position-for-position what the reference returns).
+            valid = (mask == 0).view(-1)
+            lens = (mask == 0).sum(1, dtype=torch.int32)
+            rows, lmax = (int(v) for v in torch.stack([lens.sum(), lens.max()]).tolist())   # one host sync
+            if rows < B * L and lmax > 0:
+                idx = torch.nonzero_static(valid, size=rows).view(-1)
+                starts = (torch.cumsum(lens, 0, dtype=torch.int32) - lens).contiguous()
+                meta = engine.EncoderMeta(self._packs, B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
+                                          l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
+                y = engine.EncoderFn.apply(x.index_select(0, idx), None, meta, *self._flat_params())
+                out = torch.zeros((B * L, H), dtype=y.dtype, device=y.device).index_copy(0, idx, y)
+                return (out.view(B, L, H),)
         meta = engine.EncoderMeta(self._packs, B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
-        x = hidden_states.to(torch.bfloat16).contiguous().view(B * L, H)
-        y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params())
+        y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
 
 

@@ -30,12 +30,14 @@ def synthetic_batch(dims, cfg, seed, single_stream=False, fixed_length=False, de
     phrase_index = torch.zeros(B, 2, dtype=torch.long)
     image_index = torch.zeros(B, 2, dtype=torch.long)
     for b in range(B):
-        n_r = R if fixed_length else int(ri(min(3, R), R + 1))
+        # lengths as SURVEY §8(d) specifies for the measurement: regions U{10..50}, tokens U{8..68},
+        # phrases U{0..5}, tags U{3..18} (smaller floors for the tiny test shapes)
+        n_r = R if fixed_length else int(ri(10 if R >= 20 else min(3, R), R + 1))
         feat = torch.randn(n_r, D, generator=g)
         feat[:, -6:] = torch.rand(n_r, 6, generator=g)
         img[b, :n_r] = feat
         max_t = T - 2
-        n_t = max_t if fixed_length else int(ri(min(4, max_t), max_t + 1))
+        n_t = max_t if fixed_length else int(ri(8 if max_t >= 16 else min(4, max_t), max_t + 1))
         n_p = 0 if single_stream else (P if fixed_length else int(ri(0, P + 1)))
         toks = ri(lo, W, (n_t,))
         seq = [CLS] + toks.tolist()

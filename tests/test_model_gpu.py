@@ -229,6 +229,52 @@ def test_finetune_parity(dev):
     assert _rel(o[1], torch.from_numpy(d["ve_logits"])) < 2e-2
 
 
+def test_unpadded_equals_padded_execution(dev):
+    """Row-packed encoder execution (default) against the padded execution the reference performs:
+    same losses, same hard-negative indices, same gradients; encoder outputs equal on the valid rows
+    and zero on the padded ones."""
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    dims = dict(B=12, T=20, P=4, G=8, R=9)
+    b = {k: v.to(dev) for k, v in synthetic_batch(dims, cfg, 31).items()}
+    perm = torch.randperm(dims["B"], generator=torch.Generator().manual_seed(4))
+    res, grads, outs = {}, {}, {}
+    for unpad in (True, False):
+        model, _ = _build("BiBertImgForPreTraining", cfg, 17, dev, train=True)
+        model.wra_on_device = True
+        for enc in (model.bert.txt_encoder, model.bert.vis_encoder, model.bert.mul_encoder):
+            enc.unpad = unpad
+        torch.manual_seed(123)   # same device draws (WRA picks) in both runs
+        with Replay(dict(draw_randperm=[perm.numpy()]), dev):
+            o = model(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+                      masked_lm_labels_a=b["lm_label_ids_a"], input_ids_b=b["input_ids_b"], img_feats=b["img_feats"],
+                      token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"],
+                      masked_lm_labels_b=b["lm_label_ids_b"], max_tag_length=dims["G"], phrase_index=b["phrase_index"],
+                      img_index=b["image_index"])
+        o[0].backward()
+        res[unpad] = torch.stack([x.detach() for x in o])
+        grads[unpad] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        with torch.no_grad():
+            (seq, pooled, _, _), (txt, vis, sim), _ = model.bert(
+                input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+                input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"],
+                img_feats=b["img_feats"], max_tag_length=dims["G"])
+        outs[unpad] = (seq, txt, vis, sim)
+    print("losses unpadded", res[True].tolist(), "padded", res[False].tolist())
+    assert torch.allclose(res[True], res[False], rtol=2e-4, atol=1e-5)
+    assert grads[True].keys() == grads[False].keys()
+    worst = max((_rel(grads[True][n], grads[False][n]), n) for n in grads[True] if grads[False][n].norm() > 1e-6)
+    print("worst gradient difference", worst)
+    assert worst[0] < 2e-3
+    va = b["input_mask_a"].bool()
+    vb = b["input_mask_b"].bool()
+    (seq_u, txt_u, vis_u, sim_u), (seq_p, txt_p, vis_p, sim_p) = outs[True], outs[False]
+    assert torch.equal(txt_u[va], txt_p[va]) and torch.equal(vis_u[vb], vis_p[vb]) and torch.equal(sim_u, sim_p)
+    assert float(txt_u[~va].abs().max()) == 0.0 and float(vis_u[~vb].abs().max()) == 0.0
+    vj = torch.cat([va, vb[:, dims["G"]:]], 1)
+    assert torch.equal(seq_u[vj], seq_p[vj])
+
+
 def test_wra_device_path_equals_host_path(dev):
     """wra_sample_on_device (fixed shapes, no host round trip) against the host-index version of
     vl:1553-1596 with the same draws, forward and gradient; includes samples without phrases."""

@@ -11,9 +11,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
+from mvp_pytorch_amd.synthetic import synthetic_batch  # noqa: E402
+
 dev = torch.device("cuda:0")
 dims = dict(B=256, T=70, P=5, G=20, R=50)
-mix = bench.DominantMix(dev, dims, bench.BASE_CFG)
+# argv[2] == "full": every slot valid; default: the row counts of bench.py's timed batch (seed 1234)
+full = len(sys.argv) > 2 and sys.argv[2] == "full"
+batch = None if full else synthetic_batch(dims, bench.BASE_CFG, 1234, device=dev)
+mix = bench.DominantMix(dev, dims, bench.BASE_CFG, batch)
+print("rows per launch group:", mix.Ms)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     mix.run_tn()
     mix.run_nt()
