@@ -30,7 +30,7 @@ def test_library_exports_header_symbols():
 def test_abi_version_and_error_string():
     from mvp_pytorch_amd import hip
     lib = hip.load()
-    assert hip.query(0) == 1
+    assert hip.query(0) == 2   # MVPTR_ABI_VERSION (2: row-packed mode fields in mvptr_layer_desc)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.mvptr_gemm_nt(None, 8, None, 8, 0, 8, 8, 0, None, None, 0, None, None, 8, None, None, None)
     assert rc == -1
@@ -38,8 +38,17 @@ def test_abi_version_and_error_string():
     d = hip.LayerDesc(2, 300, 128, 2, 512, 1e-12, 1, 0, 0, 0)
     assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1  # L > 256
     d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0)
-    assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) > 0
+    dense = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
+    assert dense > 0
     assert lib.mvptr_layer_workspace_bytes(ctypes.byref(d)) > 0
+    # row-packed mode: M rows + both sequence arrays, or none of them
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 50, 0, None, None)
+    assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1
+    assert b"seq_start" in lib.mvptr_last_error()
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 81, 0, 4096, 4096)
+    assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1  # M > B*L
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 50, 0, 4096, 4096)
+    assert 0 < lib.mvptr_layer_saved_bytes(ctypes.byref(d)) < dense
 
 
 def test_struct_sizes_match_header():
@@ -47,4 +56,4 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(hip.Dropout) == 16
     assert ctypes.sizeof(hip.LayerWeights) == 16 * 8
     assert ctypes.sizeof(hip.LayerGrads) == 12 * 8
-    assert ctypes.sizeof(hip.LayerDesc) == 48
+    assert ctypes.sizeof(hip.LayerDesc) == 72
