@@ -95,7 +95,7 @@ class CaptionBertEncoder(nn.Module):
         return out
 
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None,
-                return_at_layer=None):
+                return_at_layer=None, pack_hint=None):
         if isinstance(attention_mask, list) or encoder_history_states is not None or return_at_layer is not None:
             raise NotImplementedError("phase masks / history states / return_at_layer are outside the accelerated path")
         if head_mask is not None and any(h is not None for h in head_mask):
@@ -114,7 +114,10 @@ class CaptionBertEncoder(nn.Module):
             # default: inference outputs stay position-for-position what the reference returns).
             valid = (mask == 0).view(-1)
             lens = (mask == 0).sum(1, dtype=torch.int32)
-            rows, lmax = (int(v) for v in torch.stack([lens.sum(), lens.max()]).tolist())   # one host sync
+            if pack_hint is not None:   # (rows, longest) already fetched by the caller with other counts
+                rows, lmax = pack_hint
+            else:
+                rows, lmax = (int(v) for v in torch.stack([lens.sum(), lens.max()]).tolist())   # one host sync
             if rows < B * L and lmax > 0:
                 idx = torch.nonzero_static(valid, size=rows).view(-1)
                 starts = (torch.cumsum(lens, 0, dtype=torch.int32) - lens).contiguous()
@@ -214,8 +217,15 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         mask_b = additive_mask(attention_mask_b)
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
         xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self)
-        txt = self.txt_encoder(xa, mask_a)[0]
-        vis = self.vis_encoder(xb, mask_b)[0]
+        hint_a = hint_b = None
+        if self.txt_encoder.unpad is True or (self.txt_encoder.unpad == "train" and self.training):
+            # the valid-row counts of both uni-modal passes in ONE device->host copy, issued before any
+            # encoder work is queued (a sync in the middle of the forward pass drains the launch queue)
+            la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
+            c = torch.stack([la.sum(), la.max(), lb.sum(), lb.max()]).tolist()
+            hint_a, hint_b = (int(c[0]), int(c[1])), (int(c[2]), int(c[3]))
+        txt = self.txt_encoder(xa, mask_a, pack_hint=hint_a)[0]
+        vis = self.vis_encoder(xb, mask_b, pack_hint=hint_b)[0]
         return txt, vis, mask_a, mask_b
 
     def _globals(self, txt, vis):
