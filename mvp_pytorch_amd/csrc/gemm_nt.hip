@@ -743,6 +743,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   if (env != nullptr && env[0] != 0) {
     const size_t n = strlen(env);
     if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
+    if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128": 128x128, 4 waves
     if (env[0] == 't' && env[n - 1] == 'k') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
     if (env[0] == 't' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 2, 4, 8, 2>(a, s);
     if (env[0] == 't') return launch_bk<EPI, 32, 3, 2, 4, 8, 0>(a, s);
@@ -751,6 +752,10 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
     MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
   }
   const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  // few-row GEMMs (head transforms on the masked rows: M ~ 3 k, N = 768) would give a 256x256 tile to
+  // a quarter of the CUs or fewer: 128x128 tiles, 4 waves, up to three workgroups per CU ("s128":
+  // 35 vs 74 us at M = 3000, N = 768, K = 3072; at M = 11 k the big tile still wins, 74 vs 87 us)
+  if (tiles256 <= 64 && a.M > 128) return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);
   if (a.N <= 768 && a.K <= 768 && tiles256 > 256) return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
   return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
 }

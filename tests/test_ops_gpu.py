@@ -27,7 +27,7 @@ def test_gemm_nt_bias(dev, M, N, K):
     b = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     ref = a.float() @ b.float().t() + bias
-    for cfg in ("p256", "t256k", "t256", "t256g", "w4", "w4g", None):  # every tile configuration + the default choice
+    for cfg in ("p256", "s128", "t256k", "t256", "t256g", "w4", "w4g", None):  # every tile configuration + the default choice
         if cfg is None:
             os.environ.pop("MVPTR_GEMM_CFG", None)
         else:

@@ -31,7 +31,7 @@ def rnd(*s):
 
 
 H, I = 768, 3072
-for M in (64000, 32000, 19200, 17920):
+for M in (37748, 10917, 3000):
     x, xi, x3 = rnd(M, H), rnd(M, I), rnd(M, 3 * H)
     shapes = [("qkv fwd BIAS", x, rnd(3 * H, H), hip.EPI_BIAS, None),
               ("out fwd RESID", x, rnd(H, H), hip.EPI_BIAS_RESID, x),
