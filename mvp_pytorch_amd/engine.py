@@ -200,6 +200,36 @@ def _thresh(p):
     return int(round(float(p) * 65536.0))
 
 
+class PackRows(torch.autograd.Function):
+    """x [n, H] -> x[idx] for a strictly increasing idx (the valid rows of a padded batch).  idx has no
+    duplicates, so the backward pass is a plain scatter into zeros (index_copy), not the atomic
+    index_add autograd derives for index_select."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.idx, ctx.n = idx, x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        out = torch.zeros((ctx.n, g.shape[1]), dtype=g.dtype, device=g.device)
+        return out.index_copy_(0, ctx.idx, g), None
+
+
+class UnpackRows(torch.autograd.Function):
+    """inverse of PackRows: y [rows, H] scattered to row idx[i] of a zero [n, H] tensor."""
+
+    @staticmethod
+    def forward(ctx, y, idx, n):
+        ctx.idx = idx
+        out = torch.zeros((n, y.shape[1]), dtype=y.dtype, device=y.device)
+        return out.index_copy_(0, idx, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.index_select(0, ctx.idx), None, None
+
+
 class EncoderFn(torch.autograd.Function):
     """n stacked encoder layers: x bf16 [B*L,H], additive mask f32 [B,L] -> bf16 [B*L,H]."""
 

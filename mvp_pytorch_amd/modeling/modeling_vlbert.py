@@ -123,9 +123,8 @@ class CaptionBertEncoder(nn.Module):
                 starts = (torch.cumsum(lens, 0, dtype=torch.int32) - lens).contiguous()
                 meta = engine.EncoderMeta(self._packs, B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
                                           l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
-                y = engine.EncoderFn.apply(x.index_select(0, idx), None, meta, *self._flat_params())
-                out = torch.zeros((B * L, H), dtype=y.dtype, device=y.device).index_copy(0, idx, y)
-                return (out.view(B, L, H),)
+                y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
+                return (engine.UnpackRows.apply(y, idx, B * L).view(B, L, H),)
         meta = engine.EncoderMeta(self._packs, B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
