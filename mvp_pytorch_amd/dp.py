@@ -121,6 +121,15 @@ class GradSync:
         b = self.buckets[idx]
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         assert idx == self._next, "buckets are launched in index order"
+        if b["flat"].is_cuda:
+            # gradients of sub-networks that ran on a side stream (engine.SIDE_STREAMS) may still be in
+            # flight there although their hooks have fired on the host
+            from . import engine
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for st in engine.SIDE_STREAMS.values():
+                if st.device == b["flat"].device:
+                    cur.wait_stream(st)
+            cur.wait_stream(torch.cuda.default_stream(b["flat"].device))
         b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._launched.append(idx)
         self._next = idx + 1

@@ -200,6 +200,19 @@ def _thresh(p):
     return int(round(float(p) * 65536.0))
 
 
+# Side streams used for independent sub-networks (text / visual stack); mvp_pytorch_amd.dp waits on
+# them before a gradient bucket is handed to RCCL.
+SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """One extra HIP stream per device, created on first use."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in SIDE_STREAMS:
+        SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return SIDE_STREAMS[key]
+
+
 class PackRows(torch.autograd.Function):
     """x [n, H] -> x[idx] for a strictly increasing idx (the valid rows of a padded batch).  idx has no
     duplicates, so the backward pass is a plain scatter into zeros (index_copy), not the atomic

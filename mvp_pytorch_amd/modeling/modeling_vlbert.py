@@ -199,6 +199,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         self.txt_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
         self.vis_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
         self._init_img(config)
+        self.parallel_stacks = bool(getattr(config, "parallel_stacks", True))  # see _uni
         self.apply(self.init_weights)
 
     # -- stage 1: uni-modal encoders (vl:479-513)
@@ -223,8 +224,25 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
             c = torch.stack([la.sum(), la.max(), lb.sum(), lb.max()]).tolist()
             hint_a, hint_b = (int(c[0]), int(c[1])), (int(c[2]), int(c[3]))
-        txt = self.txt_encoder(xa, mask_a, pack_hint=hint_a)[0]
-        vis = self.vis_encoder(xb, mask_b, pack_hint=hint_b)[0]
+        if self.parallel_stacks and xa.is_cuda:
+            # The two uni-modal stacks are independent networks: the visual one runs on a second HIP
+            # stream beside the text one.  At ~11 k rows per stack a 256x256-tile GEMM with N = 768
+            # occupies half of the CUs, so the two stacks' kernels fill each other's idle CUs
+            # (tools/overlap_stacks.py: 3.35 -> 2.60 ms for 6+6 forward layers); autograd replays
+            # each stack's backward on the stream its forward ran on.
+            main = torch.cuda.current_stream(xa.device)
+            side = engine.side_stream(xa.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                vis = self.vis_encoder(xb, mask_b, pack_hint=hint_b)[0]
+            txt = self.txt_encoder(xa, mask_a, pack_hint=hint_a)[0]
+            main.wait_stream(side)
+            for t in (xb, mask_b):
+                t.record_stream(side)      # allocated on the main stream, read on the side stream
+            vis.record_stream(main)        # and the other way round
+        else:
+            txt = self.txt_encoder(xa, mask_a, pack_hint=hint_a)[0]
+            vis = self.vis_encoder(xb, mask_b, pack_hint=hint_b)[0]
         return txt, vis, mask_a, mask_b
 
     def _globals(self, txt, vis):
