@@ -242,6 +242,7 @@ def test_unpadded_equals_padded_execution(dev):
     for unpad in (True, False):
         model, _ = _build("BiBertImgForPreTraining", cfg, 17, dev, train=True)
         model.wra_on_device = True
+        model.bert.parallel_stacks = unpad   # fast path: packed + two streams; reference path: neither
         for enc in (model.bert.txt_encoder, model.bert.vis_encoder, model.bert.mul_encoder):
             enc.unpad = unpad
         torch.manual_seed(123)   # same device draws (WRA picks) in both runs
@@ -273,6 +274,41 @@ def test_unpadded_equals_padded_execution(dev):
     assert float(txt_u[~va].abs().max()) == 0.0 and float(vis_u[~vb].abs().max()) == 0.0
     vj = torch.cat([va, vb[:, dims["G"]:]], 1)
     assert torch.equal(seq_u[vj], seq_p[vj])
+
+
+def test_finetune_models_unpadded_two_streams_equal_padded_one_stream(dev):
+    """VQA (encode_hn=False path) and retrieval-train wrappers in training mode: row-packed stacks +
+    text/visual stacks on two streams (defaults) against padded, single-stream execution."""
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    dims = dict(B=10, T=18, P=3, G=7, R=8)
+    b = {k: v.to(dev) for k, v in synthetic_batch(dims, cfg, 41).items()}
+    kw = dict(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+              input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"],
+              img_feats=b["img_feats"])
+    labels = torch.rand(dims["B"], 37, generator=torch.Generator().manual_seed(1)).to(dev)
+    perm = torch.randperm(dims["B"], generator=torch.Generator().manual_seed(2))
+    for cls_name, extra in (("BiImageBertForVQA", dict(loss_type="bce", num_labels=37)),
+                            ("BiImageBertForRetrieval", dict(loss_type="ce", num_labels=2))):
+        got = {}
+        for fast in (True, False):
+            model, _ = _build(cls_name, dict(cfg, **extra), 23, dev, train=True)
+            model.bert.parallel_stacks = fast
+            for enc in (model.bert.txt_encoder, model.bert.vis_encoder, model.bert.mul_encoder):
+                enc.unpad = "train" if fast else False
+            if cls_name.endswith("VQA"):
+                o = model(labels=labels, **kw)
+            else:
+                model.forward_mod = "train"
+                with Replay(dict(draw_randperm=[perm.numpy()]), dev):
+                    o = model(max_tag_length=dims["G"], **kw)
+            o[0].backward()
+            torch.cuda.synchronize()
+            got[fast] = (o[0].detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        assert torch.allclose(got[True][0], got[False][0], rtol=2e-4, atol=1e-5), (cls_name, got[True][0], got[False][0])
+        worst = max((_rel(got[True][1][n], got[False][1][n]), n) for n in got[True][1] if got[False][1][n].norm() > 1e-6)
+        print(cls_name, "loss", got[True][0].item(), "worst gradient difference", worst)
+        assert worst[0] < 2e-3
 
 
 def test_wra_device_path_equals_host_path(dev):
