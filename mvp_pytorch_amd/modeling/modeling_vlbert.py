@@ -324,8 +324,29 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
     # or on the image, so they are computed once here and the pair stage runs mul_encoder alone
     # (9.1 of the 20.9 GFLOP per pair at the README's retrieval shapes).  Same kernels on the same
     # rows: the scores equal forward(..., encode_hn=False) on the materialised pairs.
+    class _packed_stacks:
+        """context: run the three stacks row-packed whatever the mode (the retrieval engine only reads
+        valid rows — [CLS] / pooled outputs).  Bit-identical to the padded execution where the padding
+        sits at the end (text stack); in the visual and joint sequences the padding is interior, the
+        valid keys move to other 32-key blocks and sums are taken in another order: equal up to bf16
+        rounding.  packed=False in encode_text / encode_image / rerank keeps the padded execution."""
+
+        def __init__(self, bert, on=True):
+            self.encs = (bert.txt_encoder, bert.vis_encoder, bert.mul_encoder)
+            self.on = on
+
+        def __enter__(self):
+            self.saved = [e.unpad for e in self.encs]
+            for e in self.encs:
+                if self.on and e.unpad is not False:
+                    e.unpad = True
+
+        def __exit__(self, *exc):
+            for e, u in zip(self.encs, self.saved):
+                e.unpad = u
+
     @torch.no_grad()
-    def encode_text(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, position_ids_a=None):
+    def encode_text(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, position_ids_a=None, packed=True):
         """-> dict(seq bf16 [N, La, H], mask additive f32 [N, La], glob f32 [N, H] unit norm)."""
         if attention_mask_a is None:
             attention_mask_a = torch.ones_like(input_ids_a)
@@ -333,13 +354,14 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             token_type_ids_a = torch.zeros_like(input_ids_a)
         mask_a = additive_mask(attention_mask_a)
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
-        txt = self.txt_encoder(xa, mask_a)[0]
+        with self._packed_stacks(self, packed):
+            txt = self.txt_encoder(xa, mask_a)[0]
         glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
         return dict(seq=txt, mask=mask_a, glob=glob)
 
     @torch.no_grad()
     def encode_image(self, input_ids_b, img_feats, token_type_ids_b=None, attention_mask_b=None, position_ids_b=None,
-                     max_tag_length=20, use_b=False):
+                     max_tag_length=20, use_b=False, packed=True):
         """-> dict(seq bf16 [N, R', H] (tag rows cut as in vl:516-519), mask [N, R'], glob f32 [N, H])."""
         if attention_mask_b is None:
             attention_mask_b = torch.ones((input_ids_b.shape[0], input_ids_b.shape[1] + img_feats.shape[1]),
@@ -348,17 +370,20 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             token_type_ids_b = torch.zeros_like(input_ids_b)
         mask_b = additive_mask(attention_mask_b)
         xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self)
-        vis = self.vis_encoder(xb, mask_b)[0]
+        with self._packed_stacks(self, packed):
+            vis = self.vis_encoder(xb, mask_b)[0]
         cut = 1 if use_b else max_tag_length
         glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj, p=2, dim=-1)
         return dict(seq=vis[:, cut:, :].contiguous(), mask=mask_b[:, cut:].contiguous(), glob=glob)
 
     @torch.no_grad()
-    def fuse_pairs(self, text, image, txt_idx, img_idx):
-        """mul_encoder + pooler on the pairs (text[txt_idx[i]], image[img_idx[i]]) -> (seq, pooled)."""
+    def fuse_pairs(self, text, image, txt_idx, img_idx, packed=True):
+        """mul_encoder + pooler on the pairs (text[txt_idx[i]], image[img_idx[i]]) -> (seq, pooled).
+        packed=False keeps the padded execution (bit-identical to forward(..., encode_hn=False))."""
         joint = torch.cat([text["seq"].index_select(0, txt_idx), image["seq"].index_select(0, img_idx)], dim=1)
         mask = torch.cat([text["mask"].index_select(0, txt_idx), image["mask"].index_select(0, img_idx)], dim=-1)
-        seq = self.mul_encoder(joint, mask)[0]
+        with self._packed_stacks(self, packed):
+            seq = self.mul_encoder(joint, mask)[0]
         return seq, self.pooler(seq)
 
 
@@ -748,12 +773,13 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
         return text["glob"] @ image["glob"].t()
 
     @torch.no_grad()
-    def rerank(self, text, image, txt_idx, img_idx, chunk=4096):
+    def rerank(self, text, image, txt_idx, img_idx, chunk=4096, packed=True):
         """ITM logits [n_pairs, num_labels] of forward_mod 'fine' for the listed pairs, computed from
-        the cached uni-modal outputs."""
+        the cached uni-modal outputs.  packed=True skips the padded slots of the joint sequences
+        (equal to 'fine' up to bf16 rounding); packed=False reproduces 'fine' bit for bit."""
         out = []
         for s0 in range(0, txt_idx.numel(), chunk):
-            _, pooled = self.bert.fuse_pairs(text, image, txt_idx[s0:s0 + chunk], img_idx[s0:s0 + chunk])
+            _, pooled = self.bert.fuse_pairs(text, image, txt_idx[s0:s0 + chunk], img_idx[s0:s0 + chunk], packed=packed)
             out.append(self.classifier(pooled))
         return torch.cat(out, 0)
 

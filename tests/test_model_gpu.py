@@ -355,20 +355,24 @@ def test_retrieval_cached_rerank_equals_fine(dev):
     kw = _bi_inputs(d, dev)
     model, _ = _build("BiImageBertForRetrieval", dict(cfg, loss_type="ce", num_labels=2), seed + 1, dev)
     n = kw["input_ids_a"].shape[0]
-    text = model.encode_text(input_ids_a=kw["input_ids_a"], token_type_ids_a=kw["token_type_ids_a"],
-                             attention_mask_a=kw["attention_mask_a"])
-    image = model.encode_image(input_ids_b=kw["input_ids_b"], img_feats=kw["img_feats"],
-                               token_type_ids_b=kw["token_type_ids_b"], attention_mask_b=kw["attention_mask_b"],
-                               max_tag_length=dims["G"])
+    enc = lambda packed: (  # noqa: E731
+        model.encode_text(input_ids_a=kw["input_ids_a"], token_type_ids_a=kw["token_type_ids_a"],
+                          attention_mask_a=kw["attention_mask_a"], packed=packed),
+        model.encode_image(input_ids_b=kw["input_ids_b"], img_feats=kw["img_feats"], token_type_ids_b=kw["token_type_ids_b"],
+                           attention_mask_b=kw["attention_mask_b"], max_tag_length=dims["G"], packed=packed))
+    text, image = enc(False)          # padded execution: bit-identical to forward_mod='fine'
+    text_p, image_p = enc(True)       # default: padded slots skipped
     ti, ii = torch.meshgrid(torch.arange(n, device=dev), torch.arange(n, device=dev), indexing="ij")
     ti, ii = ti.reshape(-1), ii.reshape(-1)
-    got = model.rerank(text, image, ti, ii, chunk=5)            # ragged chunks on purpose
+    got = model.rerank(text, image, ti, ii, chunk=5, packed=False)   # ragged chunks on purpose
+    got_packed = model.rerank(text_p, image_p, ti, ii, chunk=7)      # default: padded slots skipped
     model.forward_mod = "fine"
     pair_kw = {k: v.index_select(0, ti if k.endswith("_a") else ii) for k, v in kw.items()}
     with torch.no_grad():
         ref = model(max_tag_length=dims["G"], **pair_kw)
     print("cached rerank vs fine: max abs diff", (got - ref).abs().max().item())
     assert torch.equal(got, ref)
+    assert _rel(got_packed, ref) < 5e-3
     diag = torch.arange(n, device=dev) * (n + 1)
     assert _rel(got.index_select(0, diag), torch.from_numpy(d["ret_fine_logits"])) < 2e-2
     model.forward_mod = "coarse"
