@@ -296,7 +296,7 @@ def main():
 
     # the same step with every token / region slot valid (nothing to skip), outside the timed region:
     # reported beside `value` because the encoder stacks run row-packed (padded slots of the
-    # variable-length batch are not computed; results equal the padded execution)
+    # variable-length batch are not computed; results agree with the padded execution to rounding)
     full = None
     if world == 1 and not args.fixed_length:
         fb_batch = synthetic_batch(dims, BASE_CFG, 1234 + rank, fixed_length=True, device=dev)
