@@ -60,7 +60,7 @@ class GradSync:
         p0 = items[0][0]
         idx = len(self.buckets)
         self.buckets.append(dict(flat=torch.zeros(n, device=p0.device, dtype=torch.float32), items=items,
-                                 pending=0, work=None))
+                                 pending=0, work=None, streams=set()))
         for p, _, _ in items:
             self.where[p] = idx
 
@@ -71,6 +71,7 @@ class GradSync:
         for b in self.buckets:
             b["flat"].zero_()
             b["work"] = None
+            b["streams"] = set()
             n_exp = 0
             for p, off, n in b["items"]:
                 view = b["flat"][off:off + n].view_as(p)
@@ -96,6 +97,10 @@ class GradSync:
         if p in self._ready:
             return
         self._ready.add(p)
+        if p.grad.is_cuda:
+            # the gradient was produced on the stream current in this hook (sub-networks may run on a
+            # side stream, engine.side_stream): remember which streams fed this bucket
+            b["streams"].add(torch.cuda.current_stream(p.grad.device))
         if idx < self._next:
             # its bucket is already being reduced in place: the parameter never produced a gradient
             # before, so nobody was waiting for it.  Failing loudly beats a silently unsynchronised
@@ -122,14 +127,12 @@ class GradSync:
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         assert idx == self._next, "buckets are launched in index order"
         if b["flat"].is_cuda:
-            # gradients of sub-networks that ran on a side stream (engine.SIDE_STREAMS) may still be in
-            # flight there although their hooks have fired on the host
-            from . import engine
+            # gradients produced on another stream than the launching one may still be in flight
+            # although their hooks have fired on the host
             cur = torch.cuda.current_stream(b["flat"].device)
-            for st in engine.SIDE_STREAMS.values():
-                if st.device == b["flat"].device:
-                    cur.wait_stream(st)
-            cur.wait_stream(torch.cuda.default_stream(b["flat"].device))
+            for st in b["streams"]:
+                if st != cur:
+                    cur.wait_stream(st)   # everything queued there so far includes the gradients
         b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._launched.append(idx)
         self._next = idx + 1

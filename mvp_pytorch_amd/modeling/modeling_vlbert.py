@@ -54,6 +54,18 @@ def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
     return loss
 
 
+def _streams_allowed(setting):
+    """Two-stream execution of the uni-modal stacks is validated on one GPU (and, functionally, with
+    two gloo ranks sharing one: tests/test_dp_gpu.py); with gloo the bucketed gradient exchange
+    slows down badly beside a side stream (tools/dp_gloo_check.py), and there was no multi-GPU box
+    to measure the same thing under RCCL, so multi-rank jobs keep one stream unless the config says
+    parallel_stacks = "always"."""
+    if setting == "always":
+        return True
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def additive_mask(attention_mask):
     """vl:278-292 / vl:430-460 — [B,L] 0/1 -> f32 [B,L] additive (0 / -10000); the kernel
     broadcasts it over heads and query positions like the reference's [B,1,1,L] tensor."""
@@ -199,7 +211,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         self.txt_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
         self.vis_proj = nn.Parameter(scale * torch.randn(config.hidden_size, config.hidden_size))
         self._init_img(config)
-        self.parallel_stacks = bool(getattr(config, "parallel_stacks", True))  # see _uni
+        # see _uni: True = whenever this process is not part of a multi-rank job, "always" = also under
+        # torch.distributed, False = never
+        self.parallel_stacks = getattr(config, "parallel_stacks", True)
         self.apply(self.init_weights)
 
     # -- stage 1: uni-modal encoders (vl:479-513)
@@ -224,7 +238,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
             c = torch.stack([la.sum(), la.max(), lb.sum(), lb.max()]).tolist()
             hint_a, hint_b = (int(c[0]), int(c[1])), (int(c[2]), int(c[3]))
-        if self.parallel_stacks and xa.is_cuda:
+        if self.parallel_stacks and xa.is_cuda and _streams_allowed(self.parallel_stacks):
             # The two uni-modal stacks are independent networks: the visual one runs on a second HIP
             # stream beside the text one.  At ~11 k rows per stack a 256x256-tile GEMM with N = 768
             # occupies half of the CUs, so the two stacks' kernels fill each other's idle CUs
