@@ -375,6 +375,7 @@ class InputEmbedFn(torch.autograd.Function):
                                           group_stride=Ltot, row_offset=Lt, drop=drop_i, save_stats=use_ln)
             ctx.img = (fb, zi, mi, ri, g, drop_i, D)
         ctx.dims = (B, Lt, R, H)
+        ctx.share = meta.get("share")
         ctx.shapes = (word.shape, pos.shape, typ.shape)
         ctx.needs = [t is not None and t.requires_grad for t in (word, pos, typ, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b)]
         return out.view(B, Ltot, H)
@@ -390,10 +391,22 @@ class InputEmbedFn(torch.autograd.Function):
         dg, db = torch.zeros(H, **f32), torch.zeros(H, **f32)
         dz, _ = hip.layernorm_bwd(dout, z, mean, rstd, lnw, dg, db, None, rows_per_group=Lt,
                                   group_stride=Ltot, row_offset=0, y_drop=drop_t)
-        dword = torch.zeros(ctx.shapes[0], **f32)
+        # The word table (86 051 x 768 f32 = 264 MB) is looked up twice per forward pass (text ids, tag
+        # ids).  Both backward calls scatter into ONE zero-filled buffer (meta["share"], created per
+        # forward pass by the backbone): the second call returns no gradient of its own, which saves
+        # a 264-MB fill and the 0.8-GB add autograd would use to sum two dense gradients.
+        share = ctx.share
+        dword = share.get("dword") if share is not None else None
+        first = dword is None
+        if first:
+            dword = torch.zeros(ctx.shapes[0], **f32)
+            if share is not None:
+                share["dword"] = dword
         dpos = torch.zeros(ctx.shapes[1], **f32)
         dtyp = torch.zeros(ctx.shapes[2], **f32)
         hip.embed_bwd(idf, pof, tyf, dz, dword, dpos, dtyp)
+        if not first:
+            dword = None
         gi_w = gi_b = gi_lw = gi_lb = None
         if ctx.img is not None:
             fb, zi, mi, ri, g, drop_i, D = ctx.img
@@ -407,7 +420,7 @@ class InputEmbedFn(torch.autograd.Function):
             gi_w, gi_b = dw[:, :D].contiguous(), dbias
         outs = [dword, dpos, dtyp, dg, db, gi_w, gi_b, gi_lw, gi_lb]
         outs = [o if need else None for o, need in zip(outs, ctx.needs)]
-        ctx.txt = ctx.img = None
+        ctx.txt = ctx.img = ctx.share = None
         return (None, None, None, None, None) + tuple(outs)
 
 

@@ -82,8 +82,9 @@ class BertEmbeddings(nn.Module):
         return embed_inputs(self, input_ids, token_type_ids, position_ids, None, None)
 
 
-def embed_inputs(emb, input_ids, token_type_ids, position_ids, img_feats, owner):
-    """Shared driver: `owner` is the backbone holding img_embedding / LayerNorm / dropout."""
+def embed_inputs(emb, input_ids, token_type_ids, position_ids, img_feats, owner, share=None):
+    """Shared driver: `owner` is the backbone holding img_embedding / LayerNorm / dropout.  share: a
+    dict common to the embedding calls of one forward pass (see InputEmbedFn.backward)."""
     L = input_ids.size(1)
     if position_ids is None:
         position_ids = torch.arange(L, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
@@ -91,7 +92,7 @@ def embed_inputs(emb, input_ids, token_type_ids, position_ids, img_feats, owner)
         token_type_ids = torch.zeros_like(input_ids)
     cache = emb.__dict__.setdefault("_img_cache", engine.WeightCache())
     meta = dict(eps=emb.LayerNorm.variance_epsilon, training=emb.training, p=emb.dropout.p, cache=cache,
-                use_img_ln=False, img_eps=1e-12)
+                use_img_ln=False, img_eps=1e-12, share=share)
     img_w = img_b = ln_w = ln_b = None
     if img_feats is not None:
         img_w, img_b = owner.img_embedding.weight, owner.img_embedding.bias

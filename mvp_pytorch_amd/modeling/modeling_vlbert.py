@@ -229,8 +229,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             token_type_ids_b = torch.zeros_like(input_ids_b)
         mask_a = additive_mask(attention_mask_a)
         mask_b = additive_mask(attention_mask_b)
-        xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
-        xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self)
+        share = {}   # one word-table gradient buffer for both lookups of this forward pass
+        xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self, share)
+        xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self, share)
         hint_a = hint_b = None
         if self.txt_encoder.unpad is True or (self.txt_encoder.unpad == "train" and self.training):
             # the valid-row counts of both uni-modal passes in ONE device->host copy, issued before any
