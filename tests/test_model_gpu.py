@@ -311,6 +311,27 @@ def test_finetune_models_unpadded_two_streams_equal_padded_one_stream(dev):
         assert worst[0] < 2e-3
 
 
+def test_single_stream_unpadded_equals_padded(dev):
+    """BertImgForPreTraining (single-stream backbone, interior padding between text and regions) in
+    training mode: row-packed execution against the padded one."""
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_text_seq_length=16)
+    dims = dict(B=9, T=16, P=0, G=4, R=7)
+    b = {k: v.to(dev) for k, v in synthetic_batch(dims, cfg, 51, single_stream=True).items()}
+    got = {}
+    for unpad in (True, False):
+        model, _ = _build("BertImgForPreTraining", cfg, 29, dev, train=True)
+        model.bert.encoder.unpad = "train" if unpad else False
+        o = model(input_ids=b["input_ids"], token_type_ids=b["segment_ids"], attention_mask=b["input_mask"],
+                  masked_lm_labels=b["lm_label_ids"], next_sentence_label=b["is_next"], img_feats=b["img_feats"])
+        o[0].backward()
+        got[unpad] = (o[0].detach(), o[3].detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.allclose(got[True][0], got[False][0], rtol=2e-4) and torch.allclose(got[True][1], got[False][1], rtol=2e-4)
+    worst = max((_rel(got[True][2][n], got[False][2][n]), n) for n in got[True][2] if got[False][2][n].norm() > 1e-6)
+    print("single-stream unpadded vs padded: losses", got[True][0].item(), got[False][0].item(), "worst gradient difference", worst)
+    assert worst[0] < 2e-3
+
+
 def test_wra_device_path_equals_host_path(dev):
     """wra_sample_on_device (fixed shapes, no host round trip) against the host-index version of
     vl:1553-1596 with the same draws, forward and gradient; includes samples without phrases."""
