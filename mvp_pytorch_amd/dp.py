@@ -36,6 +36,7 @@ class GradSync:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []        # dicts: flat, items [(param, offset, numel)], pending, work
         self.where = {}          # param -> bucket index
+        self.span = {}           # param -> (offset, numel, address of its view)
         cap = max(1, int(bucket_mb * (1 << 20) // 4))
         cur, cur_n = [], 0
         for p in reversed(self.params):
@@ -61,8 +62,10 @@ class GradSync:
         idx = len(self.buckets)
         self.buckets.append(dict(flat=torch.zeros(n, device=p0.device, dtype=torch.float32), items=items,
                                  pending=0, work=None, streams=set()))
-        for p, _, _ in items:
+        flat = self.buckets[-1]["flat"]
+        for p, off, n in items:
             self.where[p] = idx
+            self.span[p] = (off, n, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
@@ -89,9 +92,9 @@ class GradSync:
             return
         idx = self.where[p]
         b = self.buckets[idx]
-        if p.grad.data_ptr() != b["flat"][self._offset(p)].data_ptr():
+        off, n, ptr = self.span[p]
+        if p.grad.data_ptr() != ptr:
             # autograd replaced the view (e.g. dtype change): copy into the bucket, re-attach
-            off, n = self._span(p)
             b["flat"][off:off + n].copy_(p.grad.reshape(-1))
             p.grad = b["flat"][off:off + n].view_as(p)
         if p in self._ready:
@@ -112,15 +115,6 @@ class GradSync:
             if self.overlap:
                 while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
                     self._launch(self._next)
-
-    def _span(self, p):
-        for q, off, n in self.buckets[self.where[p]]["items"]:
-            if q is p:
-                return off, n
-        raise KeyError
-
-    def _offset(self, p):
-        return self._span(p)[0]
 
     def _launch(self, idx):
         b = self.buckets[idx]
