@@ -30,7 +30,8 @@ BASE_CFG = dict(vocab_size=86051, only_word_size=30522, hidden_size=768, num_hid
                 img_layer_norm_eps=1e-12, num_contrast_classes=2, qa_answer_size=10,
                 max_position_embeddings=512, type_vocab_size=2, hidden_act="gelu",
                 initializer_range=0.02, loss_type="ce", num_labels=2,
-                hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+                hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                max_phrases=5)   # the data pipeline's --max_phrases (run_pretrain_ml.py): bounds the WRA phrase grid
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 

@@ -512,38 +512,44 @@ def get_pos_neg_sims(sims, text_index, img_index, draws=None):
     return pos, neg
 
 
-def wra_sample_on_device(seq32, phrase_index, img_index, text_len, draws=None):
+def wra_sample_on_device(seq, phrase_index, img_index, text_len, draws=None, max_phrases=None):
     """The phrase_mod='sample' branch of vl:1285-1300 + get_pos_neg_sims (vl:1553-1596) with every
     shape fixed by the tensor shapes — no `.tolist()`, no host loops, no device->host copy: the
     host version costs ~2 ms of Python per 256-pair step during which the GPU queue runs dry.
-    Phrase rows are the text rows [p0, p1) (all `text_len` text rows are scored and the others
-    masked), region rows the `Lj - text_len` rows from i0.  The random draws (one of the top-3
-    regions per phrase, vl:1547-1549; one other image per sample, vl:1572-1573) come from the device
-    generator: same distributions as the reference, different stream.  draws: optional
-    (pos_pick [B, text_len], neg_pick [B, text_len], neg_img [B]) for tests.
+    Phrase rows are rows [p0, p1) of the joint sequence, gathered into a [B, Pw, H] grid with
+    Pw = max_phrases (config.max_phrases, the data pipeline's --max_phrases) or, when that is not
+    known, text_len; region rows the `Lj - text_len` rows from i0.  Only the gathered rows are
+    converted to f32 and normalised.  The random draws (one of the top-3 regions per phrase,
+    vl:1547-1549; one other image per sample, vl:1572-1573) come from the device generator: same
+    distributions as the reference, different stream.  draws: optional (pos_pick [B, Pw],
+    neg_pick [B, Pw], neg_img [B]) for tests, pick j belonging to phrase row p0 + j.
     -> pos_sims [B], neg_sims [B] (0 where a sample has no phrase, as the reference)."""
-    B, Lj, H = seq32.shape
-    dev = seq32.device
+    B, Lj, H = seq.shape
+    dev = seq.device
     Rw = Lj - text_len
+    Pw = int(max_phrases) if max_phrases else text_len
     p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
-    ar_t = torch.arange(text_len, device=dev)
-    valid_p = (ar_t[None, :] >= p0[:, None]) & (ar_t[None, :] < p1[:, None])            # [B, La]
+    if max_phrases:
+        torch._assert_async(((p1 - p0) <= Pw).all(), "a sample has more phrases than config.max_phrases")
+    ar_p = torch.arange(Pw, device=dev)
+    rows_p = (p0[:, None] + ar_p[None, :]).clamp(max=Lj - 1)                              # [B, Pw]
+    valid_p = ar_p[None, :] < (p1 - p0)[:, None]
     ar_r = torch.arange(Rw, device=dev)
     rows_r = (i0[:, None] + ar_r[None, :]).clamp(max=Lj - 1)                              # [B, Rw]
     valid_r = ar_r[None, :] < (i1 - i0)[:, None]
-    txt_n = F.normalize(seq32[:, :text_len, :], p=2, dim=-1)
-    reg_n = F.normalize(seq32.gather(1, rows_r[:, :, None].expand(-1, -1, H)), p=2, dim=-1)
+    txt_n = F.normalize(seq.gather(1, rows_p[:, :, None].expand(-1, -1, H)).float(), p=2, dim=-1)
+    reg_n = F.normalize(seq.gather(1, rows_r[:, :, None].expand(-1, -1, H)).float(), p=2, dim=-1)
     if draws is None:
-        pos_pick = torch.randint(0, 3, (B, text_len), device=dev)
-        neg_pick = torch.randint(0, 3, (B, text_len), device=dev)
+        pos_pick = torch.randint(0, 3, (B, Pw), device=dev)
+        neg_pick = torch.randint(0, 3, (B, Pw), device=dev)
         neg_img = (torch.arange(B, device=dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
     else:
         pos_pick, neg_pick, neg_img = (d.to(dev) for d in draws)
-    cnt = valid_p.sum(1).clamp(min=1).to(seq32.dtype)
+    cnt = valid_p.sum(1).clamp(min=1).to(txt_n.dtype)
 
     def mean_top3(regions, rvalid, pick):
         sims = torch.bmm(txt_n, regions.transpose(1, 2)).masked_fill(~rvalid[:, None, :], float("-inf"))
-        top = sims.topk(3, dim=2)[0]                                                      # [B, La, 3]
+        top = sims.topk(3, dim=2)[0]                                                      # [B, Pw, 3]
         picked = top.gather(2, pick[:, :, None]).squeeze(2)
         return torch.where(valid_p, picked, torch.zeros_like(picked)).sum(1) / cnt
 
@@ -679,10 +685,11 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 neg_sims = get_pos_sims(hard_sequence_output, hard_phrase_index, hard_object_index)
                 valid = ((phrase_index[:, 1] - phrase_index[:, 0]) > 0) & ((hard_phrase_index[:, 1] - hard_phrase_index[:, 0]) > 0)
             elif phrase_mod == "sample":
-                seq32 = sequence_output.float()
                 if self.wra_on_device:
-                    pos_sims, neg_sims = wra_sample_on_device(seq32, phrase_index, img_index, input_ids_a.shape[1])
+                    pos_sims, neg_sims = wra_sample_on_device(sequence_output, phrase_index, img_index, input_ids_a.shape[1],
+                                                              max_phrases=getattr(self.config, "max_phrases", None))
                 else:  # host draws in the reference's order (replayable: parity tests)
+                    seq32 = sequence_output.float()
                     valid_phrases = F.normalize(mask_slice_and_stack(seq32, phrase_index), p=2, dim=-1)
                     valid_images = F.normalize(mask_slice_and_stack(seq32, img_index), p=2, dim=-1)
                     pos_sims, neg_sims = get_pos_neg_sims(valid_phrases @ valid_images.t(), phrase_index, img_index)

@@ -346,13 +346,19 @@ def test_wra_device_path_equals_host_path(dev):
     phrase_index = torch.stack([1 + n_t, 1 + n_t + n_p], 1)
     n_r = torch.randint(3, R + 1, (B,), generator=g)
     img_index = torch.stack([torch.full((B,), La), La + n_r], 1)
-    pos_grid = torch.randint(0, 3, (B, La), generator=g)
-    neg_grid = torch.randint(0, 3, (B, La), generator=g)
     neg_img = (torch.arange(B) + 1 + torch.randint(0, B - 1, (B,), generator=g)) % B
     assert (neg_img != torch.arange(B)).all()
-    flat = lambda grid: torch.cat([grid[t, phrase_index[t, 0]:phrase_index[t, 1]] for t in range(B)])  # noqa: E731
-    a = seq.to(dev).requires_grad_(True)
-    pos_d, neg_d = mv.wra_sample_on_device(a, phrase_index.to(dev), img_index.to(dev), La, draws=(pos_grid, neg_grid, neg_img))
+    for Pw in (La, 4):   # phrase grid as wide as the text, and config.max_phrases = 4
+        pos_grid = torch.randint(0, 3, (B, Pw), generator=g)
+        neg_grid = torch.randint(0, 3, (B, Pw), generator=g)
+        flat = lambda grid: torch.cat([grid[t, :int(n_p[t])] for t in range(B)])  # noqa: E731
+        a = seq.to(dev).requires_grad_(True)
+        pos_d, neg_d = mv.wra_sample_on_device(a, phrase_index.to(dev), img_index.to(dev), La, draws=(pos_grid, neg_grid, neg_img),
+                                               max_phrases=None if Pw == La else Pw)
+        _check_wra_against_host(mv, seq, phrase_index, img_index, flat, pos_grid, neg_grid, neg_img, a, pos_d, neg_d, g, dev, B)
+
+
+def _check_wra_against_host(mv, seq, phrase_index, img_index, flat, pos_grid, neg_grid, neg_img, a, pos_d, neg_d, g, dev, B):
     b = seq.to(dev).requires_grad_(True)
     vp = torch.nn.functional.normalize(mv.mask_slice_and_stack(b, phrase_index.to(dev)), p=2, dim=-1)
     vi = torch.nn.functional.normalize(mv.mask_slice_and_stack(b, img_index.to(dev)), p=2, dim=-1)
