@@ -199,6 +199,12 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   }
   RUN(mvptr_gemm_nt(bufQ, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufD, H, dx,
                     nullptr, H, nullptr, nullptr, stream));
+  // largest problem first: the exposed atomic write-out at the end of the launch is then the small one's
+  if (nwg == 2 && (int64_t)wg[0].N * wg[0].K < (int64_t)wg[1].N * wg[1].K) {
+    const mvptr_tn_problem t = wg[0];
+    wg[0] = wg[1];
+    wg[1] = t;
+  }
   if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
   return MVPTR_OK;
 }
