@@ -228,6 +228,34 @@ def kernel_roofline(dev, dims, cfg, batch=None):
                                    traffic=(t_nt or {}).get("bytes_per_launch")))
 
 
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL) as
+    CHILDREN before this process has touched the GPU, relay rank 0's JSON line, exit with the worst
+    return code.  (Replacing this process by exec after a HIP call is forbidden on the pool; a plain
+    child process per rank is also what torch.distributed.run does.)"""
+    import socket
+    import subprocess
+    n = args.gpus
+    visible = torch.cuda.device_count()   # counts devices without initialising HIP
+    if visible < n and "MVPTR_BENCH_DEVICE" not in os.environ:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, visible))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,10 +263,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fixed-length", action="store_true", help="every token/region slot valid")
+    ap.add_argument("--fixed-length", action="store_true", help="every token/region slot valid is the timed workload")
+    ap.add_argument("--model", choices=["bi", "single"], default="bi",
+                    help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            _spawn_ranks(args)   # never returns
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

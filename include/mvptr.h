@@ -70,6 +70,13 @@ typedef struct {
 int mvptr_query(int what, int64_t* out);
 const char* mvptr_last_error(void);
 
+/* Diagnostic knobs (kernel-configuration overrides used by tools/ for A/B measurements):
+ * MVPTR_GEMM_CFG, MVPTR_GEMM_TN, MVPTR_NT_EXP, MVPTR_TN_GROUP, MVPTR_LN_GRID, MVPTR_GEMM_DELAY.
+ * The environment variables of the same names are read ONCE per process (first kernel launch that
+ * looks one up) and every active one is reported on stderr; this call overrides a knob afterwards
+ * (value "" = default).  Not part of the reference's surface; not thread-safe against launches. */
+int mvptr_set_knob(const char* name, const char* value);
+
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue; A,B bf16, f32 accumulate (MFMA 16x16x32).
  * Replaces nn.Linear forward (y = x W^T + b): modeling_bert.py:348 (BertSelfOutput.dense),
  * :395 (BertIntermediate.dense + gelu :142-148), :408 (BertOutput.dense), Q/K/V projections

@@ -36,6 +36,21 @@ void mvptr_set_error(const char* fmt, ...);
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
+// Diagnostic knobs.  The environment is read ONCE, when the first knob is looked up (and every
+// active knob is reported on stderr): a stray variable cannot silently change kernel selection
+// from launch to launch.  Tools that A/B configurations inside one process use mvptr_set_knob().
+struct MvptrKnobs {
+  char gemm_cfg[16];   // MVPTR_GEMM_CFG   force a gemm_nt tile configuration
+  char gemm_tn[16];    // MVPTR_GEMM_TN    force a gemm_tn configuration
+  int nt_exp;          // MVPTR_NT_EXP     gemm_nt experiment flags
+  int tn_group;        // MVPTR_TN_GROUP   0: one launch per weight-gradient problem
+  int ln_grid;         // MVPTR_LN_GRID    partial rows of the LayerNorm backward pass (0 = default)
+  int delay[3];        // MVPTR_GEMM_DELAY "cycles[,lo,hi]"
+  unsigned long long stamps;  // MVPTR_GEMM_STAMPS (diagnostic builds)
+};
+const MvptrKnobs& mvptr_knobs();
+
+// ---------------------------------------------------------------------------------------------
 // device helpers
 __device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
 __device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }

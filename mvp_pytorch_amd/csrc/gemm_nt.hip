@@ -739,8 +739,8 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   // short-K, narrow GEMMs whose 256x256 tiles would need more than one round of the 256 CUs
   // (attention-output projection on the big batch), where the epilogue overlap of "w4" wins.
   // MVPTR_GEMM_CFG overrides the choice.
-  const char* env = getenv("MVPTR_GEMM_CFG");
-  if (env != nullptr && env[0] != 0) {
+  const char* env = mvptr_knobs().gemm_cfg;
+  if (env[0] != 0) {
     const size_t n = strlen(env);
     if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128": 128x128, 4 waves
@@ -792,22 +792,13 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.drop = make_dropdev(drop);
   a.stamps = nullptr;
   a.delay_cycles = 0;
-  a.exp_flags = 0;
-  {
-    const char* xp = getenv("MVPTR_NT_EXP");
-    if (xp != nullptr) a.exp_flags = atoi(xp);
-  }
-  a.delay_lo = 256;
-  a.delay_hi = 512;
-  {
-    const char* dp = getenv("MVPTR_GEMM_DELAY");  // "cycles[,lo,hi]"
-    if (dp != nullptr) sscanf(dp, "%d,%d,%d", &a.delay_cycles, &a.delay_lo, &a.delay_hi);
-  }
+  const MvptrKnobs& kn = mvptr_knobs();
+  a.exp_flags = kn.nt_exp;
+  a.delay_cycles = kn.delay[0];
+  a.delay_lo = kn.delay[1];
+  a.delay_hi = kn.delay[2];
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
-  {
-    const char* sp = getenv("MVPTR_GEMM_STAMPS");
-    if (sp != nullptr) a.stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
-  }
+  a.stamps = (unsigned long long*)kn.stamps;
 #endif
   a.tiles_m = a.tiles_n = 0;  // set per tile configuration in launch_bk
   const int esz = (epilogue == MVPTR_EPI_F32) ? 4 : 2;

@@ -362,8 +362,8 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
     plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c]);
   }
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
-  const char* env = getenv("MVPTR_GEMM_TN");
-  if (env != nullptr) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : 0;
+  const char* env = mvptr_knobs().gemm_tn;
+  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : 0;
   const TnPlan pl = plans[pick];
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
@@ -401,11 +401,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
     g.base[i + 1] = g.base[count];
   }
 #ifdef MVPTR_TIMELINE_BUILD
-  {
-    const char* sp = getenv("MVPTR_GEMM_STAMPS");
-    if (sp != nullptr)
-      for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)strtoull(sp, nullptr, 0);
-  }
+  for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
@@ -423,8 +419,7 @@ extern "C" int mvptr_gemm_tn_multi(const mvptr_tn_problem* probs, int count, voi
   }
   // problems are grouped while they share M (one split plan per launch); MVPTR_TN_GROUP=0 issues
   // them one by one (A/B knob)
-  const char* genv = getenv("MVPTR_TN_GROUP");
-  const int max_group = (genv != nullptr && genv[0] == '0') ? 1 : MVPTR_TN_MAX_GROUP;
+  const int max_group = (mvptr_knobs().tn_group == 0) ? 1 : MVPTR_TN_MAX_GROUP;
   int i = 0;
   while (i < count) {
     int j = i + 1;

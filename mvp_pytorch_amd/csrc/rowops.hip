@@ -647,6 +647,54 @@ void mvptr_set_error(const char* fmt, ...) {
 
 extern "C" const char* mvptr_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------------------------------------
+// diagnostic knobs (see common.h)
+namespace {
+MvptrKnobs g_knobs;
+bool knob_assign(const char* name, const char* value) {
+  const char* v = value ? value : "";
+  if (!strcmp(name, "MVPTR_GEMM_CFG")) snprintf(g_knobs.gemm_cfg, sizeof(g_knobs.gemm_cfg), "%s", v);
+  else if (!strcmp(name, "MVPTR_GEMM_TN")) snprintf(g_knobs.gemm_tn, sizeof(g_knobs.gemm_tn), "%s", v);
+  else if (!strcmp(name, "MVPTR_NT_EXP")) g_knobs.nt_exp = atoi(v);
+  else if (!strcmp(name, "MVPTR_TN_GROUP")) g_knobs.tn_group = (v[0] == 0) ? 1 : atoi(v);
+  else if (!strcmp(name, "MVPTR_LN_GRID")) g_knobs.ln_grid = atoi(v);
+  else if (!strcmp(name, "MVPTR_GEMM_DELAY")) {
+    g_knobs.delay[0] = 0; g_knobs.delay[1] = 256; g_knobs.delay[2] = 512;
+    sscanf(v, "%d,%d,%d", &g_knobs.delay[0], &g_knobs.delay[1], &g_knobs.delay[2]);
+  } else if (!strcmp(name, "MVPTR_GEMM_STAMPS")) g_knobs.stamps = strtoull(v, nullptr, 0);
+  else return false;
+  return true;
+}
+bool knobs_from_env() {
+  memset(&g_knobs, 0, sizeof(g_knobs));
+  g_knobs.tn_group = 1;
+  g_knobs.delay[1] = 256;
+  g_knobs.delay[2] = 512;
+  static const char* names[] = {"MVPTR_GEMM_CFG", "MVPTR_GEMM_TN", "MVPTR_NT_EXP", "MVPTR_TN_GROUP",
+                                "MVPTR_LN_GRID", "MVPTR_GEMM_DELAY", "MVPTR_GEMM_STAMPS"};
+  for (const char* n : names) {
+    const char* v = getenv(n);
+    if (v != nullptr && v[0] != 0) {
+      knob_assign(n, v);
+      fprintf(stderr, "[mvptr] diagnostic knob %s=%s is active\n", n, v);
+    }
+  }
+  return true;
+}
+}  // namespace
+const MvptrKnobs& mvptr_knobs() {
+  static const bool once = knobs_from_env();  // C++11: thread-safe, runs once
+  (void)once;
+  return g_knobs;
+}
+// Tools only (A/B of kernel configurations inside one process); not thread-safe against launches.
+extern "C" int mvptr_set_knob(const char* name, const char* value) {
+  if (!name) MVPTR_FAIL(MVPTR_BAD_ARG, "set_knob: NULL name");
+  (void)mvptr_knobs();
+  if (!knob_assign(name, value)) MVPTR_FAIL(MVPTR_BAD_ARG, "set_knob: unknown knob '%s'", name);
+  return MVPTR_OK;
+}
+
 extern "C" int mvptr_query(int what, int64_t* out) {
   if (!out) MVPTR_FAIL(MVPTR_BAD_ARG, "query: out is NULL");
   if (what == MVPTR_Q_ABI_VERSION) {
@@ -696,12 +744,9 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
 }
 
 static int ln_bwd_grid_cap() {
-  static int cap = 0;
-  if (cap == 0) {
-    const char* e = getenv("MVPTR_LN_GRID");  // tuning knob: partial rows (= blocks) of the backward pass
-    cap = (e != nullptr && atoi(e) > 0) ? atoi(e) : 512;  // 512 partial rows: 50 vs 55 us at M = 38 k (1024), 61 us (256)
-    if (cap > 1024) cap = 1024;
-  }
+  const int k = mvptr_knobs().ln_grid;  // tuning knob: partial rows (= blocks) of the backward pass
+  int cap = k > 0 ? k : 512;  // 512 partial rows: 50 vs 55 us at M = 38 k (1024), 61 us (256)
+  if (cap > 1024) cap = 1024;
   return cap;
 }
 

@@ -3,89 +3,129 @@ gradients averaged with bucketed all-reduce on RCCL (backend 'nccl' on ROCm) ove
 overlapped with the backward pass.
 
 Replaces what DeepSpeed ZeRO-2 / DDP did implicitly for the reference
-(oscar/run_pretrain_ml.py:406-418; oscar/tmp_config.json:11-20 — reduce buckets of 2e8 elements,
-overlap_comm).  The in-batch contrastive / hard-negative step stays rank-local exactly as in
-the reference (no feature all-gather, modeling_vlbert.py:525-534), so the gradient all-reduce is
-the only per-step collective.
+(oscar/run_pretrain_ml.py:406-418; oscar/tmp_config.json:11-20 — fp16 gradients, reduce buckets of
+2e8 elements, overlap_comm).  The in-batch contrastive / hard-negative step stays rank-local exactly
+as in the reference (no feature all-gather, modeling_vlbert.py:525-534), so the gradient all-reduce
+is the only per-step collective.
 
 Design
   * gradients live in flat f32 bucket buffers (>= `bucket_mb` MiB each, filled in reverse parameter
     order = the order backward finishes them); every p.grad is a view into its bucket, so autograd
     accumulates straight into the communication buffer and nothing is copied before or after;
-  * a post-accumulate-grad hook per parameter counts readiness; when the last expected gradient of
-    a bucket has landed, its all-reduce is launched asynchronously on RCCL's stream while the
-    remaining backward kernels keep running (xGMI is point-to-point, 7 links x ~153 GB/s: a ring
-    all-reduce of S bytes costs ~2*(7/8)*S / link rate, ~11 ms for the 0.98 GB of f32 gradients of
-    BiBertImgForPreTraining if not overlapped);
-  * parameters that produced no gradient in the previous step (qa_head when qa_ans is None,
-    modeling_vlbert.py:1184) are not waited for;
-  * buckets are launched strictly in index order (a ready bucket waits for its predecessors, as
-    DDP does): which parameters receive a gradient can differ between ranks (a shard without a
-    masked tag row skips half_mlm), and collectives on one communicator must be issued in the
-    same order everywhere; finish() launches whatever is left, again in index order.
+  * HOT and COLD buckets.  A parameter is hot once ANY rank has produced a gradient for it (the
+    used-parameter bitmap below is all-reduced, so every rank holds the same hot set).  Hot buckets
+    hold hot parameters only: a post-accumulate-grad hook per parameter counts readiness and, when the
+    last one of a bucket has landed, its all-reduce is launched asynchronously while the remaining
+    backward kernels keep running.  Parameters that have never produced a gradient (qa_head when
+    qa_ans is None, modeling_vlbert.py:1184; a data-conditional head before its first use) sit in
+    cold buckets, which are only reduced in finish() — so a parameter that produces its FIRST
+    gradient in any later step is still exchanged correctly (it is promoted to hot afterwards), and a
+    never-used parameter cannot hold back the overlap of the others.  In the first step nothing is
+    known yet and every bucket is reduced in finish();
+  * buckets are launched strictly in index order on every rank (a ready bucket waits for its
+    predecessors, as DDP does): which hot parameters receive a gradient in a given step can differ
+    between ranks (a shard without a masked tag row skips half_mlm), and collectives on one
+    communicator must be issued in the same order everywhere; finish() launches whatever is left;
+  * `comm_dtype=torch.bfloat16` (default under RCCL): each bucket is rounded to bf16 for the wire
+    and the averaged result converted back into the f32 bucket — half the xGMI bytes (0.49 instead of
+    0.98 GB per step for BiBertImgForPreTraining).  The reference exchanged fp16 gradients under
+    DeepSpeed; bf16 keeps f32's exponent range, so no loss scaling is involved;
+  * one backward per zero_grad(), or gradient accumulation inside `with sync.no_sync():` for all but
+    the last backward — a second backward outside no_sync() would add into buckets that are already
+    being reduced and raises.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S bytes moves 2*(7/8)*S
+per GPU at the per-link rate, ~5.6 ms for 0.49 GB on one ring if it were not overlapped (RCCL runs
+several rings/trees over the links in parallel; the multi-GPU curve of this design has not been
+measured by the builder: no multi-GPU box was available).
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True):
+    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="auto"):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.buckets = []        # dicts: flat, items [(param, offset, numel)], pending, work
-        self.where = {}          # param -> bucket index
-        self.span = {}           # param -> (offset, numel, address of its view)
-        cap = max(1, int(bucket_mb * (1 << 20) // 4))
-        cur, cur_n = [], 0
-        for p in reversed(self.params):
-            if cur and cur_n + p.numel() > cap:
-                self._close(cur, cur_n)
-                cur, cur_n = [], 0
-            cur.append((p, cur_n, p.numel()))
-            cur_n += p.numel()
-        if cur:
-            self._close(cur, cur_n)
-        self._expected = None     # params that produced a gradient in the previous step
-        self._ready = set()
-        self._launched = []
+        self.index = {p: i for i, p in enumerate(self.params)}
+        self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
+        if comm_dtype == "auto":
+            comm_dtype = torch.bfloat16 if backend == "nccl" else torch.float32
+        self.comm_dtype = comm_dtype
+        self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
+        self._accumulating = False
+        self._rebuild = False
+        self._build()
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
         self.zero_grad()
 
-    def _close(self, items, n):
+    # ------------------------------------------------------------------ bucket layout
+    def _build(self):
+        """(Re)build the buckets: hot parameters in reverse order (early-launchable), then cold ones."""
+        self.buckets = []        # dicts: flat, items [(param, offset, numel)], hot, pending, work, ...
+        self.where = {}          # param -> bucket index
+        self.span = {}           # param -> (offset, numel, address of its view)
+        hot = [p for p in reversed(self.params) if self._hot is not None and p in self._hot]
+        cold = [p for p in reversed(self.params) if self._hot is None or p not in self._hot]
+        for group, is_hot in ((hot, True), (cold, False)):
+            cur, cur_n = [], 0
+            for p in group:
+                if cur and cur_n + p.numel() > self.cap:
+                    self._close(cur, cur_n, is_hot)
+                    cur, cur_n = [], 0
+                cur.append((p, cur_n, p.numel()))
+                cur_n += p.numel()
+            if cur:
+                self._close(cur, cur_n, is_hot)
+        self.n_hot = sum(1 for b in self.buckets if b["hot"])
+
+    def _close(self, items, n, is_hot):
         p0 = items[0][0]
         idx = len(self.buckets)
-        self.buckets.append(dict(flat=torch.zeros(n, device=p0.device, dtype=torch.float32), items=items,
-                                 pending=0, work=None, streams=set()))
-        flat = self.buckets[-1]["flat"]
-        for p, off, n in items:
+        flat = torch.zeros(n, device=p0.device, dtype=torch.float32)
+        self.buckets.append(dict(flat=flat, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set()))
+        for p, off, k in items:
             self.where[p] = idx
-            self.span[p] = (off, n, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
+            self.span[p] = (off, k, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
         """Zero the bucket buffers and (re)attach every p.grad as a view into its bucket.  Use this
-        instead of optimizer.zero_grad() when a GradSync is active."""
+        instead of optimizer.zero_grad() when a GradSync is active.  Re-lays the buckets first when
+        the hot set changed in the exchange that just finished."""
+        if self._rebuild:
+            self._rebuild = False
+            for p in self.params:
+                p.grad = None
+            self._build()
         for b in self.buckets:
             b["flat"].zero_()
-            b["work"] = None
+            b["work"] = b["wire"] = None
             b["streams"] = set()
-            n_exp = 0
             for p, off, n in b["items"]:
                 view = b["flat"][off:off + n].view_as(p)
                 if p.grad is None or p.grad.data_ptr() != view.data_ptr():
                     p.grad = view
-                if self._expected is None or p in self._expected:
-                    n_exp += 1
-            b["pending"] = n_exp
+            b["pending"] = len(b["items"])
         self._ready = set()
-        self._launched = []
         self._next = 0            # buckets [0, _next) have been launched this step
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context only accumulate into the
+        buckets (no readiness counting, no launches); the last backward goes outside it."""
+        self._accumulating = True
+        try:
+            yield
+        finally:
+            self._accumulating = False
 
     def _hook(self, p):
         if self.world == 1:
@@ -97,24 +137,22 @@ class GradSync:
             # autograd replaced the view (e.g. dtype change): copy into the bucket, re-attach
             b["flat"][off:off + n].copy_(p.grad.reshape(-1))
             p.grad = b["flat"][off:off + n].view_as(p)
-        if p in self._ready:
-            return
-        self._ready.add(p)
         if p.grad.is_cuda:
             # the gradient was produced on the stream current in this hook (sub-networks may run on a
             # side stream, engine.side_stream): remember which streams fed this bucket
             b["streams"].add(torch.cuda.current_stream(p.grad.device))
+        if self._accumulating:
+            return
         if idx < self._next:
-            # its bucket is already being reduced in place: the parameter never produced a gradient
-            # before, so nobody was waiting for it.  Failing loudly beats a silently unsynchronised
-            # gradient; construct GradSync(..., overlap=False) for models whose set of used
-            # parameters grows during training.
-            raise RuntimeError("GradSync: a parameter produced its first gradient after its bucket was launched")
-        if self._expected is None or p in self._expected:
-            b["pending"] -= 1
-            if self.overlap:
-                while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
-                    self._launch(self._next)
+            raise RuntimeError("GradSync: a gradient arrived for a bucket that is already being reduced — run one "
+                               "backward per zero_grad(), or wrap all but the last backward in `with sync.no_sync():`")
+        if p in self._ready:
+            return                # the same parameter used twice in one graph fires once; be tolerant
+        self._ready.add(p)
+        b["pending"] -= 1
+        if self.overlap and b["hot"]:
+            while self._next < self.n_hot and self.buckets[self._next]["pending"] == 0:
+                self._launch(self._next)
 
     def _launch(self, idx):
         b = self.buckets[idx]
@@ -127,8 +165,9 @@ class GradSync:
             for st in b["streams"]:
                 if st != cur:
                     cur.wait_stream(st)   # everything queued there so far includes the gradients
-        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
-        self._launched.append(idx)
+        wire = b["flat"] if self.comm_dtype == torch.float32 else b["flat"].to(self.comm_dtype)
+        b["wire"] = wire
+        b["work"] = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
         self._next = idx + 1
 
     def __call__(self):
@@ -146,17 +185,28 @@ class GradSync:
         used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             b["work"].wait()
+            if b["wire"] is not b["flat"]:
+                if b["wire"].is_cuda:
+                    b["wire"].record_stream(torch.cuda.current_stream(b["wire"].device))
+                b["flat"].copy_(b["wire"])          # bf16 -> f32, ordered after the collective by wait()
             if not self._avg:
                 b["flat"].mul_(1.0 / self.world)
-        # wait for every parameter that has EVER produced a gradient on this rank: one that is missing
-        # in some step only delays launches to finish(), it cannot reorder them
-        self._expected = set(self._ready) if self._expected is None else (self._expected | self._ready)
+            b["wire"] = None
+        used_work.wait()
+        used = used.tolist()
         # parameters no rank produced a gradient for keep grad = None, as under DDP with
         # find_unused_parameters=True (run_pretrain_ml.py:415-418): the optimizer skips them
-        used_work.wait()
-        for p, u in zip(self.params, used.tolist()):
+        for p, u in zip(self.params, used):
             if not u:
                 p.grad = None
+        # hot set = every parameter that has EVER produced a gradient on any rank (identical on all
+        # ranks: it is derived from the all-reduced bitmap only).  One that is missing in some step
+        # only delays launches to finish(); a newly used one moves its bucket layout at the next step.
+        now = {p for p, u in zip(self.params, used) if u}
+        hot = now if self._hot is None else (self._hot | now)
+        if hot != self._hot:
+            self._hot = hot
+            self._rebuild = True
 
 
 def all_reduce_metrics(values, device):

@@ -42,18 +42,49 @@ def pad8(n):
 
 
 class WeightCache:
-    """bf16 working copies of a group of f32 parameters, refreshed when any version changes."""
+    """bf16 working copies of a group of f32 parameters.
+
+    Inference (grad mode off, or frozen parameters): refreshed when a parameter's (data_ptr, version
+    counter) changes.  In-place updates through `.data` do NOT bump the version counter (the
+    reference's own AdamW does `p.data.addcdiv_`, optimization.py:176,187; so do EMA / master-weight
+    copies), so while the parameters are being trained — grad mode on and any of them requires grad —
+    the copies are rebuilt at EVERY forward pass: the weights change every step anyway and the fused
+    cast of an encoder stack is one ~0.1 ms launch.  For inference after an update through `.data`
+    call invalidate_weight_caches(model)."""
 
     def __init__(self):
         self._key = None
         self.t = {}
 
-    def stale(self, params):
+    def stale(self, params, force=None):
+        if force is None:
+            force = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != self._key:
+        if force or key != self._key:
             self._key = key
             return True
         return False
+
+    def invalidate(self):
+        self._key = None
+
+
+def invalidate_weight_caches(model):
+    """Drop every bf16 working copy held by `model`'s modules (they are rebuilt at the next forward
+    pass).  Needed only in inference after parameters were modified through `.data` / a raw pointer,
+    which PyTorch's version counters do not see."""
+    n = 0
+    for m in model.modules():
+        for v in list(m.__dict__.values()):
+            if isinstance(v, WeightCache):
+                v.invalidate()
+                n += 1
+            elif isinstance(v, PackList):
+                v.group.cache.invalidate()
+                for pk in v:
+                    pk.cache.invalidate()
+                n += 1
+    return n
 
 
 def cast_weight(w, want_t=True, kpad=None):

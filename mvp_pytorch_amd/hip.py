@@ -21,7 +21,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
+    "mvptr_query", "mvptr_last_error", "mvptr_set_knob", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
@@ -77,6 +77,7 @@ def load():
     lib.mvptr_layer_workspace_bytes.argtypes = [POINTER(LayerDesc)]
     P, I64, I, F = c_void_p, c_int64, c_int, c_float
     lib.mvptr_query.argtypes = [I, POINTER(c_int64)]
+    lib.mvptr_set_knob.argtypes = [c_char_p, c_char_p]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
@@ -133,6 +134,11 @@ def make_dropout(p, seed):
 
 def _dp(d):
     return ctypes.byref(d) if d is not None else None
+
+
+def set_knob(name, value=""):
+    """Diagnostic override of a kernel-configuration knob (tools/ only; see mvptr.h)."""
+    _check(load().mvptr_set_knob(name.encode(), str(value).encode()))
 
 
 def query(what):

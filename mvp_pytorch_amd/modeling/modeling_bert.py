@@ -205,6 +205,17 @@ class BertLMPredictionHead(nn.Module):
 
     def loss_and_scores(self, hidden_states, labels):
         """Fused decoder + CrossEntropyLoss(ignore_index=-1): (mean loss, f32 logits [M,V])."""
+        if hidden_states.reshape(-1, hidden_states.shape[-1]).shape[0] == 0:
+            # no scored row in this batch / data-parallel shard (the dataset masks 15 % of the tokens
+            # with no guarantee of one per shard, oscar_tsv4.py:782-893): a zero that is still connected
+            # to every parameter of the head, so each rank produces the same set of gradients (the
+            # reference's CrossEntropyLoss over zero rows would give NaN; a skipped shard must not
+            # poison the averaged gradient)
+            zero = hidden_states.float().sum() * 0.0
+            for p in (self.transform.dense.weight, self.transform.dense.bias, self.transform.LayerNorm.weight,
+                      self.transform.LayerNorm.bias, self.decoder.weight, self.bias):
+                zero = zero + p.float().sum() * 0.0
+            return zero, torch.zeros((0, self.decoder.weight.shape[0]), dtype=torch.float32, device=hidden_states.device)
         h = self.transform(hidden_states)
         return engine.DecoderCEFn.apply(h.reshape(-1, h.shape[-1]), self.decoder.weight, self.bias,
                                         labels.reshape(-1), self._cache)

@@ -260,6 +260,22 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             vis = self.vis_encoder(xb, mask_b, pack_hint=hint_b)[0]
         return txt, vis, mask_a, mask_b
 
+    @staticmethod
+    def mine_hard_negatives(sim_mat, hn_mod="hard", logit=None):
+        """vl:531-542 — per text the most similar OTHER image and per image the most similar other
+        text ('hard': argmax of sim - 2 I; 'sample': one multinomial draw from softmax(logit * sim)
+        with the diagonal at -10000) -> (hard_img_index [n], hard_txt_index [n]) int64."""
+        n = sim_mat.shape[0]
+        eye = torch.eye(n, dtype=sim_mat.dtype, device=sim_mat.device)
+        if hn_mod == "hard":
+            masked = sim_mat - 2 * eye
+            return torch.max(masked, dim=1)[1], torch.max(masked, dim=0)[1]
+        if hn_mod == "sample":
+            masked = (logit * sim_mat) - 10000 * eye
+            return (torch.multinomial(F.softmax(masked, dim=1), num_samples=1).squeeze(),
+                    torch.multinomial(F.softmax(masked.t(), dim=1), num_samples=1).squeeze())
+        raise NotImplementedError
+
     def _globals(self, txt, vis):
         """vl:525-526 — f32 (feeds argmax: kept out of bf16)."""
         gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
@@ -284,19 +300,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         if encode_hn:
             n = sim_mat.shape[0]
             dev = sim_mat.device
-            if hn_mod == "hard":
-                masked = sim_mat - 2 * torch.eye(n, dtype=sim_mat.dtype, device=dev)
-                hard_img = torch.max(masked, dim=1)[1]
-                hard_txt = torch.max(masked, dim=0)[1]
-            elif hn_mod == "sample":
-                masked = (logit * sim_mat) - 10000 * torch.eye(n, dtype=sim_mat.dtype, device=dev)
-                hard_img = torch.multinomial(F.softmax(masked, dim=1), num_samples=1).squeeze()
-                hard_txt = torch.multinomial(F.softmax(masked.t(), dim=1), num_samples=1).squeeze()
-            else:
-                raise NotImplementedError
-            if getattr(self, "hard_override", None) is not None:
-                # parity-test hook: inject captured hard-negative indices
-                hard_img, hard_txt = (t.to(dev) for t in self.hard_override)
+            hard_img, hard_txt = self.mine_hard_negatives(sim_mat, hn_mod, logit)
             dice = torch.randperm(n, device=dev)
             first, second = dice[: n // 2], dice[n // 2:]
             ar = torch.arange(n, device=dev)

@@ -27,7 +27,8 @@ import torch.nn.functional as F
 class Draws:
     """Source of the three in-forward random draws; replays recorded lists when given."""
 
-    def __init__(self, randperm=None, randint3=None, choice=None, seed=0):
+    def __init__(self, randperm=None, randint3=None, choice=None, seed=0, multinomial=None):
+        self._multinomial = list(multinomial) if multinomial is not None else None
         self._randperm = list(randperm) if randperm is not None else None
         self._randint3 = list(randint3) if randint3 is not None else None
         self._choice = list(choice) if choice is not None else None
@@ -46,6 +47,14 @@ class Draws:
             assert v.numel() == n
             return v
         return torch.randint(0, 3, (n,), generator=self._gen)
+
+    def multinomial(self, probs):
+        """one draw per row of probs (vl:538,540)."""
+        if self._multinomial is not None:
+            v = torch.as_tensor(self._multinomial.pop(0), dtype=torch.long).reshape(-1)
+            assert v.numel() == probs.shape[0]
+            return v
+        return torch.multinomial(probs, num_samples=1, generator=self._gen).squeeze(1)
 
     def choice(self, options):
         if self._choice is not None:
@@ -214,8 +223,8 @@ def clip_globals(sd, txt, vis, prefix="bert"):
 def bi_bert_img_model(sd, cfg, input_ids_a, token_type_ids_a=None, attention_mask_a=None,
                       max_tag_length=None, use_b=False, input_ids_b=None, token_type_ids_b=None,
                       attention_mask_b=None, img_feats=None, encode_hn=False, draws=None,
-                      position_ids_a=None, position_ids_b=None, prefix="bert"):
-    """vl:410-609 BiBertImgModel.forward (hn_mod='hard', phrase_layer None) ->
+                      position_ids_a=None, position_ids_b=None, prefix="bert", hn_mod="hard", logit=None):
+    """vl:410-609 BiBertImgModel.forward (phrase_layer None) ->
     ((seq, pooled, hard_seq, hard_pooled), (txt, vis, sim_mat), (hard_txt_idx_full, hard_img_idx_full))."""
     txt, vis, ext_a, ext_b = bi_uni_encoders(sd, cfg, input_ids_a, token_type_ids_a, attention_mask_a,
                                              input_ids_b, token_type_ids_b, attention_mask_b, img_feats,
@@ -229,9 +238,16 @@ def bi_bert_img_model(sd, cfg, input_ids_a, token_type_ids_a=None, attention_mas
     hard_seq_out = hard_pooled = hard_txt_full = hard_img_full = None
     if encode_hn:
         n = sim.shape[0]
-        masked = sim - 2 * torch.eye(n, dtype=sim.dtype)
-        hard_img = torch.max(masked, dim=1)[1]
-        hard_txt = torch.max(masked, dim=0)[1]
+        if hn_mod == "hard":      # vl:531-534
+            masked = sim - 2 * torch.eye(n, dtype=sim.dtype)
+            hard_img = torch.max(masked, dim=1)[1]
+            hard_txt = torch.max(masked, dim=0)[1]
+        elif hn_mod == "sample":  # vl:535-540
+            masked = (logit * sim) - 10000 * torch.eye(n, dtype=sim.dtype)
+            hard_img = (draws or Draws()).multinomial(F.softmax(masked, dim=1))
+            hard_txt = (draws or Draws()).multinomial(F.softmax(masked.t(), dim=1))
+        else:
+            raise NotImplementedError
         hard_img_seq = torch.cat([txt, only_vis.index_select(0, hard_img)], dim=1)
         hard_img_mask = torch.cat([ext_a, only_vis_mask.index_select(0, hard_img)], dim=-1)
         hard_txt_seq = torch.cat([txt.index_select(0, hard_txt), only_vis], dim=1)
@@ -300,6 +316,16 @@ def get_pos_neg_sims(sims, text_index, img_index, draws):
     return torch.stack(pos), torch.stack(neg)
 
 
+def get_pos_sims(sequence_output, text_index, img_index, draws):
+    """vl:1510-1527 — per sample: its phrases against its own regions."""
+    out = []
+    for i in range(text_index.shape[0]):
+        t = F.normalize(sequence_output[i, int(text_index[i, 0]):int(text_index[i, 1])], p=2, dim=-1)
+        v = F.normalize(sequence_output[i, int(img_index[i, 0]):int(img_index[i, 1])], p=2, dim=-1)
+        out.append(t2i_sim(t @ v.t(), draws))
+    return torch.stack(out)
+
+
 def wra_loss_sample(sequence_output, phrase_index, img_index, draws):
     """vl:1285-1300 (phrase_mod='sample')."""
     vp = F.normalize(mask_slice_and_stack(sequence_output, phrase_index), p=2, dim=-1)
@@ -333,9 +359,9 @@ def bi_bert_img_for_pretraining(sd, cfg, input_ids_a, token_type_ids_a=None, att
                                 masked_lm_labels_a=None, input_ids_b=None, token_type_ids_b=None,
                                 attention_mask_b=None, masked_lm_labels_b=None, max_tag_length=20,
                                 img_feats=None, img_index=None, phrase_index=None, draws=None,
-                                return_aux=False):
-    """vl:1218-1311 BiBertImgForPreTraining.forward (qa_ans None, phrase_mod='sample') ->
-    (total, vis_mlm, retrieval, mlm, itm[, wra])."""
+                                return_aux=False, qa_ans=None, phrase_mod="sample"):
+    """vl:1218-1311 BiBertImgForPreTraining.forward ->
+    (total, vis_mlm, retrieval, mlm, itm[, qa][, wra])."""
     draws = draws or Draws()
     outs, single, hard_idx = bi_bert_img_model(
         sd, cfg, input_ids_a, token_type_ids_a, attention_mask_a, max_tag_length, False, input_ids_b,
@@ -361,8 +387,23 @@ def bi_bert_img_for_pretraining(sd, cfg, input_ids_a, token_type_ids_a=None, att
     itm = ce(rel, itm_labels)
     total = vis_mlm + retrieval + mlm + itm
     out = (vis_mlm, retrieval, mlm, itm)
+    if qa_ans is not None:        # vl:1264-1268
+        qa = ce(linear(sd, "qa_head", pooled), qa_ans)
+        total = total + qa
+        out = out + (qa,)
     if phrase_index is not None:
-        wra = wra_loss_sample(seq, phrase_index, img_index, draws)
+        if phrase_mod == "sample":
+            wra = wra_loss_sample(seq, phrase_index, img_index, draws)
+        elif phrase_mod == "hard":   # vl:1271-1283
+            hard_phrase = phrase_index.index_select(0, hard_idx[0])
+            hard_object = img_index.index_select(0, hard_idx[1])
+            pos = get_pos_sims(seq, phrase_index, img_index, draws)
+            neg = get_pos_sims(hard_seq, hard_phrase, hard_object, draws)
+            loss = torch.clamp(neg + 0.2 - pos, min=0)
+            valid = ((phrase_index[:, 1] - phrase_index[:, 0]) > 0) & ((hard_phrase[:, 1] - hard_phrase[:, 0]) > 0)
+            wra = torch.mean(torch.masked_select(loss, valid))
+        else:
+            raise NotImplementedError
         total = total + wra
         out = out + (wra,)
     res = (total,) + out
@@ -404,6 +445,23 @@ def bi_retrieval(sd, cfg, mode, input_ids_a, token_type_ids_a=None, attention_ma
     return retrieval + itm, rel, retrieval, itm, labels
 
 
+def cls_loss(cfg, logits, labels, soft_label=False):
+    """vl:1777-1797 / vl:1849-1869 — the loss switch shared by the VE / VQA wrappers."""
+    n_labels = logits.shape[-1]
+    if n_labels == 1:
+        return F.mse_loss(logits.view(-1), labels.to(torch.float).view(-1))
+    if soft_label:    # vl:27-40 soft_cross_entropy
+        logp = F.log_softmax(logits, dim=1)
+        t = torch.stack([1 - labels.float(), labels.float()], dim=1)
+        return torch.mean(-torch.sum(t.view(t.shape[0], -1) * logp, dim=1))
+    lt = cfg.get("loss_type", "ce")
+    if lt == "kl":
+        return F.kl_div(F.log_softmax(logits.contiguous().view(-1, 3129), dim=-1), labels.contiguous(), reduction="batchmean")
+    if lt == "bce":   # vl:878-883 instance_bce_with_logits
+        return F.binary_cross_entropy_with_logits(logits, labels, reduction="mean") * labels.size(1)
+    return F.cross_entropy(logits.view(-1, n_labels), labels.view(-1))
+
+
 def qa_head(sd, prefix, x, eps):
     """mb:518-533 BertQAPredictionHead."""
     return lm_head(sd, prefix, x, eps)
@@ -411,8 +469,8 @@ def qa_head(sd, prefix, x, eps):
 
 def bi_vqa(sd, cfg, input_ids_a, token_type_ids_a=None, attention_mask_a=None, labels=None,
            input_ids_b=None, token_type_ids_b=None, attention_mask_b=None, max_tag_length=20,
-           img_feats=None):
-    """vl:1834-1870 BiImageBertForVQA.forward (loss_type 'bce') -> (loss, logits) or (logits,)."""
+           img_feats=None, soft_label=False):
+    """vl:1834-1870 BiImageBertForVQA.forward -> (loss, logits) or (logits,)."""
     outs, _, _ = bi_bert_img_model(sd, cfg, input_ids_a, token_type_ids_a, attention_mask_a,
                                    max_tag_length, False, input_ids_b, token_type_ids_b,
                                    attention_mask_b, img_feats, False)
@@ -420,21 +478,20 @@ def bi_vqa(sd, cfg, input_ids_a, token_type_ids_a=None, attention_mask_a=None, l
     logits = qa_head(sd, "cls.predictions", seq[:, 0], cfg["layer_norm_eps"])
     if labels is None:
         return (logits,)
-    loss = F.binary_cross_entropy_with_logits(logits, labels, reduction="mean") * labels.size(1)  # vl:878-883
-    return loss, logits
+    return cls_loss(cfg, logits, labels, soft_label), logits
 
 
 def bi_seq_cls(sd, cfg, input_ids_a, token_type_ids_a=None, attention_mask_a=None, labels=None,
                input_ids_b=None, token_type_ids_b=None, attention_mask_b=None, max_tag_length=20,
-               use_b=False, img_feats=None):
-    """vl:1762-1798 BiImageBertForSequenceClassification.forward (loss_type 'ce')."""
+               use_b=False, img_feats=None, soft_label=False):
+    """vl:1762-1798 BiImageBertForSequenceClassification.forward."""
     outs, _, _ = bi_bert_img_model(sd, cfg, input_ids_a, token_type_ids_a, attention_mask_a,
                                    max_tag_length, use_b, input_ids_b, token_type_ids_b,
                                    attention_mask_b, img_feats, False)
     logits = _classifier(sd, cfg, outs[1])
     if labels is None:
         return (logits,)
-    return F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.view(-1)), logits
+    return cls_loss(cfg, logits, labels, soft_label), logits
 
 
 # ---------------------------------------------------------------------------------- optimisation

@@ -18,6 +18,8 @@ TINY_CFG = dict(vocab_size=1200, only_word_size=1000, hidden_size=128, num_hidde
                 initializer_range=0.02, loss_type="ce", num_labels=2)
 TINY_DIMS = dict(B=4, T=12, P=3, G=6, R=5)
 TINY_FT_DIMS = dict(B=4, T=12, P=3, G=20, R=5)   # fine-tune scripts rely on the default max_tag_length=20
+HN_DIMS = dict(B=8, T=12, P=3, G=6, R=5)         # hard-negative fixture (tiny_bi_hn)
+HN_GAIN = 5.0
 
 BASE_CFG = dict(vocab_size=86051, only_word_size=30522, hidden_size=768, num_hidden_layers=12,
                 num_attention_heads=12, intermediate_size=3072, layer_norm_eps=1e-12,
@@ -56,9 +58,11 @@ def det_uniform(name, shape, seed):
     return (2.0 * u - 1.0).reshape(shape)
 
 
-def det_state_dict(shapes, seed):
-    """name -> float32 array.  Linear/embedding weights ~ U(-s, s) with std 0.03, LayerNorm weight
-    1 +- 0.1, biases +- 0.05, logit_scale ln(1/0.07), projections scaled like the reference init."""
+def det_state_dict(shapes, seed, gain=1.0):
+    """name -> float32 array.  Linear/embedding weights ~ U(-s, s) with std 0.03 * gain, LayerNorm
+    weight 1 +- 0.1, biases +- 0.05, logit_scale ln(1/0.07), projections scaled like the reference
+    init (* gain).  gain > 1 makes the network's output depend on its input strongly enough that the
+    [CLS] embeddings of different samples are well separated (hard-negative fixtures)."""
     out = {}
     for name in sorted(shapes):
         shape = tuple(shapes[name])
@@ -70,9 +74,9 @@ def det_state_dict(shapes, seed):
         elif name.endswith("bias") or name.endswith("LayerNorm.bias"):
             v = 0.05 * u
         elif name.endswith("txt_proj") or name.endswith("vis_proj"):
-            v = u * (3.0 ** 0.5) * shape[0] ** -0.5
+            v = u * (3.0 ** 0.5) * shape[0] ** -0.5 * gain
         else:
-            v = u * (3.0 ** 0.5) * 0.03
+            v = u * (3.0 ** 0.5) * 0.03 * gain
         out[name] = v.astype(np.float32)
     return out
 
@@ -84,3 +88,21 @@ def load(name):
     d["config"] = json.loads(str(d["config_json"]))
     d["dims"] = json.loads(str(d["dims_json"]))
     return d
+
+
+class InjectHard:
+    """Test-side injection of captured hard-negative indices: replaces the
+    backbone's mine_hard_negatives() on the INSTANCE for the duration of a parity run, so that losses
+    and gradients are compared on the same hard batch the reference built.  Nothing in the product
+    reads such a hook."""
+
+    def __init__(self, bert, hard_img, hard_txt):
+        self.bert, self.hi, self.ht = bert, hard_img, hard_txt
+
+    def __enter__(self):
+        hi, ht = self.hi, self.ht
+        self.bert.mine_hard_negatives = lambda sim, hn_mod="hard", logit=None: (hi.to(sim.device), ht.to(sim.device))
+        return self
+
+    def __exit__(self, *exc):
+        del self.bert.mine_hard_negatives

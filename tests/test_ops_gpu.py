@@ -29,16 +29,16 @@ def test_gemm_nt_bias(dev, M, N, K):
     ref = a.float() @ b.float().t() + bias
     for cfg in ("p256", "s128", "t256k", "t256", "t256g", "w4", "w4g", None):  # every tile configuration + the default choice
         if cfg is None:
-            os.environ.pop("MVPTR_GEMM_CFG", None)
+            hip.set_knob("MVPTR_GEMM_CFG", "")
         else:
-            os.environ["MVPTR_GEMM_CFG"] = cfg
+            hip.set_knob("MVPTR_GEMM_CFG", cfg)
         out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
         err = _rel(out, ref)
         print("gemm_nt bias", cfg, M, N, K, err)
         assert err < 4e-3
         out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
         assert _rel(out32, ref) < 1e-5
-    os.environ.pop("MVPTR_GEMM_CFG", None)
+    hip.set_knob("MVPTR_GEMM_CFG", "")
 
 
 def test_gemm_nt_identity_layout(dev):
@@ -111,9 +111,9 @@ def test_gemm_tn(dev, M, N, K):
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
     for cfg in ("32", "64", "k2", "K", None):  # every tile configuration + the planner's own choice
         if cfg is None:
-            os.environ.pop("MVPTR_GEMM_TN", None)
+            hip.set_knob("MVPTR_GEMM_TN", "")
         else:
-            os.environ["MVPTR_GEMM_TN"] = cfg
+            hip.set_knob("MVPTR_GEMM_TN", cfg)
         dw = torch.zeros(N, K, device=dev)
         cs = torch.zeros(N, device=dev)
         hip.gemm_tn(dy, x, dw, n=N, colsum=cs)
@@ -124,7 +124,7 @@ def test_gemm_tn(dev, M, N, K):
         assert _rel(cs, dy[:, :N].float().sum(0)) < 1e-5
         hip.gemm_tn(dy, x, dw, n=N)  # accumulates
         assert _rel(dw, 2 * ref) < 1e-5
-    os.environ.pop("MVPTR_GEMM_TN", None)
+    hip.set_knob("MVPTR_GEMM_TN", "")
 
 
 def test_gemm_tn_multi(dev):
@@ -149,9 +149,9 @@ def test_gemm_tn_multi(dev):
     refs.append(dy5.float().t() @ x5.float())
     for cfg in ("32", "K", None):
         if cfg is None:
-            os.environ.pop("MVPTR_GEMM_TN", None)
+            hip.set_knob("MVPTR_GEMM_TN", "")
         else:
-            os.environ["MVPTR_GEMM_TN"] = cfg
+            hip.set_knob("MVPTR_GEMM_TN", cfg)
         for _, _, dw, cs in probs:
             dw.zero_()
             if cs is not None:
@@ -161,7 +161,7 @@ def test_gemm_tn_multi(dev):
             assert _rel(dw, ref) < 1e-5
             if cs is not None:
                 assert _rel(cs, dy.float().sum(0)) < 1e-5
-    os.environ.pop("MVPTR_GEMM_TN", None)
+    hip.set_knob("MVPTR_GEMM_TN", "")
 
 
 def test_gemm_tn_layout_exact(dev):

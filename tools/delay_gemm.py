@@ -25,7 +25,7 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-os.environ["MVPTR_GEMM_CFG"] = "t256k"
+hip.set_knob("MVPTR_GEMM_CFG", "t256k")
 for M in (64000, 32000):
     for N, K, epi, name in [(2304, 768, hip.EPI_BIAS, "BIAS"), (3072, 768, hip.EPI_BIAS_GELU, "GELU"),
                             (3072, 768, hip.EPI_GELU_BWD, "GELU_BWD"), (768, 3072, hip.EPI_BIAS_RESID, "RESID")]:
@@ -41,7 +41,7 @@ for M in (64000, 32000):
         best = {}
         for rep in range(3):  # interleave the settings so clock / cache state is shared
             for d in settings:
-                os.environ["MVPTR_GEMM_DELAY"] = d
+                hip.set_knob("MVPTR_GEMM_DELAY", d)
                 us = timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec), reps=10)
                 best.setdefault(d, []).append(us)
         for d in dict.fromkeys(settings):

@@ -34,7 +34,7 @@ for N, K, epi, name in ((2304, 768, hip.EPI_BIAS, "BIAS"), (3072, 768, hip.EPI_B
     res = {}
     for rep in range(3):
         for cfg, xp in (("t256k", "0"), ("p256", "0"), ("p256", "1")):
-            os.environ["MVPTR_GEMM_CFG"] = cfg
-            os.environ["MVPTR_NT_EXP"] = xp
+            hip.set_knob("MVPTR_GEMM_CFG", cfg)
+            hip.set_knob("MVPTR_NT_EXP", xp)
             res.setdefault((cfg, xp), []).append(timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, out=out, out1=out1)))
     print("%-12s M=%d N=%d K=%d: " % (name, M, N, K) + "  ".join("%s/%s min %.1f" % (k[0], "noprefetch" if k[1] == "1" else "std", min(v)) for k, v in res.items()), flush=True)

@@ -34,7 +34,7 @@ for N, K, name in ((3072, 768, "w_i"), (768, 3072, "w_out"), (2304, 768, "w_qkv"
     dw = torch.zeros(N, K, device=dev)
     line = "%s %-6s" % (sys.argv[1] if len(sys.argv) > 1 else "prod", name)
     for cfg in ("32", "K", "k2"):
-        os.environ["MVPTR_GEMM_TN"] = cfg
+        hip.set_knob("MVPTR_GEMM_TN", cfg)
         us = min(timeit(lambda: hip.gemm_tn(dy, x, dw)) for _ in range(3))
         line += "  %s %6.1fus %5.0fTF" % (cfg, us, 2.0 * M * N * K / us / 1e6)
     print(line, flush=True)

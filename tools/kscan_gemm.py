@@ -34,7 +34,7 @@ if len(sys.argv) > 2:  # small grids: "M1,M2,..." -> BIAS and GELU at those M
 for M, N, epi, name in SHAPES:
     Ks = [256, 512, 768, 1536, 3072]
     for cfg in CFGS:
-        os.environ["MVPTR_GEMM_CFG"] = cfg
+        hip.set_knob("MVPTR_GEMM_CFG", cfg)
         ts = []
         for K in Ks:
             a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
@@ -48,4 +48,4 @@ for M, N, epi, name in SHAPES:
         slope, icpt = np.polyfit(Ks, ts, 1)
         print("%-8s M=%d N=%d cfg=%-6s us@K=%s: %s | fit: %.1f us + %.4f us/K  -> loop rate %.0f TF, fixed part = %.0f%% of the K=768 time"
               % (name, M, N, cfg, Ks, " ".join("%.1f" % t for t in ts), icpt, slope, 2.0 * M * N / slope / 1e6, 100 * icpt / ts[2]), flush=True)
-os.environ.pop("MVPTR_GEMM_CFG", None)
+hip.set_knob("MVPTR_GEMM_CFG", "")

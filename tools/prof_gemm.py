@@ -25,9 +25,9 @@ for _ in range(3):
     hip.gemm_nt(xi, w_out, hip.EPI_BIAS_RESID, bias=b_out, aux=x)  # gemm_nt<2>: K=3072, N=768
     hip.gemm_nt(x, w_i, hip.EPI_BIAS_GELU, bias=b_i)           # gemm_nt<1>: K=768, N=3072
     dw = torch.zeros(I, H, device=dev)
-    os.environ["MVPTR_GEMM_TN"] = "32"
+    hip.set_knob("MVPTR_GEMM_TN", "32")
     hip.gemm_tn(xi, x, dw)                                     # gemm_tn<32,1,3>: N=3072, K=768
-    os.environ["MVPTR_GEMM_TN"] = "K"
+    hip.set_knob("MVPTR_GEMM_TN", "K")
     hip.gemm_tn(xi, x, dw)                                     # gemm_tn<64,2,2>
     os.environ.pop("MVPTR_GEMM_TN")
 B, L, heads = 512, 125, 12

@@ -23,7 +23,7 @@ def run(M, N, K, epi, name):
     aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (hip.EPI_BIAS_RESID,) else None
     nwg = ((M + 255) // 256) * ((N + 127) // 128) * 2
     st = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-    os.environ["MVPTR_GEMM_STAMPS"] = str(st.data_ptr())
+    hip.set_knob("MVPTR_GEMM_STAMPS", str(st.data_ptr()))
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
     for _ in range(3):
@@ -37,10 +37,10 @@ def run(M, N, K, epi, name):
           % (name, M, N, K, w, i, l, m, tot, 100 * m / tot))
 
 
-os.environ["MVPTR_GEMM_CFG"] = "w4"
+hip.set_knob("MVPTR_GEMM_CFG", "w4")
 run(32000, 768, 3072, hip.EPI_BIAS_RESID, "ffn2 fwd (w4)")
 run(32000, 2304, 768, hip.EPI_BIAS, "qkv fwd (w4)")
 run(32000, 3072, 768, hip.EPI_BIAS_GELU, "ffn1 fwd (w4)")
 for cfg in ("t256k", "t256"):
-    os.environ["MVPTR_GEMM_CFG"] = cfg
+    hip.set_knob("MVPTR_GEMM_CFG", cfg)
     run(19200, 768, 3072, hip.EPI_BIAS_RESID, "ffn2 fwd (%s)" % cfg)

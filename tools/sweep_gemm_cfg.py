@@ -44,18 +44,18 @@ for M in (37748, 10917, 3000):
         N, K = b.shape
         bias = torch.zeros(N, device=dev)
         out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
-        os.environ.pop("MVPTR_GEMM_CFG", None)
+        hip.set_knob("MVPTR_GEMM_CFG", "")
         ref = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=ref, out1=out1,
                     vec_out=torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None)
         ref = ref.float()
         line = "M=%5d N=%4d K=%4d %-20s" % (M, N, K, name)
         for cfg in CFGS:
-            os.environ["MVPTR_GEMM_CFG"] = cfg
+            hip.set_knob("MVPTR_GEMM_CFG", cfg)
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
             us = timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec))
             ok = torch.equal(out.float(), ref)
             line += "  %s %6.1fus %6.1fTF%s" % (cfg, us, 2.0 * M * N * K / us / 1e6, "" if ok else " MISMATCH")
         print(line, flush=True)
-os.environ.pop("MVPTR_GEMM_CFG", None)
+hip.set_knob("MVPTR_GEMM_CFG", "")

@@ -34,9 +34,9 @@ for M in (37748, 10917, 3000):
         line = "M=%5d N=%4d K=%4d %-6s" % (M, N, K, name)
         for cfg in CFGS:
             if cfg == "auto":
-                os.environ.pop("MVPTR_GEMM_TN", None)
+                hip.set_knob("MVPTR_GEMM_TN", "")
             else:
-                os.environ["MVPTR_GEMM_TN"] = cfg
+                hip.set_knob("MVPTR_GEMM_TN", cfg)
             dw = torch.zeros(N, K, device=dev)
             cs = torch.zeros(N, device=dev)
             hip.gemm_tn(dy, x, dw, colsum=cs)
@@ -54,4 +54,4 @@ for M in (37748, 10917, 3000):
             if (err == err and err > 1e-3) or errc > 1e-3:
                 line += " ERR(%.1e,%.1e)" % (err, errc)
         print(line, flush=True)
-os.environ.pop("MVPTR_GEMM_TN", None)
+hip.set_knob("MVPTR_GEMM_TN", "")

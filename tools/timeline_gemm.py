@@ -19,14 +19,14 @@ dev = torch.device("cuda:0")
 
 
 def run(cfg, M, N, K, epi, name, bm, bn):
-    os.environ["MVPTR_GEMM_CFG"] = cfg
+    hip.set_knob("MVPTR_GEMM_CFG", cfg)
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     b = (torch.randn(N, K, device=dev) * 0.5).to(torch.bfloat16)
     bias = torch.zeros(N, device=dev)
     aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (hip.EPI_BIAS_RESID, hip.EPI_GELU_BWD) else None
     nwg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     st = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-    os.environ["MVPTR_GEMM_STAMPS"] = str(st.data_ptr())
+    hip.set_knob("MVPTR_GEMM_STAMPS", str(st.data_ptr()))
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
     vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None

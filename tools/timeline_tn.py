@@ -20,7 +20,7 @@ def run(M, N, K, name):
     x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     dw = torch.zeros(N, K, device=dev)
     st = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
-    os.environ["MVPTR_GEMM_STAMPS"] = str(st.data_ptr())
+    hip.set_knob("MVPTR_GEMM_STAMPS", str(st.data_ptr()))
     for _ in range(3):
         st.zero_()
         hip.gemm_tn(dy, x, dw)
@@ -40,9 +40,9 @@ def run(M, N, K, name):
 
 for cfg in ("32", "K"):
     if cfg is None:
-        os.environ.pop("MVPTR_GEMM_TN", None)
+        hip.set_knob("MVPTR_GEMM_TN", "")
     else:
-        os.environ["MVPTR_GEMM_TN"] = cfg
+        hip.set_knob("MVPTR_GEMM_TN", cfg)
     print("MVPTR_GEMM_TN =", cfg)
     run(64000, 3072, 768, "w_i")
     run(64000, 768, 768, "w_o")
