@@ -172,7 +172,8 @@ class BertPooler(nn.Module):
         self.activation = nn.Tanh()
 
     def forward(self, hidden_states):
-        return self.activation(self.dense(hidden_states[:, 0].float()))
+        # f32 master weights -> f32; after model.half() the tail runs in the parameters' dtype like the reference
+        return self.activation(self.dense(hidden_states[:, 0].to(self.dense.weight.dtype)))
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -237,7 +238,7 @@ class BertQAPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(config.num_labels))
 
     def forward(self, hidden_states):
-        h = self.transform(hidden_states).float()
+        h = self.transform(hidden_states).to(self.decoder.weight.dtype)
         return self.decoder(h) + self.bias
 
 

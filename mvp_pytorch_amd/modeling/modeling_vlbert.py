@@ -278,8 +278,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
 
     def _globals(self, txt, vis):
         """vl:525-526 — f32 (feeds argmax: kept out of bf16)."""
-        gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
-        gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj, p=2, dim=-1)
+        gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
+        gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
         return gt, gi
 
     def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
@@ -375,7 +375,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
         with self._packed_stacks(self, packed):
             txt = self.txt_encoder(xa, mask_a)[0]
-        glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj, p=2, dim=-1)
+        glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
         return dict(seq=txt, mask=mask_a, glob=glob)
 
     @torch.no_grad()
@@ -392,7 +392,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         with self._packed_stacks(self, packed):
             vis = self.vis_encoder(xb, mask_b)[0]
         cut = 1 if use_b else max_tag_length
-        glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj, p=2, dim=-1)
+        glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
         return dict(seq=vis[:, cut:, :].contiguous(), mask=mask_b[:, cut:].contiguous(), glob=glob)
 
     @torch.no_grad()
@@ -417,7 +417,7 @@ class BertPreTrainingHeads(nn.Module):
         self.seq_relationship = nn.Linear(config.hidden_size, n)
 
     def forward(self, sequence_output, pooled_output):
-        return self.predictions(sequence_output), self.seq_relationship(pooled_output.float())
+        return self.predictions(sequence_output), self.seq_relationship(pooled_output.to(self.seq_relationship.weight.dtype))
 
 
 class BertVQAHeads(nn.Module):

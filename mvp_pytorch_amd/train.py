@@ -19,7 +19,11 @@ def build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, warmup
 
 def model_inputs(batch, max_tag_length):
     """batch (13 tensors of OscarTSVDataset_C, oscar_tsv4.py:363-377) -> model kwargs
-    (run_pretrain_ml.py:528-531)."""
+    (run_pretrain_ml.py:528-531); a single-stream batch (input_ids / input_mask / ...) maps to
+    BertImgForPreTraining's arguments (run_pretrain_ml.py:533 positional order)."""
+    if "input_ids" in batch:
+        return dict(input_ids=batch["input_ids"], token_type_ids=batch["segment_ids"], attention_mask=batch["input_mask"],
+                    masked_lm_labels=batch["lm_label_ids"], next_sentence_label=batch["is_next"], img_feats=batch["img_feats"])
     return dict(input_ids_a=batch["input_ids_a"], token_type_ids_a=batch["segment_ids_a"],
                 attention_mask_a=batch["input_mask_a"], masked_lm_labels_a=batch["lm_label_ids_a"],
                 input_ids_b=batch["input_ids_b"], img_feats=batch["img_feats"],
