@@ -92,24 +92,39 @@ def cpu_baseline(seconds_budget=20.0, single=False):
     BASELINE.json configs[0] shapes: B=4, 35 tok (+5 phrase slots), 20 tags, 10 regions.  All host
     cores, forward + backward + AdamW, median of the warm steps."""
     if single:
-        return _best_threads(_cpu_baseline_single, seconds_budget)
-    res = _best_threads(_cpu_baseline_bi, seconds_budget)
-    res["single_stream"] = _best_threads(_cpu_baseline_single, seconds_budget / 2)   # BASELINE.md §3: both models
+        return _best_threads("single", seconds_budget)
+    res = _best_threads("bi", seconds_budget)
+    res["single_stream"] = _best_threads("single", seconds_budget / 2)   # BASELINE.md §3: both models
     return res
 
 
-def _best_threads(fn, seconds_budget):
+def _best_threads(which, seconds_budget):
     """BASELINE.md §3 asks for all host cores; a B=4 fp32 step stops scaling (and can slow down) far
     below the core count of a GPU host, so a 32-thread run is timed too and the faster one is reported
-    with the thread count it used."""
+    with the thread count it used.  Each candidate runs in a CHILD process (fresh OpenMP pool, hard
+    timeout): a candidate that does not finish is reported, not waited for."""
+    import subprocess
     total = os.cpu_count() or 1
     cands = [total] + ([32] if total > 32 else [])
-    best = None
+    best, notes = None, []
     for c in cands:
-        r = fn(seconds_budget / len(cands), c)
+        budget = seconds_budget / len(cands)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", which, "--threads", str(c),
+               "--budget", "%.1f" % budget]
+        env = dict(os.environ, OMP_NUM_THREADS=str(c), MKL_NUM_THREADS=str(c), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        try:
+            out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=6 * budget + 90)
+            r = json.loads(out.stdout.decode().strip().splitlines()[-1])
+        except (subprocess.TimeoutExpired, ValueError, IndexError) as e:
+            notes.append("%d threads: %s" % (c, type(e).__name__))
+            continue
         if best is None or r["value"] > best["value"]:
             best = r
+    if best is None:
+        best = dict(value=None, unit="pairs/s", cores=0, kind="port", sample="no candidate finished")
     best["host_cores"] = total
+    if notes:
+        best["skipped"] = notes
     return best
 
 
@@ -340,7 +355,15 @@ def main():
                     help="timed steps only (no all-slots-valid leg, kernel replay or CPU baseline): the command profiles/ are made from")
     ap.add_argument("--model", choices=["bi", "single"], default="bi",
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
+    ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--budget", type=float, default=10.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_child:   # CPU only: never touches the GPU
+        fn = _cpu_baseline_bi if args.cpu_baseline_child == "bi" else _cpu_baseline_single
+        print(json.dumps(fn(args.budget, args.threads or (os.cpu_count() or 1))), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:

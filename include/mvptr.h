@@ -259,6 +259,21 @@ int mvptr_adamw_multi(const mvptr_adamw_tensor* table, const int32_t* chunk_tens
                       const int64_t* chunk_offset, int n_chunks, int chunk_elems, float beta1,
                       float beta2, float eps, void* stream);
 
+/* Input pipeline: region features of n_samples TSV rows, still base64 text, ->
+ * out_f32 [n_samples, R, D] and/or out_bf16 [n_samples * R, ld_bf16] (columns D..ld_bf16-1 zero: the
+ * K-padded operand of the region-embedding GEMM).  Replaces get_img_feature
+ * oscar/oscar_datasets_ml/oscar_tsv4.py:696-724 (np.frombuffer(base64.b64decode(arr[-1]), float32)
+ * .reshape(num_boxes, img_feature_dim)), the truncation to max_img_seq_length rows and zero padding
+ * of __getitem__ :332-352, and data_process' images.to(dtype) run_pretrain_ml.py:501-504.
+ * text: device bytes; sample s occupies text[offsets[s] .. offsets[s] + n_chars[s]), offsets 16-byte
+ * aligned and the buffer readable up to the next multiple of 16 after every sample.  offsets, n_chars
+ * (int64) and num_boxes (int32) are device arrays.  err_flag (device int32, zero it first) gets
+ * bit 0 if a sample's text is shorter than num_boxes x D floats need (or misaligned), bit 1 for a
+ * character outside the RFC 4648 alphabet inside the kept rows (base64.b64decode would skip it). */
+int mvptr_b64_decode_features(const void* text, const int64_t* offsets, const int64_t* n_chars,
+                              const int32_t* num_boxes, int n_samples, int R, int D, float* out_f32,
+                              void* out_bf16, int64_t ld_bf16, int32_t* err_flag, void* stream);
+
 /* Materialise the dropout keep-mask (1/0 bytes) for n elements — test support. */
 int mvptr_dropout_mask(const mvptr_dropout* drop, int64_t n, uint8_t* keep, void* stream);
 

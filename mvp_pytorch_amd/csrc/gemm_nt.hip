@@ -744,6 +744,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
     const size_t n = strlen(env);
     if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128": 128x128, 4 waves
+    if (env[0] == 'h') return launch_bk<EPI, 32, 3, 2, 2, 8, 0>(a, s);  // "h4": 256x128, 4 waves of 128x64, 2 WG/CU
     if (env[0] == 't' && env[n - 1] == 'k') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
     if (env[0] == 't' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 2, 4, 8, 2>(a, s);
     if (env[0] == 't') return launch_bk<EPI, 32, 3, 2, 4, 8, 0>(a, s);

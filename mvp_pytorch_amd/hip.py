@@ -25,7 +25,7 @@ SYMBOLS = [
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
-    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd",
+    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
     lib.mvptr_ce_bwd.argtypes = [P, I64, P, P, P, P, I64, I, I, I, P]
     lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
     lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P]
+    lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
     _lib = lib
@@ -306,6 +307,26 @@ def cast_pack(src, dst=None, dst_t=None, col_off_t=0):
     rows, cols = src.shape
     _check(load().mvptr_cast_pack(_p(src), src.stride(0), rows, cols, _p(dst), dst.stride(0) if dst is not None else 0,
                                   _p(dst_t), dst_t.stride(0) if dst_t is not None else 0, col_off_t, _stream()))
+
+
+def b64_decode_features(text, offsets, n_chars, num_boxes, R, D, out_f32=None, out_bf16=None, err=None):
+    """Region features of a batch, still the base64 text of the TSV rows (uint8 device tensor,
+    samples at 16-byte aligned `offsets`), -> f32 [n, R, D] and / or K-padded bf16 [n*R, ld]
+    (oscar_tsv4.py:696-724 + the padding of :332-352).  err: int32[1] device flag (see mvptr.h)."""
+    n = offsets.shape[0]
+    assert text.dtype == torch.uint8 and offsets.dtype == torch.int64 and n_chars.dtype == torch.int64
+    assert num_boxes.dtype == torch.int32 and num_boxes.shape[0] == n and n_chars.shape[0] == n
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and out_f32.is_contiguous() and out_f32.numel() == n * R * D
+    ld = 0
+    if out_bf16 is not None:
+        assert out_bf16.dtype == torch.bfloat16 and out_bf16.stride(1) == 1 and out_bf16.shape[0] == n * R
+        ld = out_bf16.stride(0)
+    if err is None:
+        err = torch.zeros(1, device=text.device, dtype=torch.int32)
+    _check(load().mvptr_b64_decode_features(_p(text), _p(offsets), _p(n_chars), _p(num_boxes), n, R, D, _p(out_f32),
+                                            _p(out_bf16), ld, _p(err), _stream()))
+    return err
 
 
 def cast_f32(src, rows=None, cols=None):

@@ -522,3 +522,52 @@ def warmup_linear(step, warmup_steps, t_total):
     if step < warmup_steps:
         return float(step) / float(max(1, warmup_steps))
     return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
+
+
+# ---------------------------------------------------------------------------------------------
+# input pipeline
+def decode_img_feature(b64_text, num_boxes, img_feature_dim, max_img_seq_length, dtype=torch.float32):
+    """Region features of one TSV row -> [max_img_seq_length, img_feature_dim].
+    oscar/oscar_datasets_ml/oscar_tsv4.py:716-724 (get_img_feature: base64 -> float32 [num_boxes, D]
+    -> tensor of args.dtype) followed by __getitem__ :332-352 (keep the first max_img_seq_length rows,
+    zero-pad the missing ones)."""
+    import base64
+    import numpy as np
+    feat = np.frombuffer(base64.b64decode(b64_text), dtype=np.float32).reshape((num_boxes, img_feature_dim))
+    feat = torch.tensor(np.copy(feat), dtype=dtype)
+    if feat.shape[0] >= max_img_seq_length:
+        feat = feat[0:max_img_seq_length, ]
+    if feat.shape[0] < max_img_seq_length:
+        pad = torch.zeros((max_img_seq_length - feat.shape[0], feat.shape[1]), dtype=dtype)
+        feat = torch.cat((feat, pad), 0)
+    return feat
+
+
+# ---------------------------------------------------------------------------------------------
+# retrieval evaluation, coarse stage (SURVEY §8 f4)
+def compute_ranks_coarse(similarities, num_captions_per_img_train, num_captions_per_img_val, num_images_per_cap_val):
+    """oscar/run_retrieval.py:481-522 on a numpy [n_img, n_cap] matrix.  Returns (i2t_ranks, t2i_ranks,
+    i2t_index, t2i_index) with the candidate lists as plain indices: i2t_index[i] = caption indices
+    (the reference stores (img_keys[ind // c], ind % c)), t2i_index[j] = image indices."""
+    import numpy as np
+    c = num_captions_per_img_train
+    i2t_ranks, t2i_ranks, i2t_index, t2i_index = [], [], [], []
+    for i in range(similarities.shape[0]):
+        inds = np.argsort(similarities[i, :])[::-1]
+        rank = similarities.shape[1]
+        for r, ind in enumerate(inds):
+            if i * c <= ind < (i + 1) * c:
+                rank = r
+                break
+        i2t_ranks.append(rank)
+        i2t_index.append([int(ind) for ind in inds[:num_captions_per_img_val]])
+    for j in range(similarities.shape[1]):
+        inds = np.argsort(similarities[:, j])[::-1]
+        rank = similarities.shape[0]
+        for r, ind in enumerate(inds):
+            if ind == j // c:
+                rank = r
+                break
+        t2i_ranks.append(rank)
+        t2i_index.append([int(ind) for ind in inds[:num_images_per_cap_val]])
+    return i2t_ranks, t2i_ranks, i2t_index, t2i_index

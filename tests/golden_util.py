@@ -18,7 +18,7 @@ TINY_CFG = dict(vocab_size=1200, only_word_size=1000, hidden_size=128, num_hidde
                 initializer_range=0.02, loss_type="ce", num_labels=2)
 TINY_DIMS = dict(B=4, T=12, P=3, G=6, R=5)
 TINY_FT_DIMS = dict(B=4, T=12, P=3, G=20, R=5)   # fine-tune scripts rely on the default max_tag_length=20
-HN_DIMS = dict(B=8, T=12, P=3, G=6, R=5)         # hard-negative fixture (tiny_bi_hn)
+HN_DIMS = dict(B=4, T=12, P=3, G=6, R=5)         # hard-negative fixture (tiny_bi_hn)
 HN_GAIN = 5.0
 
 BASE_CFG = dict(vocab_size=86051, only_word_size=30522, hidden_size=768, num_hidden_layers=12,

@@ -199,3 +199,44 @@ def test_branches():
         loss, logits = orc.bi_vqa(sdk, ck, labels=torch.from_numpy(d["kl_labels"]), **kw)
     np.testing.assert_allclose(loss.item(), float(d["kl_loss"]), rtol=2e-5)
     np.testing.assert_allclose(logits.numpy()[:, :128], d["kl_logits_head"], atol=2e-5)
+
+
+def _feature_rows(tag):
+    z = np.load(gu.GOLDEN_DIR + "/tiny_features.npz")
+    D, n = int(z[tag + ":D"]), int(z[tag + ":n"])
+    return D, [(z["%s:%d:text" % (tag, i)].tobytes(), int(z["%s:%d:num_boxes" % (tag, i)]), z["%s:%d:feat" % (tag, i)])
+               for i in range(n)]
+
+
+@pytest.mark.parametrize("tag,R", [("small", 5), ("small", 50), ("wide", 4), ("wide", 50)])
+def test_decode_img_feature_matches_reference_rows(tag, R):
+    """oracle.decode_img_feature == the reference's get_img_feature (oscar_tsv4.py:696-724) on the
+    fixture's TSV rows, bit for bit, with the truncation / zero padding of __getitem__ :332-352."""
+    D, rows = _feature_rows(tag)
+    for text, nb, feat in rows:
+        got = orc.decode_img_feature(text, nb, D, R).numpy()
+        assert got.shape == (R, D)
+        keep = min(nb, R)
+        assert np.array_equal(got[:keep].view(np.uint32), feat[:keep].view(np.uint32))
+        assert not got[keep:].any()
+
+
+def test_compute_ranks_coarse_oracle_and_device_routine_match_reference():
+    """oracle.compute_ranks_coarse and the product's tensor routine (retrieval_eval.coarse_ranks, plain
+    torch: runs on the CPU here, on the GPU in tests/test_pipeline_gpu.py) == the reference's
+    compute_ranks_coarse (oscar/run_retrieval.py:481-522) on the fixture matrix: integer outputs,
+    bit for bit (random f32 similarities: no ties)."""
+    from mvp_pytorch_amd import retrieval_eval
+    z = np.load(gu.GOLDEN_DIR + "/tiny_ranks.npz")
+    sim, c, k_c, k_i = z["sim"], int(z["c"]), int(z["k_c"]), int(z["k_i"])
+    i2t, t2i, i2t_idx, t2i_idx = orc.compute_ranks_coarse(sim, c, k_c, k_i)
+    assert np.array_equal(np.array(i2t), z["i2t_ranks"]) and np.array_equal(np.array(t2i), z["t2i_ranks"])
+    assert np.array_equal(np.array(i2t_idx), z["i2t_top"]) and np.array_equal(np.array(t2i_idx), z["t2i_top"])
+    out = retrieval_eval.coarse_ranks(torch.from_numpy(sim), c, k_c, k_i)
+    assert out["i2t_ranks"].dtype == torch.int64
+    assert np.array_equal(out["i2t_ranks"].numpy(), z["i2t_ranks"]) and np.array_equal(out["t2i_ranks"].numpy(), z["t2i_ranks"])
+    assert np.array_equal(out["i2t_topk"].numpy(), z["i2t_top"]) and np.array_equal(out["t2i_topk"].numpy(), z["t2i_top"])
+    # second stage: rank of the first ground-truth candidate after sorting by score
+    scores = torch.tensor([[0.1, 0.9, 0.5], [0.3, 0.2, 0.1], [0.3, 0.2, 0.1]])
+    gt = torch.tensor([[False, False, True], [True, False, False], [False, False, False]])
+    assert retrieval_eval.rerank_ranks(scores, None, gt).tolist() == [1, 0, 3]

@@ -411,6 +411,72 @@ def gen_branches(name, c, dims, seed):
           "bce", data["bce_loss"], "kl", data["kl_loss"])
 
 
+
+def gen_features(name):
+    """Input-pipeline fixture: TSV rows (image id, num_boxes, base64 of the float32
+    features) are written to a scratch TSV file and read back through the REFERENCE's own reader
+    and decoder — oscar/utils/tsv_file.py TSVFile.seek and OscarTSVDataset_C.get_img_feature
+    (oscar/oscar_datasets_ml/oscar_tsv4.py:696-724) — on a stand-in `self` that only carries the
+    attributes that method reads.  Stored: the base64 text of every row and the decoded arrays."""
+    import base64
+    import tempfile
+    from oscar.oscar_datasets_ml.oscar_tsv4 import OscarTSVDataset_C
+    from oscar.utils.tsv_file import TSVFile
+    rng = np.random.RandomState(20260101)
+    cases = [("small", 38, [0, 1, 3, 5, 7, 12]), ("wide", 2054, [3, 11])]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, D, boxes in cases:
+            path = os.path.join(tmp, tag + ".tsv")
+            feats = []
+            with open(path, "w") as f:
+                for i, nb in enumerate(boxes):
+                    a = rng.randn(nb, D).astype(np.float32)
+                    if nb:
+                        a[:, -6:] = rng.rand(nb, 6).astype(np.float32)
+                        a[0, 0] = np.float32(1e-38)      # subnormal-range, sign and extreme bit patterns survive
+                        a[-1, -1] = np.float32(-3.4e38)
+                    feats.append(a)
+                    f.write("%d\t%d\t%s\n" % (i, nb, base64.b64encode(a.tobytes()).decode()))
+            tsv = TSVFile(path, generate_lineidx=True)
+            stub = types.SimpleNamespace(
+                check_img_feature_file=lambda: None, check_img_feature_offset_map=lambda: None,
+                datasets_with_splits=[], img_feat_offset_map={"coco": {str(i): i for i in range(len(boxes))}},
+                img_feature_file={"coco": tsv}, args=types.SimpleNamespace(img_feature_dim=D, dtype=torch.float32))
+            for i, nb in enumerate(boxes):
+                got = OscarTSVDataset_C.get_img_feature(stub, "coco_%d" % i)
+                assert got.dtype == torch.float32 and tuple(got.shape) == (nb, D)
+                assert np.array_equal(got.numpy().view(np.uint32), feats[i].view(np.uint32))
+                row = tsv.seek(i)
+                out["%s:%d:text" % (tag, i)] = np.frombuffer(row[-1].encode(), dtype=np.uint8).copy()
+                out["%s:%d:num_boxes" % (tag, i)] = np.array(int(row[1]))
+                out["%s:%d:feat" % (tag, i)] = got.numpy()
+            out[tag + ":D"] = np.array(D)
+            out[tag + ":n"] = np.array(len(boxes))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "rows", sum(len(c[2]) for c in cases))
+
+
+
+def gen_ranks(name):
+    """Coarse-stage ranking fixture: the reference's compute_ranks_coarse (oscar/run_retrieval.py:481-522)
+    on a random similarity matrix, with a stand-in dataset object that carries the attributes it reads."""
+    from oscar import run_retrieval as ref_rr
+    rng = np.random.RandomState(7)
+    n_img, c, k_c, k_i = 23, 5, 16, 8
+    sim = rng.randn(n_img, n_img * c).astype(np.float32)
+    sim[np.arange(n_img), np.arange(n_img) * c + 2] += 1.5     # matched pairs tend to score high, not always first
+    ds = types.SimpleNamespace(img_keys=list(range(100, 100 + n_img)),
+                               args=types.SimpleNamespace(num_captions_per_img_train=c, num_captions_per_img_val=k_c,
+                                                          num_images_per_cap_val=k_i))
+    i2t, t2i, i2t_index, t2i_index = ref_rr.compute_ranks_coarse(ds, sim)
+    i2t_top = np.array([[(key - 100) * c + cc for key, cc in i2t_index[ds.img_keys[i]]] for i in range(n_img)])
+    t2i_top = np.array([t2i_index[(ds.img_keys[j // c], j % c)] for j in range(n_img * c)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), sim=sim, c=np.array(c), k_c=np.array(k_c), k_i=np.array(k_i),
+                        i2t_ranks=np.array(i2t), t2i_ranks=np.array(t2i), i2t_top=i2t_top, t2i_top=t2i_top)
+    print(name, "i2t R@1", np.mean(np.array(i2t) < 1), "t2i R@1", np.mean(np.array(t2i) < 1))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -432,7 +498,11 @@ if __name__ == "__main__":
         # hard-negative fixture: weights with a gain > 1 separate the [CLS] embeddings, so the f32 top-2
         # margin of every row / column of sim_mat is >= 10x the bf16 error of the kernels' sim_mat
         # (~1e-3): the argmax indices (vl:531-534) must then come out bit-exact, unconditionally
-        s3 = pick_seed(gu.TINY_CFG, gu.HN_DIMS, list(range(7000, 7000 + 400)), wseed=777, gain=gu.HN_GAIN)
+        s3 = pick_seed(gu.TINY_CFG, gu.HN_DIMS, list(range(7000, 7000 + 600)), wseed=777, gain=gu.HN_GAIN)
         gen_bi_pretrain("tiny_bi_hn", gu.TINY_CFG, gu.HN_DIMS, 777, s3, full_grads=False, gain=gu.HN_GAIN, lean=True)
+    if want("tiny_features"):
+        gen_features("tiny_features")
+    if want("tiny_ranks"):
+        gen_ranks("tiny_ranks")
     if want("tiny_branches"):
         gen_branches("tiny_branches", gu.TINY_CFG, gu.TINY_FT_DIMS, 1237)

@@ -31,7 +31,8 @@ def rnd(*s):
 
 
 H, I = 768, 3072
-for M in (37748, 10917, 3000):
+MS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [37748, 10917, 3000]
+for M in MS:
     x, xi, x3 = rnd(M, H), rnd(M, I), rnd(M, 3 * H)
     shapes = [("qkv fwd BIAS", x, rnd(3 * H, H), hip.EPI_BIAS, None),
               ("out fwd RESID", x, rnd(H, H), hip.EPI_BIAS_RESID, x),
