@@ -44,10 +44,18 @@ struct GemmTnGroup {
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, uint32_t off_lo, uint32_t off_hi) {
+  // speed ablations only (wrong values; diagnostic builds, tools/exp_tn.py):
+  //   MVPTR_TN_EXP 1: one 16-byte read per fragment instead of two transposed 8-byte reads
+  //   2: no MFMA   3: no LDS reads   4: no LDS-DMA loads   5: no atomic write-out
 #if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 1
-  // speed experiment only (wrong values): one 16-byte read instead of two transposed 8-byte reads
   (void)off_hi;
   return *reinterpret_cast<const bf16x8*>(tile + (off_lo & ~15u));
+#endif
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 3
+  bf16x8 c;
+  for (int e = 0; e < 8; ++e) c[e] = f2bf((float)((off_lo + off_hi + e) & 7));
+  asm volatile("" : "+v"(c));
+  return c;
 #endif
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)LDS_PTR(tile + off_lo));
@@ -133,6 +141,9 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
     offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
   }
   auto stage = [&](int buf, int mrow0) {
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 4
+    return;
+#endif
     char* la = lds + buf * STAGE_B;
     char* lb = la + 2 * SUB_B;
 #pragma unroll
@@ -226,7 +237,11 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
       for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 2
+          asm volatile("" ::"v"(af[cur][nb]), "v"(bfr[cur][kb]));
+#else
           acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][nb], bfr[cur][kb], acc[nb][kb], 0, 0, 0);
+#endif
       if (do_bias) {  // 4 x v_dot2c_f32_bf16 against (1, 1) per fragment
         const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
 #pragma unroll
@@ -253,7 +268,11 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + ncol_w + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 5
+        if (n < p.N && k < p.K && acc[nb][kb][r] == 12345.678f) p.dW[(int64_t)n * p.ldw + k] = 1.f;
+#else
         if (n < p.N && k < p.K) atomicAdd(p.dW + (int64_t)n * p.ldw + k, acc[nb][kb][r]);
+#endif
       }
     }
   if (do_bias) {

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void b64_features_kernel(const uint8_t* __rest
   const int64_t total = (int64_t)R * D;
   // the text must hold the whole num_boxes x D array: 4 * ceil(4 nb D / 3) characters
   const int64_t need_chars = (((int64_t)max(nb, 0) * D * 4 + 2) / 3) * 4;
-  if (threadIdx.x == 0 && blockIdx.x == 0 && (nb < 0 || t1 - t0 < need_chars || (t0 & 15))) atomicOr(err, 1);
+  const bool short_text = (nb < 0 || t1 - t0 < need_chars || (t0 & 15));
+  if (threadIdx.x == 0 && blockIdx.x == 0 && short_text) atomicOr(err, 1);
   const int64_t groups = (total + 2) / 3;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t f0 = g * 3;
@@ -66,15 +67,20 @@ __global__ __launch_bounds__(256) void b64_features_kernel(const uint8_t* __rest
       v[0] = __builtin_bit_cast(float, d0);
       v[1] = __builtin_bit_cast(float, d1);
       v[2] = __builtin_bit_cast(float, d2);
-      // characters that only feed floats beyond `valid` (the '=' padding, dropped rows) are not checked
-      if (bad && f0 + 2 < valid) atomicOr(err, 2);
-      if (bad && f0 + 2 >= valid) {
-        // the group straddles the end of the kept data: re-check the characters the kept floats use
-        const int64_t kept_bytes = (valid - f0) * 4;  // 4 or 8
-        const int kept_chars = (int)((kept_bytes * 4 + 2) / 3);
-        int b2 = 0;
-        for (int c = 0; c < kept_chars; ++c) b2 |= b64_val(text[t0 + g * 16 + c]) < 0;
-        if (b2) atomicOr(err, 2);
+      // only characters that feed kept floats and lie inside the sample's text are checked: the '='
+      // padding, dropped rows and (for a text flagged short) the bytes past its end are not
+      if (bad && !short_text) {   // a short text is an error already; its '=' padding sits among "kept" floats
+        int kept_chars = 16;
+        if (f0 + 2 >= valid) kept_chars = (int)(((valid - f0) * 16 + 2) / 3);   // 4 or 8 bytes -> 6 or 11 chars
+        const int64_t inside = t1 - (t0 + g * 16);
+        if (inside < kept_chars) kept_chars = (int)inside;
+        if (kept_chars >= 16) {
+          atomicOr(err, 2);
+        } else {
+          int b2 = 0;
+          for (int c = 0; c < kept_chars; ++c) b2 |= b64_val(text[t0 + g * 16 + c]) < 0;
+          if (b2) atomicOr(err, 2);
+        }
       }
     }
 #pragma unroll

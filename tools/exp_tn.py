@@ -9,8 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mvp_pytorch_amd import hip  # noqa: E402
 
-if len(sys.argv) > 1 and sys.argv[1] == "exp":
-    hip.LIB_PATH = os.path.join(ROOT, "mvp_pytorch_amd", "csrc", "libmvptr_hip_exp.so")
+# argv[1]: "prod" | "exp" (one 16-B read per fragment) | "exp2" no MFMA | "exp3" no LDS reads |
+# "exp4" no LDS-DMA | "exp5" no atomic write-out   (make -C mvp_pytorch_amd/csrc ablate)
+if len(sys.argv) > 1 and sys.argv[1].startswith("exp"):
+    hip.LIB_PATH = os.path.join(ROOT, "mvp_pytorch_amd", "csrc", "libmvptr_hip_%s.so" % sys.argv[1])
 dev = torch.device("cuda:0")
 
 
