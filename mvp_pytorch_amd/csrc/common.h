@@ -183,6 +183,38 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+// the same from values that ARE wave-uniform but that the compiler may not be able to prove so (it
+// would then wrap every buffer operation in a waterfall loop): broadcast the inputs explicitly
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const uint32_t nb = __builtin_amdgcn_readfirstlane(bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)nb, 0x00020000);
+}
+
+// Hand-issued LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, LDS destination = lds_byte_addr +
+// 16 * lane).  hipcc does not see the load: no compiler-inserted waits, the caller counts vmcnt.
+// The descriptor words must be wave-uniform (make_rsrc_words); M0 is written in the same statement.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t voffset, uint32_t lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc)
+               : "memory");
+}
+
 // bijective XCD-aware remap of a 1-D block id (8 XCDs, blocks dealt round-robin):
 // blocks that share an XCD get a contiguous range of logical tile ids.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -12,6 +12,7 @@
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -295,6 +296,260 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 #endif
 }
 
+// "Q" configuration: 256(n) x 256(k) output tile per 256-thread workgroup, FOUR waves as 2(n) x 2(k),
+// each 128x128 = 4x4 v_mfma_f32_32x32x16_bf16 (256 accumulator registers, one wave per SIMD with the
+// whole 512-register file).  Against the 64x64 wave tiles above this halves the transposed LDS
+// reads per MFMA (16 ds_read_b64_tr_b16 per 16 MFMAs) and against the 256x128 tile it needs a third
+// fewer L2->LDS bytes per FLOP — the two resources the ablation builds showed to be co-limiting.
+// 32 token rows per stage (32 KiB), STAGES-deep ring.  A lone wave per SIMD has no partner to cover
+// its barrier / LDS-DMA issue / fragment-read latency, so the loop is rotated: the barrier that
+// certifies stage st+1 sits between the two 16-row halves of stage st, and what follows it (issue of
+// stage st+STAGES into the buffer just freed, fragment reads of the next stage's first half) runs
+// under the 16 MFMAs of the second half, whose fragments are already in registers.
+template <int STAGES>
+__global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
+  constexpr int TM_ = 32;
+  constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
+  constexpr int STAGE_B = 4 * SUB_B;   // A: 2 sub-tiles (256 n), B: 2 sub-tiles (256 k)
+  constexpr int NI = 4, LPS = 8;       // staging instructions per wave: 4 for A, 4 for B
+  constexpr int TKW = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gidx = xcd_remap(blockIdx.x, gridDim.x);
+  // problem lookup by uniform selects (a dynamically indexed kernel-argument array would be copied
+  // to scratch and fetched on the vector path, which turns every buffer operation into a waterfall loop)
+  GemmTnArgs p = grp.prob[0];
+  int pbase = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
+    if (i < grp.count && gidx >= grp.base[i]) {
+      p = grp.prob[i];
+      pbase = grp.base[i];
+    }
+  const int nt = p.tiles_n * p.tiles_k;
+  const int idx = gidx - pbase;
+  const int split = idx / nt;
+  const int t = idx - split * nt;
+  const int tn = t / p.tiles_k;
+  const int tk = t - tn * p.tiles_k;
+  const int n0 = tn * TN_, k0 = tk * TKW;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int rows = m_end - m_begin;
+  if (rows <= 0) return;
+  const int ncols = min(TN_, p.N - n0);
+  const int kcols = min(TKW, p.K - k0);
+  const int ncols8 = (int)min((int64_t)((ncols + 7) & ~7), p.lda - n0);
+  const int kcols8 = (int)min((int64_t)((kcols + 7) & ~7), p.ldb - k0);
+  const u32x4 rsA = make_rsrc_words(
+      p.A + (int64_t)m_begin * p.lda + n0, (uint32_t)(((int64_t)(rows - 1) * p.lda + ncols8) * 2));
+  const u32x4 rsB = make_rsrc_words(
+      p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
+  const uint32_t lds0 = lds_addr(lds);
+
+  // staging instruction i of this wave fills LDS KiB (i * 4 + wave) of the operand: sub-tile
+  // (i * 4 + wave) / 8, 4-row group (i * 4 + wave) % 8
+  uint32_t offA[NI], offB[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = i * 4 + wave;
+    const int row = (j & 7) * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ swz256(row);
+    const int col = (j >> 3) * 128 + ch * 8;
+    offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
+    offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
+  }
+  const uint32_t stepA = (uint32_t)(TM_ * p.lda * 2), stepB = (uint32_t)(TM_ * p.ldb * 2);
+  // The LDS-DMA loads are inline asm: hipcc does not count them, so it neither drains them with a
+  // vmcnt(0) in front of the next ds_read (it does for the builtin form) nor needs to know their
+  // count; every wait for them is the hand-counted one in front of the barrier.
+  // piece i (0..7) of a stage: A instructions 0..3, then B instructions 0..3
+  auto stage_piece = [&](int buf, int st, int i) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
+    if (i < NI) {
+      const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)st * stepA;
+      lds_dma16(rsA, va, la + i * 4096);
+    } else {
+      const int j = i - NI;
+      const uint32_t vb = (offB[j] == MVPTR_OOB) ? MVPTR_OOB : offB[j] + (uint32_t)st * stepB;
+      lds_dma16(rsB, vb, la + 2 * SUB_B + j * 4096);
+    }
+  };
+  auto stage = [&](int buf, int st) {
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i) stage_piece(buf, st, i);
+  };
+
+  const int wn = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int h = g >> 1, cb = g & 1;
+  const int q = i16 >> 2, pp = i16 & 3;
+  // transposed-read offsets of the first 16-row half; the second half adds 4096 bytes
+  uint32_t ta[4][2], tb[4][2];
+#pragma unroll
+  for (int hl = 0; hl < 2; ++hl) {
+    const int row = 8 * h + 4 * hl + q;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ch = b * 4 + 2 * cb + (pp >> 1);
+      const uint32_t o = row * 256 + ((ch ^ swz256(row)) << 4) + 8 * (pp & 1);
+      ta[b][hl] = (uint32_t)wn * SUB_B + o;
+      tb[b][hl] = (uint32_t)(2 + wk) * SUB_B + o;
+    }
+  }
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  auto read_frags = [&](const char* base, bf16x8(&fa)[4], bf16x8(&fb)[4]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fa[b] = tr_frag(base, ta[b][0], ta[b][1]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fb[b] = tr_frag(base, tb[b][0], tb[b][1]);
+  };
+  // fragment reads in the order B0 B1 | B2 B3 | A0 A1 | A2 A3 (one pair per quarter): a quarter's
+  // MFMAs use A-fragment j with all four B fragments, so everything the next half's first quarter
+  // needs has been requested at least a quarter (4 MFMAs) earlier
+  auto read_pair = [&](const char* base, int j, bf16x8(&fa)[4], bf16x8(&fb)[4]) {
+    if (j < 2) {
+      fb[2 * j] = tr_frag(base, tb[2 * j][0], tb[2 * j][1]);
+      fb[2 * j + 1] = tr_frag(base, tb[2 * j + 1][0], tb[2 * j + 1][1]);
+    } else {
+      fa[2 * j - 4] = tr_frag(base, ta[2 * j - 4][0], ta[2 * j - 4][1]);
+      fa[2 * j - 3] = tr_frag(base, ta[2 * j - 3][0], ta[2 * j - 3][1]);
+    }
+  };
+  // BIAS is a compile-time tag: a run-time branch inside the MFMA loop made hipcc spill the loop's
+  // LDS offsets to scratch (whose reloads count in vmcnt beside the LDS-DMA loads)
+  auto mma_row = [&](int nb, const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto bias_tag) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nb], fb[kb], acc[nb][kb], 0, 0, 0);
+    if constexpr (decltype(bias_tag)::value) {
+      const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
+        bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
+      }
+    }
+  };
+
+  const int nsteps = (rows + TM_ - 1) / TM_;
+#pragma unroll
+  for (int i = 0; i < STAGES; ++i)
+    if (i < nsteps) stage(i, i);
+  // stage 0 has landed once only the younger issued stages remain outstanding
+  {
+    const int younger = min(STAGES, nsteps) - 1;
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  read_frags(lds, fa0, fb0);
+  auto main_loop = [&](auto bias_tag) {
+    int buf = 0;
+    // one 32-row stage = two 16-row halves of four quarters (4 MFMAs each).  First half: MFMAs on
+    // F0 beside the reads of F1 (second 16 rows of this stage).  Then the barrier.  Second half:
+    // MFMAs on F1 beside the LDS-DMA issue of stage st+STAGES (into the buffer just freed) and the
+    // reads of the next stage's F0.  sched_barrier(0) pins the quarters: hipcc otherwise sinks the
+    // reads below the MFMAs and the wave then waits out a full LDS latency with an idle matrix pipe.
+    // STEADY: the stage STAGES ahead exists and STAGES-2 younger stages stay in flight.
+    auto step = [&](int st, auto steady_tag) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      const char* cur = lds + buf * STAGE_B;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        read_pair(cur + 4096, j, fa1, fb1);
+        mma_row(j, fa0, fb0, bias_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+      const bool more = STEADY || st + 1 < nsteps;
+      if (more) {
+        // this wave's reads of stage st are complete (lgkmcnt(0), as a builtin so that hipcc knows
+        // F1 has landed and puts no wait between the barrier and its MFMAs); after the barrier
+        // every wave's are, and the buffer can be refilled
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if constexpr (STEADY) {
+          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
+        } else {
+          const int younger = min(STAGES - 2, nsteps - 2 - st);
+          if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      const char* nxt = lds + nbuf * STAGE_B;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (STEADY) {
+          stage_piece(buf, st + STAGES, 2 * j);
+          stage_piece(buf, st + STAGES, 2 * j + 1);
+        }
+        if (more) read_pair(nxt, j, fa0, fb0);
+        mma_row(j, fa1, fb1, bias_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      buf = nbuf;
+    };
+    int st = 0;
+    for (; st + STAGES < nsteps; ++st) step(st, std::true_type{});
+    for (; st < nsteps; ++st) step(st, std::false_type{});
+  };
+  if (do_bias) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+
+  // write-out: f32 atomics, one accumulator register = two 128-B row segments per wave instruction.
+  // The lane-derived addresses are formed from an opaque copy of the lane id so that they are
+  // computed here and not hoisted above the main loop (256 live addresses would be spilled).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int l31 = lane_e & 31, hh = lane_e >> 5;
+  const int nw = n0 + wn * 128 + 4 * hh, kw = k0 + wk * 128 + l31;
+  const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
+  float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
+  if (full) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* rowp = wbase + (int64_t)(nb * 32 + (r & 3) + 8 * (r >> 2)) * p.ldw;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) atomicAdd(rowp + kb * 32, acc[nb][kb][r]);
+      }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = nb * 32 + (r & 3) + 8 * (r >> 2);
+        float* rowp = wbase + (int64_t)nn * p.ldw;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if (nw + nn < p.N && kw + kb * 32 < p.K) atomicAdd(rowp + kb * 32, acc[nb][kb][r]);
+      }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
+      const int n = n0 + wn * 128 + nb * 32 + l31;
+      if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
+    }
+  }
+}
+
 __global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float* out,
                               int rows_per_block) {
   // block handles a 64-column strip x rows_per_block rows; 256 threads = 4 row lanes x 64 cols
@@ -328,6 +583,17 @@ int launch_tn(const GemmTnGroup& g, hipStream_t stream) {
   return MVPTR_OK;
 }
 
+template <int STAGES>
+int launch_tn_q(const GemmTnGroup& g, hipStream_t stream) {
+  const int lds_b = STAGES * 4 * 32 * 256;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_q_kernel<STAGES>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
+  MVPTR_CHECK_LAUNCH("gemm_tn");
+  return MVPTR_OK;
+}
+
 struct TnPlan {
   int tm, ksub, splits;
   double cost;
@@ -336,10 +602,10 @@ struct TnPlan {
 // Estimated time of one configuration for `tiles` output tiles of one launch (all problems of a
 // group share M, so they share the split count): whole rounds of workgroups x steps per split,
 // plus the f32 atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
-TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub) {
+TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
-  // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1)
-  const double t64 = (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
+  // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1; "Q": round 2)
+  const double t64 = quad ? 1.9 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
   TnPlan best{tm, ksub, 1, 1e30};
   const int max_splits = (M + 255) / 256;
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
@@ -369,20 +635,20 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
   // four configurations (see gemm_tn_kernel); MVPTR_GEMM_TN = "32" | "64" | "k2" | "K" forces one
   // (tuning knob).  The 256x256 tiles measured no faster than 256x128 at two workgroups per CU on
   // this model's shapes, so only the 256x128 tiles compete by default.
-  const int cfg_tm[4] = {32, 64, 32, 64}, cfg_ks[4] = {1, 1, 2, 2};
-  TnPlan plans[4];
-  for (int c = 0; c < 4; ++c) {
+  const int cfg_tm[5] = {32, 64, 32, 64, 32}, cfg_ks[5] = {1, 1, 2, 2, 2};
+  TnPlan plans[5];
+  for (int c = 0; c < 5; ++c) {
     int tiles = 0;
     int64_t out_elems = 0;
     for (int i = 0; i < count; ++i) {
       tiles += ((probs[i].N + TN_ - 1) / TN_) * ((probs[i].K + cfg_ks[c] * 128 - 1) / (cfg_ks[c] * 128));
       out_elems += (int64_t)probs[i].N * probs[i].K;
     }
-    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c]);
+    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4);
   }
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
   const char* env = mvptr_knobs().gemm_tn;
-  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : 0;
+  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q') ? 4 : 0;
   const TnPlan pl = plans[pick];
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
@@ -422,6 +688,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
+  if (pick == 4) return launch_tn_q<4>(g, stream);
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
   if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);

@@ -109,7 +109,7 @@ def test_gemm_tn(dev, M, N, K):
     dy[:, :N] = _bf(torch.randn(M, N, generator=g))
     dy = dy.to(dev)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    for cfg in ("32", "64", "k2", "K", None):  # every tile configuration + the planner's own choice
+    for cfg in ("32", "64", "k2", "K", "q", None):  # every tile configuration + the planner's own choice
         if cfg is None:
             hip.set_knob("MVPTR_GEMM_TN", "")
         else:
@@ -147,7 +147,7 @@ def test_gemm_tn_multi(dev):
     dw5 = torch.zeros(104, 72, device=dev)
     probs.append((dy5, x5, dw5, None))
     refs.append(dy5.float().t() @ x5.float())
-    for cfg in ("32", "K", None):
+    for cfg in ("32", "K", "q", None):
         if cfg is None:
             hip.set_knob("MVPTR_GEMM_TN", "")
         else:

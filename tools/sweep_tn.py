@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvp_pytorch_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
-CFGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto", "32", "64", "k2", "K"]
+CFGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto", "32", "64", "k2", "K", "q"]
 
 
 def timeit(fn, reps=10):
@@ -26,7 +26,7 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for M in (37748, 10917, 3000):
+for M in (64000, 37748, 10917, 3000):
     for N, K, name in ((2304, 768, "w_qkv"), (768, 768, "w_o"), (3072, 768, "w_i"), (768, 3072, "w_out")):
         dy = (torch.randn(M, N, device=dev) * 0.5).to(torch.bfloat16)
         x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
