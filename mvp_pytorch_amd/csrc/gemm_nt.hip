@@ -25,6 +25,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -682,6 +683,287 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNtArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Q" configuration: 256x256 tile per 256-thread workgroup, FOUR waves as 2(M) x 2(N), each
+// 128x128 = 4x4 v_mfma_f32_32x32x16_bf16 (256 accumulator registers; one wave per SIMD owns the
+// whole 512-register file).  Per MFMA: half a ds_read_b128 (8 fragment reads per 16 MFMAs) and the
+// fewest L2->LDS bytes per FLOP of any tile here.
+//  * 64 k per stage (whole 128-byte lines per row: half-line fetches of a 32-k stage measured 10 %
+//    slower), 64 KiB per stage, double buffer; a row's eight 16-byte chunks XOR-swizzled with
+//    (row >> 1) & 7: the 32x32x16 operand reads (a lane reads chunk 2s+h of row r) are conflict free.
+//  * the LDS-DMA loads are hand-issued (lds_dma16): hipcc drains the builtin form with a vmcnt(0)
+//    in front of the next ds_read, which serialises a ring; here every wait is the counted one in
+//    front of the barrier.
+//  * rotated loop (see gemm_tn_q_kernel): the barrier sits in front of the last of a stage's four
+//    16-k sub-steps; the LDS-DMA issue of the stage after next and the fragment reads of the next
+//    stage run under that sub-step's 16 MFMAs; quarters pinned with sched_barrier(0).
+//  * the weight tile is the MFMA A operand: a lane holds 4 consecutive output columns per register
+//    group; v_permlane32_swap pairs two groups so that each lane owns 8 consecutive columns of one
+//    row and the epilogue finishes straight from registers with 16-byte loads / stores (no LDS
+//    restaging; a row's 128 columns are written by 4 consecutive store instructions).
+template <int EPI>
+__device__ __forceinline__ void ntq_finish8(const GemmNtArgs& p, int m, int n, float (&v)[8]) {
+  // v = 8 consecutive columns n..n+7 of row m of the f32 product; N % 8 == 0 (launch condition)
+  if (m >= p.M || n >= p.N) return;
+  if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] += b0[e];
+      v[4 + e] += b1[e];
+    }
+  }
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (kNeedsAux && p.aux != nullptr) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p.aux + (int64_t)m * p.ld_aux + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = bf2f(x[e]);
+  }
+  auto store_bf8 = [&](void* base, const float (&o)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(o[e]);
+    *reinterpret_cast<bf16x8*>((__bf16*)base + (int64_t)m * p.ldc + n) = t;
+  };
+  if (EPI == MVPTR_EPI_BIAS) {
+    store_bf8(p.out0, v);
+  } else if (EPI == MVPTR_EPI_BIAS_GELU) {
+    float g[8], dg[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      f32x2 a2, d2;
+      gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+      g[e] = a2.x;
+      g[e + 1] = a2.y;
+      dg[e] = d2.x;
+      dg[e + 1] = d2.y;
+    }
+    store_bf8(p.out0, dg);
+    store_bf8(p.out1, g);
+  } else if (EPI == MVPTR_EPI_BIAS_RESID) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)  // N even: (m * N + n + e) even, lanes own whole hash pairs
+      drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a[e];
+    store_bf8(p.out0, v);
+  } else if (EPI == MVPTR_EPI_GELU_BWD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= a[e];
+    store_bf8(p.out0, v);
+  } else if (EPI == MVPTR_EPI_ADD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a[e];
+    store_bf8(p.out0, v);
+  } else if (EPI == MVPTR_EPI_F32) {
+    float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
+    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else if (EPI == MVPTR_EPI_BIAS_TANH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+    store_bf8(p.out0, v);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_ntq_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int OP_B = 256 * BK * 2;      // one operand tile of a stage (32 KiB)
+  constexpr int STAGE_B = 2 * OP_B;       // activations, then weights
+  constexpr int LPS = 16;                 // LDS-DMA instructions per wave and stage
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int gsz = GROUP_M * p.tiles_n;
+  const int grp = t / gsz;
+  const int first_m = grp * GROUP_M;
+  const int gm = min(GROUP_M, p.tiles_m - first_m);
+  const int in_g = t - grp * gsz;
+  const int tm = first_m + in_g % gm;
+  const int tn = in_g / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int rows_a = min(BM, p.M - m0);
+  const int rows_b = min(BN, p.N - n0);
+  const u32x4 rsA = make_rsrc_words(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+  const u32x4 rsB = make_rsrc_words(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
+  const uint32_t lds0 = lds_addr(lds);
+
+  // staging instruction i (0..7) of this wave fills KiB (i * 4 + wave) of an operand tile: rows
+  // 8 * (i * 4 + wave) .. + 7, whole 128-byte lines; lane -> row + (lane >> 3), 16-byte slot
+  // lane & 7 holds k-chunk slot ^ ((row >> 1) & 7) = slot ^ ((4 * (wave & 1) + (lane >> 4)) & 7)
+  const int srow = wave * 8 + (lane >> 3);
+  const int kc = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
+  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
+  const uint32_t rstepA = (uint32_t)(32 * p.lda * 2), rstepB = (uint32_t)(32 * p.ldb * 2);
+  auto stage_piece = [&](int buf, int st, int i) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
+    const bool in_k = (st * BK + kc < p.K);
+    if (i < 8) {
+      const uint32_t va = in_k ? offA0 + (uint32_t)i * rstepA + (uint32_t)(st * BK * 2) : MVPTR_OOB;
+      lds_dma16(rsA, va, la + i * 4096);
+    } else {
+      const uint32_t vb = in_k ? offB0 + (uint32_t)(i - 8) * rstepB + (uint32_t)(st * BK * 2) : MVPTR_OOB;
+      lds_dma16(rsB, vb, la + OP_B + (i - 8) * 4096);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  // fragment offsets of the four 16-k sub-steps; row block b adds b * 4096 (an immediate)
+  uint32_t fx[4], fw[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const uint32_t o = (uint32_t)(r31 * 128 + (((2 * s4 + h) ^ ((r31 >> 1) & 7)) << 4));
+    fx[s4] = (uint32_t)(wm * 128 * 128) + o;
+    fw[s4] = (uint32_t)(OP_B + wn * 128 * 128) + o;
+  }
+
+  f32x16 acc[4][4];  // [nb][mb]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 wf0[4], xf0[4], wf1[4], xf1[4];
+  // quarter nb multiplies W fragment nb with all four X fragments.  The eight fragment reads of a
+  // sub-step are spread X0 X1 X2 | X3 W0 W1 | W2 W3 | - over the quarters of the previous sub-step:
+  // the last quarter issues none, so they have all landed when the next sub-step's first MFMA waits
+  auto read_frag = [&](const char* base, int s4, int f, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
+    if (f < 4) xf[f] = *reinterpret_cast<const bf16x8*>(base + fx[s4] + f * 4096);
+    else wf[f - 4] = *reinterpret_cast<const bf16x8*>(base + fw[s4] + (f - 4) * 4096);
+  };
+  auto read_quarter = [&](const char* base, int s4, int j, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
+    constexpr int first[5] = {0, 3, 6, 8, 8};
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f >= first[j] && f < first[j + 1]) read_frag(base, s4, f, wf, xf);
+  };
+  auto mma_row = [&](int nb, const bf16x8(&wf)[4], const bf16x8(&xf)[4]) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+      acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+  };
+
+  const int nsteps = (p.K + BK - 1) / BK;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) stage_piece(0, 0, j);
+  if (nsteps > 1) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) stage_piece(1, 1, j);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_quarter(lds, 0, j, wf0, xf0);
+  // One 64-k stage = four 16-k sub-steps of 16 MFMAs; sub-step s multiplies the fragments read
+  // during sub-step s-1.  The barrier sits in front of the LAST sub-step: by then this wave has read
+  // all of stage st (lgkmcnt(0)) and the next stage has landed (it is the only one in flight), so the
+  // last sub-step's MFMAs cover the LDS-DMA issue of stage st+2 into the buffer just freed and the
+  // reads of the next stage's first fragments.
+  // MORE / REFILL are compile-time tags (run-time branches around the MFMA quarters make hipcc spill).
+  auto step = [&](int st, auto more_tag, auto refill_tag) {
+    constexpr bool MORE = decltype(more_tag)::value, REFILL = decltype(refill_tag)::value;
+    const char* cur = lds + (st & 1) * STAGE_B;
+    const char* nxt = lds + ((st + 1) & 1) * STAGE_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 1, j, wf1, xf1);
+      mma_row(j, wf0, xf0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 2, j, wf0, xf0);
+      mma_row(j, wf1, xf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 3, j, wf1, xf1);
+      mma_row(j, wf0, xf0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MORE) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of stage st are done
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (REFILL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_piece(st & 1, st + 2, 4 * j + i);
+      }
+      if constexpr (MORE) read_quarter(nxt, 0, j, wf0, xf0);
+      mma_row(j, wf1, xf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  {
+    int st = 0;
+    for (; st + 2 < nsteps; ++st) step(st, std::true_type{}, std::true_type{});
+    if (st + 1 < nsteps) step(st++, std::true_type{}, std::false_type{});
+    step(st, std::false_type{}, std::false_type{});
+  }
+
+  // epilogue straight from the accumulators.  Block (nb, mb): lane (r31, h) holds row m = ..+r31,
+  // columns 8g + 4h + (0..3) in registers 4g..4g+3; swapping group 2q+1 of the low half-wave with
+  // group 2q of the high half-wave leaves columns 16q + 8h + (0..7) in each lane.
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int er = lane_e & 31, eh = lane_e >> 5;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wm * 128 + mb * 32 + er;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = acc[nb][mb][8 * q2 + e], hi = acc[nb][mb][8 * q2 + 4 + e];
+          // lanes 32-63 of `lo` <-> lanes 0-31 of `hi` (two wait states after a VALU write of either)
+          asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+          v[e] = lo;
+          v[4 + e] = hi;
+        }
+        const int n = n0 + wn * 128 + nb * 32 + 16 * q2 + 8 * eh;
+        ntq_finish8<EPI>(p, m, n, v);
+      }
+  }
+}
+
+template <int EPI>
+int launch_q(GemmNtArgs a, hipStream_t s) {
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 64 * 2;  // 128 KiB
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntq_kernel<EPI>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_ntq_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
+}
+// what the "Q" kernel's register epilogue needs: whole 8-column runs and 16-byte accesses
+inline bool q_eligible(const GemmNtArgs& a) {
+  if ((a.N & 7) || !a.vec_out_ok || a.vec_out != nullptr) return false;
+  if (a.aux != nullptr && !a.vec_aux_ok) return false;
+  if (a.bias != nullptr && !a.vec_bias_ok) return false;
+  return true;
+}
+
 template <int EPI>
 int launch_persist(GemmNtArgs a, hipStream_t s) {
   using C = Cfg<64, 2, 2, 4, 8>;
@@ -742,6 +1024,10 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
     const size_t n = strlen(env);
+    if (env[0] == 'q') {
+      if (!q_eligible(a)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=q needs N %% 8 == 0, 16-byte aligned operands, no vec_out");
+      return launch_q<EPI>(a, s);
+    }
     if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128": 128x128, 4 waves
     if (env[0] == 'h') return launch_bk<EPI, 32, 3, 2, 2, 8, 0>(a, s);  // "h4": 256x128, 4 waves of 128x64, 2 WG/CU

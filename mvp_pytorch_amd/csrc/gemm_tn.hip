@@ -605,7 +605,7 @@ struct TnPlan {
 TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
   // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1; "Q": round 2)
-  const double t64 = quad ? 1.9 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
+  const double t64 = quad ? 1.5 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
   TnPlan best{tm, ksub, 1, 1e30};
   const int max_splits = (M + 255) / 256;
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
@@ -646,10 +646,14 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
     }
     plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4);
   }
+  // "Q" (256x256 tile, four waves of 128x128) wins from ~6 k token rows up (tools/sweep_tn.py,
+  // tools/sweep_tn_group.py: 1.0-1.15 PF/s against 0.7-0.8 at M >= 19 k, +8 % at 11 k, -7 % at 3 k)
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
+  if (M >= 6000) pick = 4;
   const char* env = mvptr_knobs().gemm_tn;
   if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q') ? 4 : 0;
-  const TnPlan pl = plans[pick];
+  TnPlan pl = plans[pick];
+  if (mvptr_knobs().tn_splits > 0) pl.splits = min(mvptr_knobs().tn_splits, (M + 255) / 256);
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
   // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)

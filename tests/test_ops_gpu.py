@@ -41,6 +41,53 @@ def test_gemm_nt_bias(dev, M, N, K):
     hip.set_knob("MVPTR_GEMM_CFG", "")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (300, 2304, 768), (777, 768, 3072), (37, 104, 64), (515, 1000, 136), (500, 768, 2056), (1030, 520, 40)])
+def test_gemm_nt_q_config(dev, M, N, K):
+    """The 256x256 / four-wave "Q" tile configuration: every epilogue, ragged M, N and K edges."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = _bf(torch.randn(M, N, generator=g)).to(dev)
+    base = a.float() @ b.float().t()
+    hip.set_knob("MVPTR_GEMM_CFG", "q")
+    try:
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_F32, bias=bias), base + bias) < 1e-5
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias), base + bias) < 4e-3
+        dact, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+        uref = (base + bias).requires_grad_(True)
+        aref = torch.nn.functional.gelu(uref)
+        aref.sum().backward()
+        assert _rel(act, aref.detach()) < 4e-3
+        assert _rel(dact, uref.grad) < 4e-3
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux), base + bias + aux.float()) < 4e-3
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS_TANH, bias=bias), torch.tanh(base + bias)) < 4e-3
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux), base + aux.float()) < 4e-3
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_ADD), base) < 4e-3
+        assert _rel(hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=aux), base * aux.float()) < 4e-3
+        drop = hip.make_dropout(0.1, 0x1234567890)
+        z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux, drop=drop)
+        keep = hip.dropout_mask(drop, M * N, dev).reshape(M, N).float()
+        scale = 65536.0 / (65536.0 - drop.thresh16)
+        assert _rel(z, (base + bias) * keep * scale + aux.float()) < 4e-3
+    finally:
+        hip.set_knob("MVPTR_GEMM_CFG", "")
+
+
+def test_gemm_nt_q_identity_layout(dev):
+    from mvp_pytorch_amd import hip
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    b = (torch.arange(192 * K, device=dev, dtype=torch.float32).reshape(192, K) % 251 - 125).to(torch.bfloat16)
+    hip.set_knob("MVPTR_GEMM_CFG", "q")
+    try:
+        out = hip.gemm_nt(a, b, hip.EPI_F32)
+    finally:
+        hip.set_knob("MVPTR_GEMM_CFG", "")
+    assert torch.equal(out, b.float().t().contiguous())
+
+
 def test_gemm_nt_identity_layout(dev):
     """A = I against an asymmetric B catches transposed / permuted fragment maps exactly."""
     from mvp_pytorch_amd import hip
