@@ -705,6 +705,7 @@ template <int EPI>
 __device__ __forceinline__ void ntq_finish8(const GemmNtArgs& p, int m, int n, float (&v)[8]) {
   // v = 8 consecutive columns n..n+7 of row m of the f32 product; N % 8 == 0 (launch condition)
   if (m >= p.M || n >= p.N) return;
+  if ((p.exp_flags & 4) && v[0] != 12345.678f) return;  // ablation (MVPTR_NT_EXP bit 2): no loads / math / stores
   if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr) {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -914,6 +915,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntq_kernel(GemmNtArgs p) {
     step(st, std::false_type{}, std::false_type{});
   }
 
+  if (p.exp_flags & 2) return;  // ablation (MVPTR_NT_EXP bit 1): no epilogue at all
   // epilogue straight from the accumulators.  Block (nb, mb): lane (r31, h) holds row m = ..+r31,
   // columns 8g + 4h + (0..3) in registers 4g..4g+3; swapping group 2q+1 of the low half-wave with
   // group 2q of the high half-wave leaves columns 16q + 8h + (0..7) in each lane.
@@ -941,6 +943,335 @@ __global__ __launch_bounds__(256, 1) void gemm_ntq_kernel(GemmNtArgs p) {
       }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// "QP": the Q tile as a PERSISTENT kernel with a DEFERRED epilogue.  With K = 768 a 256x256 tile is
+// ~20 us of MFMA work and 128-256 KiB of output; when every CU finishes its tile at the same time
+// the outputs leave as one burst at the chip's write rate (~3 TB/s: 100 us of a 300-us launch,
+// measured with the stores ablated) while no MFMA runs.  Here a workgroup walks over its tiles with
+// one continuous LDS-DMA / MFMA pipeline; at the end of a tile the accumulators (+ bias) are packed
+// to bf16 into 128 "pending" registers, and the epilogue proper (permlane swaps to 8-column runs,
+// GELU, the 16-byte stores) is dripped through the first eight 64-k stages of the NEXT tile, one
+// 32-row x 128-byte group per stage, under that tile's MFMAs.  Output writes are thereby spread
+// evenly over the launch and overlap the matrix pipe chip-wide.
+//  * stage loads run two stages ahead across tile boundaries (issue-side tile state in SGPRs); after
+//    the last tile the descriptors have zero records, so the tail needs no branches.
+//  * the first MFMA of every accumulator block of a tile takes C = 0: no accumulator clearing.
+//  * the bias row of a tile is staged in LDS (one LDS-DMA instruction of wave 0 in the tile's first
+//    stage) and added in f32 before the bf16 rounding: EPI_BIAS results are bit-identical to the
+//    other configurations.
+//  * needs K >= 512 (eight stages to drip into) and the Q conditions; epilogues without an aux operand.
+struct NtqpOut {
+  __amdgpu_buffer_rsrc_t out0, out1;
+};
+// Every call issues the same number of store instructions whatever the lane predicate (rows /
+// columns outside the problem, or no pending tile, take the always-out-of-range offset): the
+// barrier waits of the main loop count them.
+template <int EPI>
+__device__ __forceinline__ void ntqp_finish8(const GemmNtArgs& p, const NtqpOut& o, int m, int n, const u32x4& pk) {
+  // pk = 8 consecutive columns n..n+7 of row m, bf16(acc + bias)
+  const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : MVPTR_OOB;
+  if (EPI == MVPTR_EPI_BIAS) {
+    __builtin_amdgcn_raw_buffer_store_b128(pk, o.out0, off, 0, 0);
+  } else if (EPI == MVPTR_EPI_BIAS_GELU) {
+    u32x4 og, od;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u0 = __builtin_bit_cast(float, pk[e] << 16);
+      const float u1 = __builtin_bit_cast(float, pk[e] & 0xffff0000u);
+      f32x2 a2, d2;
+      gelu_pair(f32x2{u0, u1}, a2, d2);
+      const bf16x2 ga = {f2bf(a2.x), f2bf(a2.y)};
+      const bf16x2 gd = {f2bf(d2.x), f2bf(d2.y)};
+      og[e] = __builtin_bit_cast(uint32_t, ga);
+      od[e] = __builtin_bit_cast(uint32_t, gd);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(od, o.out0, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(og, o.out1, off, 0, 0);
+  }
+}
+template <int EPI>
+constexpr int ntqp_stores_per_unit() { return EPI == MVPTR_EPI_BIAS_GELU ? 2 : 1; }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int OP_B = 256 * BK * 2;      // one operand tile of a stage (32 KiB)
+  constexpr int STAGE_B = 2 * OP_B;       // activations, then weights
+  constexpr int BIAS_OFF = 2 * STAGE_B;   // two 1-KiB bias rows (tile parity)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = gridDim.x;
+  const int nk = (p.K + BK - 1) / BK;
+  const uint32_t lds0 = lds_addr(lds);
+
+  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
+    const int base = round * grid;
+    const int left = ntiles - base;
+    if (left <= 0) return false;
+    const int nthis = min(left, grid);
+    if ((int)blockIdx.x >= nthis) return false;
+    const int t = base + xcd_remap(blockIdx.x, nthis);
+    const int gsz = GROUP_M * p.tiles_n;
+    const int grp = t / gsz;
+    const int first_m = grp * GROUP_M;
+    const int gm = min(GROUP_M, p.tiles_m - first_m);
+    const int in_g = t - grp * gsz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+    return true;
+  };
+
+  // ---- issue side: the tile whose stages are being loaded (two stages ahead of the MFMAs)
+  int is_round = 0, is_k = 0;
+  u32x4 rsA, rsB;
+  auto issue_tile = [&](int round) {
+    int m0 = 0, n0 = 0;
+    if (tile_origin(round, m0, n0)) {
+      const int rows_a = min(BM, p.M - m0), rows_b = min(BN, p.N - n0);
+      rsA = make_rsrc_words(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+      rsB = make_rsrc_words(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
+    } else {
+      rsA = make_rsrc_words(p.A, 0u);  // zero records: every load returns zeros without touching memory
+      rsB = make_rsrc_words(p.B, 0u);
+    }
+  };
+  issue_tile(0);
+  const int srow = wave * 8 + (lane >> 3);
+  const int kc = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
+  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
+  const uint32_t rstepA = (uint32_t)(32 * p.lda * 2), rstepB = (uint32_t)(32 * p.ldb * 2);
+  auto stage_piece = [&](int buf, int i) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
+    const bool in_k = (is_k * BK + kc < p.K);
+    if (i < 8) {
+      const uint32_t va = in_k ? offA0 + (uint32_t)i * rstepA + (uint32_t)(is_k * BK * 2) : MVPTR_OOB;
+      lds_dma16(rsA, va, la + i * 4096);
+    } else {
+      const uint32_t vb = in_k ? offB0 + (uint32_t)(i - 8) * rstepB + (uint32_t)(is_k * BK * 2) : MVPTR_OOB;
+      lds_dma16(rsB, vb, la + OP_B + (i - 8) * 4096);
+    }
+  };
+  auto issue_advance = [&]() {
+    if (++is_k == nk) {
+      is_k = 0;
+      issue_tile(++is_round);
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r31 = lane & 31, h = lane >> 5;
+  uint32_t fx[4], fw[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const uint32_t o = (uint32_t)(r31 * 128 + (((2 * s4 + h) ^ ((r31 >> 1) & 7)) << 4));
+    fx[s4] = (uint32_t)(wm * 128 * 128) + o;
+    fw[s4] = (uint32_t)(OP_B + wn * 128 * 128) + o;
+  }
+
+  f32x16 acc[4][4];    // [nb][mb]
+  uint32_t pend[4][4][8];  // [nb][mb][register pair]: bf16(acc + bias) of the previous tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pend[i][j][e] = 0u;
+  int pm0 = 0x40000000, pn0 = 0;  // origin of the pending tile (none yet: no row passes m < M)
+
+  bf16x8 wf0[4], xf0[4], wf1[4], xf1[4];
+  auto read_frag = [&](const char* base, int s4, int f, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
+    if (f < 4) xf[f] = *reinterpret_cast<const bf16x8*>(base + fx[s4] + f * 4096);
+    else wf[f - 4] = *reinterpret_cast<const bf16x8*>(base + fw[s4] + (f - 4) * 4096);
+  };
+  auto read_quarter = [&](const char* base, int s4, int j, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
+    constexpr int first[5] = {0, 3, 6, 8, 8};
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f >= first[j] && f < first[j + 1]) read_frag(base, s4, f, wf, xf);
+  };
+  auto mma_row = [&](int nb, const bf16x8(&wf)[4], const bf16x8(&xf)[4], auto first_tag) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      if constexpr (decltype(first_tag)::value) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], z, 0, 0, 0);
+      } else {
+        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
+      }
+    }
+  };
+  const u32x4 rsBias = make_rsrc_words(p.bias, p.bias != nullptr ? (uint32_t)p.N * 4u : 0u);
+  const uint32_t out_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);  // < 4 GiB (launch condition)
+  NtqpOut outs;
+  outs.out0 = make_rsrc_uniform(p.out0, out_bytes);
+  outs.out1 = make_rsrc_uniform(p.out1 != nullptr ? p.out1 : p.out0, p.out1 != nullptr ? out_bytes : 0u);
+  // one unit of the deferred epilogue: block (nb, mb), register groups 2*q2 / 2*q2+1 -> the lane's
+  // 8-column run at columns 32 nb + 16 q2 + 8 h of row 32 mb + r31
+  auto drip_unit = [&](int nb, int mb, int q2) {
+    u32x4 pk;
+    uint32_t lo0 = pend[nb][mb][4 * q2], lo1 = pend[nb][mb][4 * q2 + 1];
+    uint32_t hi0 = pend[nb][mb][4 * q2 + 2], hi1 = pend[nb][mb][4 * q2 + 3];
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo0), "+v"(hi0));
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo1), "+v"(hi1));
+    pk[0] = lo0;
+    pk[1] = lo1;
+    pk[2] = hi0;
+    pk[3] = hi1;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int m = pm0 + wm * 128 + mb * 32 + (lane_e & 31);
+    const int n = pn0 + wn * 128 + nb * 32 + 16 * q2 + 8 * (lane_e >> 5);
+    ntqp_finish8<EPI>(p, outs, m, n, pk);
+  };
+  // group g (0..7) = rows 32 (g >> 1).., columns 64 (g & 1)..: four units = whole 128-byte lines
+  auto drip_group_unit = [&](int g, int u) { drip_unit(2 * (g & 1) + (u >> 1), g >> 1, u & 1); };
+
+
+  int round = 0, m0 = 0, n0 = 0;
+  tile_origin(0, m0, n0);  // grid <= ntiles: always valid
+  // prologue: two stages in flight, the first one landed
+#pragma unroll
+  for (int j = 0; j < 16; ++j) stage_piece(0, j);
+  issue_advance();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) stage_piece(1, j);
+  issue_advance();
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_quarter(lds, 0, j, wf0, xf0);
+  int bufsel = 0;
+
+  // G: drip group handled in this stage (-1: none); FIRST: the tile's first stage (C = 0 MFMAs and
+  // the bias-row load)
+  auto stage_body = [&](auto g_tag, auto first_tag, auto second_tag) {
+    constexpr int G = decltype(g_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    (void)second_tag;
+    const char* cur = lds + bufsel * STAGE_B;
+    const char* nxt = lds + (bufsel ^ 1) * STAGE_B;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 1, j, wf1, xf1);
+      mma_row(j, wf0, xf0, first_tag);
+      if constexpr (G >= 0) {
+        if (j == 1) drip_group_unit(G, 0);
+        if (j == 3) drip_group_unit(G, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 2, j, wf0, xf0);
+      mma_row(j, wf1, xf1, std::false_type{});
+      if constexpr (G >= 0) {
+        if (j == 1) drip_group_unit(G, 2);
+        if (j == 3) drip_group_unit(G, 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      read_quarter(cur, 3, j, wf1, xf1);
+      mma_row(j, wf0, xf0, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are done
+    // the next stage's loads are older than this stage's deferred stores, which may stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G >= 0 ? 4 * ntqp_stores_per_unit<EPI>() : 0) : "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stage_piece(bufsel, 4 * j + i);
+      read_quarter(nxt, 0, j, wf0, xf0);
+      mma_row(j, wf1, xf1, std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FIRST) {
+      // the tile's bias row (256 floats) goes to LDS by one LDS-DMA instruction of wave 0; the next
+      // barrier's vmcnt(0) covers it, the conversion at the end of the tile reads it
+      if (wave == 0)
+        lds_dma16(rsBias, (uint32_t)((n0 + lane * 4) * 4), lds0 + (uint32_t)(BIAS_OFF + (round & 1) * 1024));
+    }
+    issue_advance();
+    bufsel ^= 1;
+  };
+
+  for (;;) {
+    stage_body(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+    stage_body(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 3>{}, std::false_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 4>{}, std::false_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 5>{}, std::false_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 6>{}, std::false_type{}, std::false_type{});
+    stage_body(std::integral_constant<int, 7>{}, std::false_type{}, std::false_type{});
+    for (int kk = 8; kk < nk; ++kk)
+      stage_body(std::integral_constant<int, -1>{}, std::false_type{}, std::false_type{});
+    // tile end: accumulators + bias -> bf16 pending registers
+    {
+      const char* brow = lds + BIAS_OFF + (round & 1) * 1024 + (wn * 128 + 4 * h) * 4;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        f32x4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(brow + (nb * 32 + 8 * g) * 4);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = 2 * e;
+            const bf16x2 t2 = {f2bf(acc[nb][mb][r] + b[r >> 2][r & 3]), f2bf(acc[nb][mb][r + 1] + b[r >> 2][(r & 3) + 1])};
+            pend[nb][mb][e] = __builtin_bit_cast(uint32_t, t2);
+          }
+          // one block at a time: hipcc otherwise reads all 256 accumulators first and spills the
+          // loop's address registers to make room
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    pm0 = m0;
+    pn0 = n0;
+    ++round;
+    if (!tile_origin(round, m0, n0)) break;
+  }
+  // the last tile's epilogue
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) drip_group_unit(g, u);
+}
+
+template <int EPI>
+int launch_qp(GemmNtArgs a, hipStream_t s) {
+  constexpr int LDS_BYTES = 2 * 2 * 256 * 64 * 2 + 2048;  // 128 KiB ring + two bias rows
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff ||
+      (int64_t)a.M * a.ldc * 2 >= (int64_t)0x7fffffff)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntqp_kernel<EPI>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
+    num_cu = prop.multiProcessorCount;
+  }
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = ntiles < num_cu ? ntiles : num_cu;
+  hipLaunchKernelGGL((gemm_ntqp_kernel<EPI>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
+}
+template <int EPI>
+constexpr bool qp_has_epilogue() { return EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU; }
 
 template <int EPI>
 int launch_q(GemmNtArgs a, hipStream_t s) {
@@ -1024,6 +1355,14 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
     const size_t n = strlen(env);
+    if (env[0] == 'q' && env[1] == 'p') {
+      if constexpr (qp_has_epilogue<EPI>()) {
+        if (!q_eligible(a) || a.K < 512) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=qp needs the Q conditions and K >= 512");
+        return launch_qp<EPI>(a, s);
+      } else {
+        MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=qp: epilogue not supported");
+      }
+    }
     if (env[0] == 'q') {
       if (!q_eligible(a)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=q needs N %% 8 == 0, 16-byte aligned operands, no vec_out");
       return launch_q<EPI>(a, s);

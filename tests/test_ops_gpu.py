@@ -75,6 +75,34 @@ def test_gemm_nt_q_config(dev, M, N, K):
         hip.set_knob("MVPTR_GEMM_CFG", "")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (300, 2304, 768), (777, 768, 3072), (500, 768, 2056), (70000, 512, 512), (1030, 520, 1000)])
+def test_gemm_nt_qp_config(dev, M, N, K):
+    """The persistent Q kernel with the deferred epilogue: same results as the default configuration
+    (bit-identical for EPI_BIAS), several tiles per workgroup (M = 70000: 548 tiles on 256 CUs)."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(12)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
+    dref, aref = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+    ref0 = hip.gemm_nt(a, b, hip.EPI_BIAS)
+    hip.set_knob("MVPTR_GEMM_CFG", "qp")
+    try:
+        out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
+        out0 = hip.gemm_nt(a, b, hip.EPI_BIAS)
+        dact, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+    finally:
+        hip.set_knob("MVPTR_GEMM_CFG", "")
+    assert torch.equal(out, ref)
+    assert torch.equal(out0, ref0)
+    base = a[:2048].float() @ b.float().t() + bias
+    assert _rel(out[:2048], base) < 4e-3
+    # gelu of the bf16-rounded pre-activation: within bf16 rounding of the f32 path
+    assert _rel(act, aref) < 4e-3 and _rel(dact, dref) < 4e-3
+    assert _rel(act[:2048], torch.nn.functional.gelu(base)) < 6e-3
+
+
 def test_gemm_nt_q_identity_layout(dev):
     from mvp_pytorch_amd import hip
     K = 128
