@@ -207,7 +207,7 @@ def _cpu_baseline_single(seconds_budget, cores):
 
 class DominantMix:
     """Per-step launch mix of the two kernels that lead the rocprofv3 kernel summary
-    (profiles/r01_bench_kernel_stats_*.csv): gemm_tn_kernel (grouped weight gradients) and
+    (profiles/r02_bench_*_kernel_stats.csv): gemm_tn_q_kernel (grouped weight gradients) and
     gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward).  Row counts of a configs[1] step: text B*75, visual
     B*70, joint + hard-negative batch 2B*125; six layers each."""
 
@@ -280,9 +280,10 @@ def _time_launches(fn, reps):
 
 
 def _pmc_traffic(kernel, packed=True):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_dominant_traffic.json, made
-    by tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_traffic.json")
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_dominant_traffic.json, made
+    by tools/runs/r02_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
+    WRITE_SIZE, FETCH_SIZE calibrated on a known 1-GiB stream by tools/calib_fetch.py), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
@@ -291,7 +292,7 @@ def _pmc_traffic(kernel, packed=True):
 
 
 def kernel_roofline(dev, dims, cfg, batch=None, single=False):
-    """Dominant kernel by total time = gemm_tn_kernel (grouped weight gradients, 36 launches/step).
+    """Dominant kernel by total time = gemm_tn_q_kernel (grouped weight gradients, 36 launches/step).
     achieved = algorithmic FLOPs per launch / mean launch duration of the step's launch mix (row
     counts of the timed batch), timed with HIP events on the launch stream; the FFN1 forward GEMM
     (second by time) rides along."""
@@ -300,15 +301,16 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     nt_ms, nt_flops = _time_launches(mix.run_nt, 4)
     tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
     nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
-    t_tn, t_nt = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>"))
-    return dict(bound="mfma", kernel="gemm_tn_kernel<32,1,3> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and "
-                                     "attention pair per layer; M = %s rows)" % " / ".join(str(m) for m in mix.Ms),
+    t_tn, t_nt = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_q_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>"))
+    return dict(bound="mfma", kernel="gemm_tn_q_kernel<4> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and "
+                                     "attention pair per layer; 256x256 tiles, four waves of 128x128; M = %s rows)" % " / ".join(str(m) for m in mix.Ms),
                 achieved=round(tn_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
                 flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
                 traffic=(t_tn or {}).get("bytes_per_launch"),
-                traffic_source="profiles/r01_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
-                               "tools/prof_dominant.py; FETCH_SIZE doubled for the 16-B/lane streaming reads, gfx950 rule)",
+                traffic_source="profiles/r02_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                               "tools/prof_dominant.py; FETCH_SIZE divided by the factor measured on a known 1-GiB LDS-DMA stream, "
+                               "tools/calib_fetch.py)",
                 second_kernel=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu and gelu')",
                                    achieved=round(nt_ach, 1), frac=round(nt_ach / MFMA_BF16_PEAK_TFLOPS, 4),
                                    avg_launch_us=round(nt_ms * 1e3, 1), algorithmic_bytes_per_launch=round(mix.nt_bytes()),
@@ -402,6 +404,10 @@ def main():
     cls = modeling.BertImgForPreTraining if single else modeling.BiBertImgForPreTraining
     model = cls(modeling.make_config(cfg)).to(dev)
     model.train()
+    if single:
+        # loss-only training loop: masked rows through the fused decoder + cross-entropy kernels
+        # ("prediction_scores"); the reference's loop reads outputs[0] only
+        model.return_prediction_scores = False
     opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
     sync = dp.GradSync(model) if world > 1 else None
 
@@ -432,7 +438,7 @@ def main():
 
     batch = make_batch(args.fixed_length)
     lab_a = batch["lm_label_ids" if single else "lm_label_ids_a"]
-    n_text = int((lab_a > -1).sum().item()) if not single else args.batch * dims["T"]   # single-stream head scores all T positions
+    n_text = int((lab_a > -1).sum().item())   # the heads run on the scored rows only
     n_tag = 0 if single else int((batch["lm_label_ids_b"] > -1).sum().item())
     ms_per_step, loss = timed(batch, args.warmup, args.steps)
     value = world * args.batch / (ms_per_step * 1e-3)
@@ -466,7 +472,7 @@ def main():
         mk = "input_mask" if single else "input_mask_a"
         valid = {"text": round(float(batch[mk][:, :dims["T"] + dims["P"]].float().mean()), 3),
                  "tags+regions": round(float((batch[mk][:, dims["T"]:] if single else batch["input_mask_b"]).float().mean()), 3)}
-        what = ("BertImgForPreTraining (single-stream, 12 layers over 70 tok + 50 regions, MLM over all 70 text positions + ITM)"
+        what = ("BertImgForPreTraining (single-stream, 12 layers over 70 tok + 50 regions, MLM on the masked text positions + ITM)"
                 if single else
                 "BiBertImgForPreTraining BERT-base, 70 tok + 5 phrase slots, 20 tag slots, 50 regions x 2054-d, MLM+MCP+ITM+contrastive+WRA")
         out = {

@@ -240,6 +240,24 @@ int mvptr_ce_bwd(const float* logits, int64_t ld, const int64_t* labels, const f
                  const float* scale, void* dlogits, int64_t ld_d, int M, int V, int Vpad,
                  void* stream);
 
+/* Vocabulary decoder + CrossEntropyLoss(ignore_index < 0) WITHOUT the [M, V] f32 logits in HBM:
+ * replaces `prediction_scores = decoder(h) + bias` followed by the masked-LM loss
+ * (transformers/pytorch_transformers/modeling_bert.py:513-516; oscar/modeling/modeling_vlbert.py:1112-1125,
+ * 1245-1249) for callers that only need the loss.  h: bf16 [M, ldh] (K columns), W: bf16 [V, ldw],
+ * bias: f32 [V] or NULL, labels: int64 [M] (rows with a label outside [0, V) are not scored).
+ * Forward: the logits exist tile by tile in the GEMM epilogue only; `part` (f32 [M, ceil(V/64), 2]) takes
+ * the per-64-column (max, sum exp) partials, `lab_logit` (f32 [M]) the logit at the label; a second
+ * small kernel writes lse_row[m] and loss_row[m] = lse - logit[label] (0 for unscored rows). */
+int mvptr_decoder_ce_fwd(const void* h, int64_t ldh, const void* W, int64_t ldw, const float* bias,
+                         const int64_t* labels, int M, int V, int K, float* part, float* lab_logit,
+                         float* loss_row, float* lse_row, void* stream);
+/* Backward: the logits are recomputed by the same GEMM; its epilogue writes
+ * dlogits[m, n] = (exp(logit - lse_row[m]) - [n == label[m]]) * scale[0] as bf16 [M, ld_d] with columns
+ * V..Vpad-1 zero (0 everywhere for unscored rows): the operand of the data / weight gradient GEMMs. */
+int mvptr_decoder_ce_bwd(const void* h, int64_t ldh, const void* W, int64_t ldw, const float* bias,
+                         const int64_t* labels, const float* lse_row, const float* scale, int M, int V,
+                         int K, void* dlogits, int64_t ld_d, int Vpad, void* stream);
+
 /* Fused multi-tensor AdamW step with the numerics of
  * transformers/pytorch_transformers/optimization.py:131-187: m = b1 m + (1-b1) g;
  * v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) + eps); p *= decay  (decay = 1 - lr*wd,
@@ -348,6 +366,11 @@ int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights
                             const void* x, const float* mask_add, const void* saved,
                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
                             int64_t ws_bytes, void* stream);
+
+/* Measurement helper (never on the product path): reads `bytes` (a multiple of 4096) of `src` exactly
+ * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,
+ * so that rocprofv3's FETCH_SIZE can be calibrated against a known byte count (tools/calib_fetch.py). */
+int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

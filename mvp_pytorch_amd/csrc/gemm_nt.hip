@@ -77,7 +77,18 @@ struct GemmNtArgs {
   int delay_lo, delay_hi;
   int exp_flags;  // experiments (MVPTR_NT_EXP): bit 0 = persistent kernel without next-tile prefetch
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
+  // fused vocabulary decoder + cross entropy (mvptr_decoder_ce_fwd / _bwd)
+  const int64_t* labels;  // [M], < 0 or >= N: row not scored
+  const float* lse;       // [M] row log-sum-exp (backward)
+  const float* scale;     // [1] d(loss)/d(row loss) (backward)
+  float* part;            // [M, part_ld, 2] per-64-column (max, sum exp) partials (forward)
+  float* lab_logit;       // [M] logit at the label (forward)
+  int part_ld;
+  int n_store;            // columns written by EPI_CE_BWD (N rounded up to the operand padding)
 };
+// library-internal epilogues of the fused decoder + cross-entropy entry points
+constexpr int EPI_CE_PART = 7;  // per row and 64-column wave strip: (max, sum exp(v - max)) of v = acc + bias; logit at the label
+constexpr int EPI_CE_BWD = 8;   // out0(bf16) = (exp(v - lse[m]) - [n == label[m]]) * scale, 0 for unscored rows / pad columns
 
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -185,12 +196,65 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       v0 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch) ^ lrow) << 2));
       v1 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch + 1) ^ lrow) << 2));
     }
-    if (m >= p.M || n >= p.N) continue;
+    if constexpr (EPI == EPI_CE_PART) {
+      // online log-sum-exp over this lane's 8 columns, then over the 8 lanes that share the row
+      // (lane bits 0-2): every lane takes part in the shuffles, masked columns count as -inf
+      float mx = -1e30f, sm = 0.f, u[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u[e] = v0[e] + b8[e];
+        u[4 + e] = v1[e] + b8[4 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) mx = fmaxf(mx, u[e]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) sm += __expf(u[e] - mx);
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        const float m2 = __shfl_xor(mx, o), s2 = __shfl_xor(sm, o);
+        const float mm = fmaxf(mx, m2);
+        sm = sm * __expf(mx - mm) + s2 * __expf(m2 - mm);
+        mx = mm;
+      }
+      if (m < p.M) {
+        if (ch == 0 && (n0 >> 6) + wn < p.part_ld) {  // strips past the last column do not exist
+          float* pp = p.part + ((int64_t)m * p.part_ld + ((n0 >> 6) + wn)) * 2;
+          pp[0] = mx;
+          pp[1] = sm;
+        }
+        const int64_t lab = p.labels[m];
+        if (lab >= n && lab < n + 8 && lab < p.N) p.lab_logit[m] = u[(int)(lab - n)];
+      }
+      continue;
+    }
+    if (m >= p.M || n >= (EPI == EPI_CE_BWD ? p.n_store : p.N)) continue;
     float v[8], a[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] = v0[e] + b8[e];
       v[4 + e] = v1[e] + b8[4 + e];
+    }
+    if constexpr (EPI == EPI_CE_BWD) {
+      const int64_t lab = p.labels[m];
+      const bool scored = lab >= 0 && lab < p.N;
+      const float sc = scored ? p.scale[0] : 0.f, lse = p.lse[m];
+      __bf16* op = (__bf16*)p.out0 + (int64_t)m * p.ldc + n;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = (n + e < p.N && scored) ? (__expf(v[e] - lse) - ((int64_t)(n + e) == lab ? 1.f : 0.f)) * sc : 0.f;
+        o[e] = f2bf(g);
+      }
+      if (n + 7 < p.n_store && p.vec_out_ok) {
+        *reinterpret_cast<bf16x8*>(op) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.n_store) op[e] = o[e];
+      }
+      continue;
     }
     if (kNeedsAux) {
 #pragma unroll
@@ -1387,6 +1451,101 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* part, int part_ld, const float* lab_logit,
+                                                          const int64_t* labels, float* loss_row, float* lse_row, int M, int V) {
+  // one wave per row: combine the per-strip (max, sum) partials
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float mx = -1e30f, sm = 0.f;
+  for (int i = lane; i < part_ld; i += 64) {
+    const float m2 = part[((int64_t)row * part_ld + i) * 2], s2 = part[((int64_t)row * part_ld + i) * 2 + 1];
+    const float mm = fmaxf(mx, m2);
+    sm = sm * __expf(mx - mm) + s2 * __expf(m2 - mm);
+    mx = mm;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(mx, o), s2 = __shfl_xor(sm, o);
+    const float mm = fmaxf(mx, m2);
+    sm = sm * __expf(mx - mm) + s2 * __expf(m2 - mm);
+    mx = mm;
+  }
+  if (lane == 0) {
+    const float lse = mx + logf(sm);
+    lse_row[row] = lse;
+    const int64_t lab = labels[row];
+    loss_row[row] = (lab >= 0 && lab < V) ? (lse - lab_logit[row]) : 0.f;
+  }
+}
+
+int decoder_args(GemmNtArgs& a, const void* h, int64_t ldh, const void* W, int64_t ldw, const float* bias,
+                 const int64_t* labels, int M, int V, int K, const char* who) {
+  if (M <= 0 || V <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: M, V, K must be > 0", who);
+  if ((K & 7) || (ldh & 7) || (ldw & 7) || ldh < K || ldw < K) MVPTR_FAIL(MVPTR_BAD_ALIGN, "%s: K, ldh, ldw must be multiples of 8 and >= K", who);
+  if (!h || !W || !labels) MVPTR_FAIL(MVPTR_BAD_ARG, "%s: NULL argument", who);
+  if (((uintptr_t)h & 15) || ((uintptr_t)W & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "%s: h and W must be 16-byte aligned", who);
+  memset(&a, 0, sizeof(a));
+  a.A = (const __bf16*)h;
+  a.B = (const __bf16*)W;
+  a.lda = ldh;
+  a.ldb = ldw;
+  a.M = M;
+  a.N = V;
+  a.K = K;
+  a.bias = bias;
+  a.drop = make_dropdev(nullptr);
+  a.labels = labels;
+  a.vec_bias_ok = (bias && (((uintptr_t)bias & 15) == 0)) ? 1 : 0;
+  a.delay_lo = 256;
+  a.delay_hi = 512;
+  return MVPTR_OK;
+}
+}  // namespace
+
+// Vocabulary decoder + CrossEntropyLoss without the [M, V] f32 logits in HBM
+// (modeling_bert.py:513-516 + the loss of modeling_vlbert.py:1112-1125,1245-1249).
+// Forward: logits tile by tile in the GEMM epilogue, reduced to per-row (max, sum exp) partials per
+// 64-column strip plus the logit at the label; a small kernel folds the partials into lse / loss.
+extern "C" int mvptr_decoder_ce_fwd(const void* h, int64_t ldh, const void* W, int64_t ldw, const float* bias,
+                                    const int64_t* labels, int M, int V, int K, float* part, float* lab_logit,
+                                    float* loss_row, float* lse_row, void* stream) {
+  GemmNtArgs a;
+  const int rc = decoder_args(a, h, ldh, W, ldw, bias, labels, M, V, K, "decoder_ce_fwd");
+  if (rc != MVPTR_OK) return rc;
+  if (!part || !lab_logit || !loss_row || !lse_row) MVPTR_FAIL(MVPTR_BAD_ARG, "decoder_ce_fwd: NULL output");
+  a.part = part;
+  a.lab_logit = lab_logit;
+  a.part_ld = (V + 63) / 64;
+  a.out0 = part;  // not written by this epilogue
+  a.ldc = 8;
+  const int rc2 = launch<EPI_CE_PART>(a, (hipStream_t)stream);
+  if (rc2 != MVPTR_OK) return rc2;
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, a.part_ld,
+                     lab_logit, labels, loss_row, lse_row, M, V);
+  MVPTR_CHECK_LAUNCH("decoder_ce_fwd");
+  return MVPTR_OK;
+}
+
+// Backward: the logits are recomputed by the same GEMM and leave its epilogue as
+// d = (softmax - onehot) * scale in bf16 [M, ld_d] (columns V..Vpad-1 zero), the operand of the
+// data- and weight-gradient GEMMs.
+extern "C" int mvptr_decoder_ce_bwd(const void* h, int64_t ldh, const void* W, int64_t ldw, const float* bias,
+                                    const int64_t* labels, const float* lse_row, const float* scale, int M, int V,
+                                    int K, void* dlogits, int64_t ld_d, int Vpad, void* stream) {
+  GemmNtArgs a;
+  const int rc = decoder_args(a, h, ldh, W, ldw, bias, labels, M, V, K, "decoder_ce_bwd");
+  if (rc != MVPTR_OK) return rc;
+  if (!lse_row || !scale || !dlogits || Vpad < V || ld_d < Vpad) MVPTR_FAIL(MVPTR_BAD_ARG, "decoder_ce_bwd: bad argument");
+  a.lse = lse_row;
+  a.scale = scale;
+  a.out0 = dlogits;
+  a.ldc = ld_d;
+  a.n_store = Vpad;
+  a.vec_out_ok = ((ld_d % 8 == 0) && (((uintptr_t)dlogits & 15) == 0)) ? 1 : 0;
+  return launch<EPI_CE_BWD>(a, (hipStream_t)stream);
+}
 
 extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,
                              int K, int epilogue, const float* bias, const void* aux,

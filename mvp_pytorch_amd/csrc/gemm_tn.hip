@@ -30,6 +30,7 @@ struct GemmTnArgs {
   int tiles_n, tiles_k;
   int rows_per_split;
   float* colsum;  // optional: += column sums of A (bias gradient)
+  int order_n_major;  // A/B knob (MVPTR_NT_EXP bit 5): n-tile-major tile order whatever the grid shape
   unsigned long long* stamps;  // -DMVPTR_TIMELINE_BUILD only (MVPTR_GEMM_STAMPS)
 };
 
@@ -331,8 +332,17 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   const int idx = gidx - pbase;
   const int split = idx / nt;
   const int t = idx - split * nt;
-  const int tn = t / p.tiles_k;
-  const int tk = t - tn * p.tiles_k;
+  // tile order inside a split: the LONGER tile dimension outside, the shorter inside, so that the
+  // contiguous run of tiles an XCD gets is a compact block of the (tn, tk) grid and re-reads the
+  // fewest operand panels through its L2 (FFN2's 3 x 12 grid: 18 panel reads per split instead of 25)
+  int tn, tk;
+  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
+    tk = t / p.tiles_n;
+    tn = t - tk * p.tiles_n;
+  } else {
+    tn = t / p.tiles_k;
+    tk = t - tn * p.tiles_k;
+  }
   const int n0 = tn * TN_, k0 = tk * TKW;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
@@ -679,6 +689,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
     a.dW = probs[i].dW;
     a.ldw = probs[i].ldw;
     a.colsum = probs[i].colsum;
+    a.order_n_major = (mvptr_knobs().nt_exp & 32) ? 1 : 0;
     a.stamps = nullptr;
     a.tiles_n = (a.N + TN_ - 1) / TN_;
     a.tiles_k = (a.K + pl.ksub * 128 - 1) / (pl.ksub * 128);

@@ -532,33 +532,49 @@ class LayerNormFn(torch.autograd.Function):
 
 class DecoderCEFn(torch.autograd.Function):
     """loss = mean_{labels>=0} CE(h W^T + b, labels); W f32 [V,H] (vocabulary decoder).
-    Returns (loss, logits f32 [M,V] view) — logits are a non-differentiable side output."""
+    Returns (loss, logits f32 [M,V] view) — logits are a non-differentiable side output.
+
+    want_scores=False (the training path when nobody reads prediction_scores): the fused kernels
+    mvptr_decoder_ce_fwd / _bwd — the [M,V] f32 logits never reach HBM; forward keeps per-strip
+    log-sum-exp partials, backward recomputes the logits inside the GEMM whose epilogue writes
+    softmax - onehot in bf16.  The second output is then an empty [0, V] tensor."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, labels, cache):
+    def forward(ctx, h, weight, bias, labels, cache, want_scores=True):
         M, H = h.shape
         V = weight.shape[0]
         Vp = pad8(V)
         if cache.stale([weight]):
             cache.t["w"], cache.t["wt"] = cast_weight(weight)
         h = h.contiguous()
+        labels = labels.contiguous()
+        nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32)
+        ctx.needs = (h.requires_grad, weight.requires_grad, bias.requires_grad)
+        if not want_scores:
+            b32 = _f32(bias)
+            loss_row, lse = hip.decoder_ce_fwd(h, cache.t["w"], b32, labels, V)
+            loss = loss_row.sum() / nvalid
+            ctx.save = (h, None, labels, lse, nvalid, cache, V, Vp, b32)
+            out_logits = torch.zeros((0, V), device=h.device, dtype=torch.float32)
+            ctx.mark_non_differentiable(out_logits)
+            return loss, out_logits
         logits = torch.empty((M, Vp), device=h.device, dtype=torch.float32)
         hip.gemm_nt(h, cache.t["w"], hip.EPI_F32, bias=_f32(bias), out=logits, n=V)
-        labels = labels.contiguous()
         loss_row, lse = hip.ce_fwd(logits, labels, V=V)
-        nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32)
         loss = loss_row.sum() / nvalid
-        ctx.save = (h, logits, labels, lse, nvalid, cache, V, Vp)
-        ctx.needs = (h.requires_grad, weight.requires_grad, bias.requires_grad)
+        ctx.save = (h, logits, labels, lse, nvalid, cache, V, Vp, None)
         out_logits = logits[:, :V]
         ctx.mark_non_differentiable(out_logits)
         return loss, out_logits
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
-        h, logits, labels, lse, nvalid, cache, V, Vp = ctx.save
+        h, logits, labels, lse, nvalid, cache, V, Vp, b32 = ctx.save
         scale = (gloss.to(torch.float32) / nvalid).reshape(1).contiguous()
-        d = hip.ce_bwd(logits, labels, lse, scale, V, Vp)
+        if logits is None:
+            d = hip.decoder_ce_bwd(h, cache.t["w"], b32, labels, lse, scale, V, Vp)
+        else:
+            d = hip.ce_bwd(logits, labels, lse, scale, V, Vp)
         H = h.shape[1]
         dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H) if ctx.needs[0] else None
         dw = db = None
@@ -570,4 +586,4 @@ class DecoderCEFn(torch.autograd.Function):
         elif db is not None:
             hip.colsum(d, db, n=V)
         ctx.save = None
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None

@@ -25,7 +25,8 @@ SYMBOLS = [
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
-    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features",
+    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
+    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd",
 ]
 
 
@@ -100,6 +101,9 @@ def load():
     lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
     lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P]
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
+    lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
+    lib.mvptr_decoder_ce_fwd.argtypes = [P, I64, P, I64, P, P, I, I, I, P, P, P, P, P]
+    lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
     _lib = lib
@@ -307,6 +311,34 @@ def cast_pack(src, dst=None, dst_t=None, col_off_t=0):
     rows, cols = src.shape
     _check(load().mvptr_cast_pack(_p(src), src.stride(0), rows, cols, _p(dst), dst.stride(0) if dst is not None else 0,
                                   _p(dst_t), dst_t.stride(0) if dst_t is not None else 0, col_off_t, _stream()))
+
+
+def decoder_ce_fwd(h, w, bias, labels, V):
+    """Fused decoder GEMM + cross entropy (no logits tensor): returns (loss_row f32 [M], lse_row f32 [M])."""
+    assert h.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and labels.dtype == torch.int64
+    M, K = h.shape
+    part = torch.empty((M, (V + 63) // 64, 2), device=h.device, dtype=torch.float32)
+    lab_logit = torch.zeros(M, device=h.device, dtype=torch.float32)
+    loss_row = torch.empty(M, device=h.device, dtype=torch.float32)
+    lse_row = torch.empty(M, device=h.device, dtype=torch.float32)
+    _check(load().mvptr_decoder_ce_fwd(_p(h), h.stride(0), _p(w), w.stride(0), _p(bias), _p(labels), M, V, K,
+                                       _p(part), _p(lab_logit), _p(loss_row), _p(lse_row), _stream()))
+    return loss_row, lse_row
+
+
+def decoder_ce_bwd(h, w, bias, labels, lse_row, scale, V, Vp):
+    """d = (softmax(h w^T + bias) - onehot(labels)) * scale as bf16 [M, Vp], logits recomputed in the GEMM."""
+    M, K = h.shape
+    d = torch.empty((M, Vp), device=h.device, dtype=torch.bfloat16)
+    _check(load().mvptr_decoder_ce_bwd(_p(h), h.stride(0), _p(w), w.stride(0), _p(bias), _p(labels), _p(lse_row),
+                                       _p(scale), M, V, K, _p(d), d.stride(0), Vp, _stream()))
+    return d
+
+
+def diag_stream_read(buf, mode, sink):
+    """Calibration helper: read every byte of `buf` once (mode 0: LDS-DMA, mode 1: global loads)."""
+    nbytes = buf.numel() * buf.element_size()
+    _check(load().mvptr_diag_stream_read(_p(buf), nbytes, mode, _p(sink), _stream()))
 
 
 def b64_decode_features(text, offsets, n_chars, num_boxes, R, D, out_f32=None, out_bf16=None, err=None):

@@ -204,8 +204,10 @@ class BertLMPredictionHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(n_out))
         self._cache = engine.WeightCache()
 
-    def loss_and_scores(self, hidden_states, labels):
-        """Fused decoder + CrossEntropyLoss(ignore_index=-1): (mean loss, f32 logits [M,V])."""
+    def loss_and_scores(self, hidden_states, labels, want_scores=True):
+        """Fused decoder + CrossEntropyLoss(ignore_index=-1): (mean loss, f32 logits [M,V]).
+        want_scores=False: the loss only — the logits stay inside the GEMM epilogues
+        (mvptr_decoder_ce_fwd / _bwd) and the second result is an empty [0, V] tensor."""
         if hidden_states.reshape(-1, hidden_states.shape[-1]).shape[0] == 0:
             # no scored row in this batch / data-parallel shard (the dataset masks 15 % of the tokens
             # with no guarantee of one per shard, oscar_tsv4.py:782-893): a zero that is still connected
@@ -219,7 +221,7 @@ class BertLMPredictionHead(nn.Module):
             return zero, torch.zeros((0, self.decoder.weight.shape[0]), dtype=torch.float32, device=hidden_states.device)
         h = self.transform(hidden_states)
         return engine.DecoderCEFn.apply(h.reshape(-1, h.shape[-1]), self.decoder.weight, self.bias,
-                                        labels.reshape(-1), self._cache)
+                                        labels.reshape(-1), self._cache, want_scores)
 
     def forward(self, hidden_states):
         h = self.transform(hidden_states)

@@ -595,6 +595,9 @@ class BertImgForPreTraining(ImgPreTrainedModel):
         self.cls = BertPreTrainingHeads(config)
         self.num_seq_relations = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
         self.max_text_seq_length = config.max_text_seq_length if hasattr(config, "max_text_seq_length") else None
+        # True (default): the reference's output tuple, prediction_scores [B, T, V] included.  False:
+        # loss-only training — masked rows through the fused decoder + cross-entropy kernels
+        self.return_prediction_scores = True
         self.apply(self.init_weights)
         self.tie_weights()
 
@@ -611,8 +614,17 @@ class BertImgForPreTraining(ImgPreTrainedModel):
         if masked_lm_labels is None or next_sentence_label is None:
             return (self.cls.predictions(text), seq_relationship_score)
         labels = masked_lm_labels[:, :T].contiguous() if T is not None else masked_lm_labels
-        masked_lm_loss, scores = self.cls.predictions.loss_and_scores(text.reshape(-1, text.shape[-1]), labels.reshape(-1))
-        prediction_scores = scores.reshape(text.shape[0], text.shape[1], -1)
+        if not self.return_prediction_scores:
+            # training loops that read outputs[0] only (run_oscarplus_pretrain-style): the head runs on
+            # the scored rows alone and the logits never reach HBM; prediction_scores comes back empty
+            flat = labels.reshape(-1)
+            idx = torch.nonzero(flat >= 0).squeeze(1)
+            rows = text.reshape(-1, text.shape[-1]).index_select(0, idx)
+            masked_lm_loss, scores = self.cls.predictions.loss_and_scores(rows, flat.index_select(0, idx), want_scores=False)
+            prediction_scores = scores
+        else:
+            masked_lm_loss, scores = self.cls.predictions.loss_and_scores(text.reshape(-1, text.shape[-1]), labels.reshape(-1))
+            prediction_scores = scores.reshape(text.shape[0], text.shape[1], -1)
         loss_fct = CrossEntropyLoss(ignore_index=-1)
         next_sentence_loss = loss_fct(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
         total_loss = masked_lm_loss + next_sentence_loss
@@ -660,7 +672,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         ce_loss = CrossEntropyLoss(ignore_index=-1)
 
         vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b)
-        vis_mlm_loss, _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels)
+        vis_mlm_loss, _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels, want_scores=False)
 
         logits = sim_mat * self.logit_scale.exp()
         pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
@@ -668,7 +680,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
 
         sequence_output, pooled_output, hard_sequence_output, hard_pooled_output = outputs
         rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a)
-        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels)
+        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels, want_scores=False)
         seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
         n = pooled_output.shape[0]
         next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long), torch.ones(n, dtype=torch.long)]).to(seq_relationship_score.device)

@@ -212,6 +212,32 @@ def test_single_pretrain_parity(dev, name):
             assert err < 5e-2, (pname, err)
 
 
+@pytest.mark.parametrize("name", ["tiny_single_pretrain", "cfg1_single_pretrain"])
+def test_single_pretrain_loss_only_path(dev, name):
+    """return_prediction_scores = False: scored rows only, fused decoder + cross entropy (no logits
+    tensor); same losses and gradient norms as the reference fixture."""
+    d = gu.load(name)
+    cfg = d["config"]
+    model, sd = _build("BertImgForPreTraining", cfg, int(d["seed"]), dev)
+    with torch.no_grad():
+        model.bert.embeddings.word_embeddings.weight.copy_(sd["cls.predictions.decoder.weight"])
+        model.tie_weights()
+    model.return_prediction_scores = False
+    t = lambda k: torch.from_numpy(d["in:" + k]).to(dev)  # noqa: E731
+    out = model(t("input_ids"), t("segment_ids"), t("input_mask"), t("lm_label_ids"), t("is_next"), img_feats=t("img_feats"))
+    got = np.array([out[0].item(), out[3].item()])
+    rel = np.abs(got - d["losses"]) / np.abs(d["losses"])
+    print(name, "losses (loss-only path)", got, d["losses"], rel)
+    assert rel.max() < LOSS_RTOL
+    assert out[1].shape[0] == 0
+    out[0].backward()
+    for pname, p in model.named_parameters():
+        key = "gnorm:" + pname
+        if key in d and float(d[key]) > 1e-6 and p.grad is not None:
+            err = abs(p.grad.double().norm().item() - float(d[key])) / float(d[key])
+            assert err < 5e-2, (pname, err)
+
+
 def test_finetune_parity(dev):
     d = gu.load("tiny_finetune")
     cfg, dims, seed = d["config"], d["dims"], int(d["seed"])

@@ -492,6 +492,41 @@ def test_cross_entropy(dev):
     assert _rel(d[:, :V], lr.grad) < 4e-3
 
 
+@pytest.mark.parametrize("M,V,K", [(50, 30522, 768), (3000, 30522, 768), (300, 1000, 136), (7, 37, 64), (513, 3129, 768)])
+def test_fused_decoder_cross_entropy(dev, M, V, K):
+    """mvptr_decoder_ce_fwd / _bwd (no logits tensor) against the materialising path and torch f32."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(21)
+    Vp = (V + 7) // 8 * 8
+    h = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(V, K, generator=g) * 0.08).to(dev)
+    bias = torch.randn(V, generator=g).to(dev)
+    labels = torch.randint(0, V, (M,), generator=g)
+    labels[::5] = -1
+    labels = labels.to(dev)
+    loss, lse = hip.decoder_ce_fwd(h, w, bias, labels, V)
+    logits = (h.float() @ w.float().t() + bias).requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(logits, labels, ignore_index=-1, reduction="none")
+    assert (loss - ref.detach()).abs().max().item() < 2e-3
+    assert (lse - torch.logsumexp(logits.detach(), 1)).abs().max().item() < 2e-3
+    assert torch.all(loss[labels < 0] == 0)
+    nvalid = (labels >= 0).sum()
+    ref.sum().div(nvalid).backward()
+    scale = (1.0 / nvalid.float()).reshape(1)
+    d = hip.decoder_ce_bwd(h, w, bias, labels, lse, scale, V, Vp)
+    assert d.shape == (M, Vp)
+    assert torch.all(d[:, V:] == 0)
+    assert torch.all(d[labels < 0] == 0)
+    assert _rel(d[:, :V], logits.grad) < 6e-3
+    # the materialising kernels on f32 logits of the same GEMM give the same numbers up to bf16 rounding
+    lg = torch.zeros(M, Vp, device=dev)
+    hip.gemm_nt(h, w, hip.EPI_F32, bias=bias, out=lg, n=V)
+    loss2, lse2 = hip.ce_fwd(lg, labels, V=V)
+    assert (loss - loss2).abs().max().item() < 1e-4 and (lse - lse2).abs().max().item() < 1e-4
+    d2 = hip.ce_bwd(lg, labels, lse2, scale, V, Vp)
+    assert _rel(d, d2) < 1e-3
+
+
 def test_fused_adamw_matches_oracle(dev):
     """mvptr_adamw_multi (through mvp_pytorch_amd.optimization.AdamW) against the oracle's
     restatement of optimization.py:131-187, three steps, two weight-decay groups, ragged sizes."""

@@ -13,6 +13,7 @@ dev = torch.device("cuda:0")
 CFGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto", "32", "q"]
 SPLITS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 MS = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [64000, 37748, 19200, 10917]
+ORDERS = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
 
 
 def timeit(fn, reps=10):
@@ -42,8 +43,11 @@ for M in MS:
             hip.set_knob("MVPTR_GEMM_TN", "" if cfg == "auto" else cfg)
             for sp in SPLITS:
                 hip.set_knob("MVPTR_TN_SPLITS", str(sp))
-                us = timeit(lambda: hip.gemm_tn_multi(probs))
-                line += "  %s/%d %6.1fus %5.0fTF" % (cfg, sp, us, flops / us / 1e6)
+                for order in ORDERS:
+                    hip.set_knob("MVPTR_NT_EXP", str(order))
+                    us = min(timeit(lambda: hip.gemm_tn_multi(probs)) for _ in range(3))
+                    line += "  %s/%d/o%d %6.1fus %5.0fTF" % (cfg, sp, order, us, flops / us / 1e6)
+                hip.set_knob("MVPTR_NT_EXP", "0")
         print(line, flush=True)
 hip.set_knob("MVPTR_GEMM_TN", "")
 hip.set_knob("MVPTR_TN_SPLITS", "0")
