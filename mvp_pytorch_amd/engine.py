@@ -16,18 +16,34 @@ Functions
 """
 import ctypes
 
+import threading
+
 import torch
 
 from . import hip
 
+# nn.DataParallel (oscar/run_retrieval.py:577-578,1125 — that script's only multi-GPU mode) runs one
+# THREAD per device over replicas whose non-tensor attributes are shared by reference
+# (torch.nn.parallel.replicate copies module.__dict__ shallowly): every piece of module-level state
+# below is therefore either guarded by this lock or kept per device (WeightCache.for_device,
+# PackList.for_device, side_stream).
+_state_lock = threading.Lock()
 _seed_counter = [0x5DEECE66D]
 
 
 def next_seed():
     """Fresh 64-bit dropout seed; derived from torch's RNG so torch.manual_seed controls it."""
-    _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
-    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-    return (_seed_counter[0] ^ (base << 20)) & 0xFFFFFFFFFFFFFFFF
+    with _state_lock:
+        _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return (_seed_counter[0] ^ (base << 20)) & 0xFFFFFFFFFFFFFFFF
+
+
+def _dev_key(device):
+    d = torch.device(device)
+    if d.type != "cuda":
+        return -1
+    return d.index if d.index is not None else torch.cuda.current_device()
 
 
 def _f32(p):
@@ -55,6 +71,26 @@ class WeightCache:
     def __init__(self):
         self._key = None
         self.t = {}
+        self._dev = None        # device this object serves (set at first use)
+        self._children = {}     # other devices' caches (replicas of the owning module under DataParallel)
+
+    def for_device(self, device):
+        """The cache to use for parameters living on `device`: this object for the first device seen,
+        a per-device child otherwise (replicas made by torch.nn.parallel.replicate share this object
+        by reference while their parameters live on different GPUs and are used from different threads)."""
+        k = _dev_key(device)
+        if self._dev is None:
+            with _state_lock:
+                if self._dev is None:
+                    self._dev = k
+        if k == self._dev:
+            return self
+        with _state_lock:
+            c = self._children.get(k)
+            if c is None:
+                c = self._children[k] = WeightCache()
+                c._dev = k
+        return c
 
     def stale(self, params, force=None):
         if force is None:
@@ -67,6 +103,8 @@ class WeightCache:
 
     def invalidate(self):
         self._key = None
+        for c in self._children.values():
+            c.invalidate()
 
 
 def invalidate_weight_caches(model):
@@ -80,9 +118,10 @@ def invalidate_weight_caches(model):
                 v.invalidate()
                 n += 1
             elif isinstance(v, PackList):
-                v.group.cache.invalidate()
-                for pk in v:
-                    pk.cache.invalidate()
+                for pl in [v] + list(v._children.values()):
+                    pl.group.cache.invalidate()
+                    for pk in pl:
+                        pk.cache.invalidate()
                 n += 1
     return n
 
@@ -152,6 +191,25 @@ class PackList(list):
     def __init__(self, it):
         super().__init__(it)
         self.group = EncoderPacks(self)
+        self._dev = None
+        self._children = {}
+
+    def for_device(self, device):
+        """Per-device working copies (see WeightCache.for_device): this list for the first device that
+        uses it, a lazily built twin for every other device."""
+        k = _dev_key(device)
+        if self._dev is None:
+            with _state_lock:
+                if self._dev is None:
+                    self._dev = k
+        if k == self._dev:
+            return self
+        with _state_lock:
+            c = self._children.get(k)
+            if c is None:
+                c = self._children[k] = PackList(LayerPack() for _ in range(len(self)))
+                c._dev = k
+        return c
 
 
 class EncoderPacks:
@@ -239,9 +297,10 @@ SIDE_STREAMS = {}
 def side_stream(device):
     """One extra HIP stream per device, created on first use."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in SIDE_STREAMS:
-        SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
-    return SIDE_STREAMS[key]
+    with _state_lock:
+        if key not in SIDE_STREAMS:
+            SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        return SIDE_STREAMS[key]
 
 
 class PackRows(torch.autograd.Function):
@@ -394,6 +453,7 @@ class InputEmbedFn(torch.autograd.Function):
             fb = torch.empty((B * R, Dp), device=dev, dtype=torch.bfloat16)
             hip.cast_pack(feats.contiguous(), dst=fb)
             cache = meta["cache"]
+            cache = cache.for_device(img_w.device)
             if cache.stale([img_w]):
                 cache.t["img_w"] = cast_weight(img_w, want_t=False)[0]
             zi = hip.gemm_nt(fb, cache.t["img_w"], hip.EPI_BIAS, bias=_f32(img_b))
@@ -464,6 +524,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.stride(1) != 1 or (x2.stride(0) % 8) or (x2.data_ptr() % 16):
             x2 = x2.contiguous()
+        cache = cache.for_device(weight.device)
         if cache.stale([weight]):
             cache.t["w"], cache.t["wt"] = cast_weight(weight)
         b = _f32(bias) if bias is not None else None
@@ -544,6 +605,7 @@ class DecoderCEFn(torch.autograd.Function):
         M, H = h.shape
         V = weight.shape[0]
         Vp = pad8(V)
+        cache = cache.for_device(weight.device)
         if cache.stale([weight]):
             cache.t["w"], cache.t["wt"] = cast_weight(weight)
         h = h.contiguous()

@@ -133,11 +133,11 @@ class CaptionBertEncoder(nn.Module):
             if rows < B * L and lmax > 0:
                 idx = torch.nonzero_static(valid, size=rows).view(-1)
                 starts = (torch.cumsum(lens, 0, dtype=torch.int32) - lens).contiguous()
-                meta = engine.EncoderMeta(self._packs, B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
+                meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
                                           l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
                 y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
                 return (engine.UnpackRows.apply(y, idx, B * L).view(B, L, H),)
-        meta = engine.EncoderMeta(self._packs, B, L, Hc, heads, I, eps, self.training,
+        meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)

@@ -292,3 +292,32 @@ def test_flops_formula_matches_survey():
     fwd, fb = bench.flops_per_pair(dict(B=256, T=70, P=5, G=20, R=50), bench.BASE_CFG, 11, 3)
     assert abs(fwd / 1e9 - 35.16) < 0.15  # 35.16 GFLOP forward per pair
     assert fb == 3 * fwd
+
+
+def test_weight_caches_are_per_device():
+    """WeightCache / PackList hand out one object per device (nn.DataParallel replicas share the
+    owning module's attributes by reference): first device -> the object itself, others -> children."""
+    import torch
+    from mvp_pytorch_amd import engine
+    c = engine.WeightCache()
+    keys = iter([0, 0, 1, 1, 2, 0])
+    orig = engine._dev_key
+    engine._dev_key = lambda device: next(keys)
+    try:
+        a0, a0b, a1, a1b, a2, a0c = (c.for_device(None) for _ in range(6))
+    finally:
+        engine._dev_key = orig
+    assert a0 is c and a0b is c and a0c is c
+    assert a1 is a1b and a1 is not c and a2 is not a1 and a2 is not c
+    c._key, a1._key = "x", "y"
+    c.invalidate()
+    assert c._key is None and a1._key is None
+    pl = engine.PackList(engine.LayerPack() for _ in range(3))
+    keys = iter([3, 5, 5, 3])
+    engine._dev_key = lambda device: next(keys)
+    try:
+        p3, p5, p5b, p3b = (pl.for_device(None) for _ in range(4))
+    finally:
+        engine._dev_key = orig
+    assert p3 is pl and p3b is pl and p5 is p5b and p5 is not pl and len(p5) == 3 and p5.group is not pl.group
+    assert engine._dev_key(torch.device("cpu")) == -1

@@ -278,6 +278,41 @@ def test_finetune_parity(dev):
     assert _rel(o[1], torch.from_numpy(d["ve_logits"])) < 2e-2
 
 
+def test_data_parallel_replicas_match_single_module(dev):
+    """oscar/run_retrieval.py:577-578,1125 wraps BiImageBertForRetrieval in nn.DataParallel (its only
+    multi-GPU mode): replicas made by torch.nn.parallel.replicate share the module's non-tensor
+    attributes by reference and run from one thread per device.  A replica (and nn.DataParallel on the
+    visible devices) must give the single module's outputs bit for bit, from worker threads too."""
+    import threading
+    d = gu.load("tiny_finetune")
+    cfg, dims, seed = d["config"], d["dims"], int(d["seed"])
+    kw = _bi_inputs(d, dev)
+    model, _ = _build("BiImageBertForRetrieval", dict(cfg, loss_type="ce", num_labels=2), seed + 1, dev)
+    for mode in ("coarse", "fine"):
+        model.forward_mod = mode
+        with torch.no_grad():
+            ref = model(max_tag_length=dims["G"], **kw)
+            reps = torch.nn.parallel.replicate(model, [dev.index or 0, dev.index or 0])
+            outs = [None, None]
+
+            def run(i):
+                with torch.cuda.device(dev):
+                    outs[i] = reps[i](max_tag_length=dims["G"], **kw)
+
+            for i in range(2):   # worker threads, as DataParallel's parallel_apply uses (one device here:
+                t_ = threading.Thread(target=run, args=(i,))   # the replicas take turns)
+                t_.start()
+                t_.join()
+            torch.cuda.synchronize()
+            dp = torch.nn.DataParallel(model, device_ids=list(range(torch.cuda.device_count())))
+            dpo = dp(max_tag_length=dims["G"], **kw)
+        refs = ref if isinstance(ref, tuple) else (ref,)
+        for o in outs + [dpo]:
+            o = o if isinstance(o, tuple) else (o,)
+            for a, b in zip(o, refs):
+                assert torch.equal(a, b), mode
+
+
 def test_unpadded_equals_padded_execution(dev):
     """Row-packed encoder execution (default) against the padded execution the reference performs:
     same losses, same hard-negative indices, same gradients; encoder outputs equal on the valid rows
