@@ -409,7 +409,10 @@ def main():
         # ("prediction_scores"); the reference's loop reads outputs[0] only
         model.return_prediction_scores = False
     opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
-    sync = dp.GradSync(model) if world > 1 else None
+    # bi model: the MLM decoders are clones of the first 30 522 embedding rows (not tied), so the word
+    # table's gradient holds the looked-up rows only and is exchanged by rows (dp.GradSync.note_rows)
+    sparse = [] if single else [model.bert.embeddings.word_embeddings.weight]
+    sync = dp.GradSync(model, sparse_rows=sparse) if world > 1 else None
 
     def make_batch(fixed):
         return synthetic_batch(dims, cfg, 1234 + rank, single_stream=single, fixed_length=fixed, device=dev)

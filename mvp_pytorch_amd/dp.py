@@ -30,6 +30,15 @@ Design
     and the averaged result converted back into the f32 bucket — half the xGMI bytes (0.49 instead of
     0.98 GB per step for BiBertImgForPreTraining).  The reference exchanged fp16 gradients under
     DeepSpeed; bf16 keeps f32's exponent range, so no loss scaling is involved;
+  * ROW-SPARSE parameters (`sparse_rows=[...]`, the 86 051 x 768 word-embedding table whose f32
+    gradient is 264 MB and is produced LAST, so it cannot overlap the backward pass): each gets a
+    bucket of its own; when the step has told the exchange which rows were looked up
+    (note_rows(param, ids): token, phrase and tag ids of the rank's shard), the ranks all-gather their
+    unique row ids, every rank forms the same sorted union, and only those rows are all-reduced (a
+    compact [U, H] buffer in the wire dtype) and scattered back; rows outside the union are zero on
+    every rank already.  A rank without noted ids (or a caller that never calls note_rows) makes all
+    ranks fall back to the dense all-reduce of that bucket for the step, so the result never depends
+    on the optimisation;
   * one backward per zero_grad(), or gradient accumulation inside `with sync.no_sync():` for all but
     the last backward — a second backward outside no_sync() would add into buckets that are already
     being reduced and raises.
@@ -45,8 +54,10 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="auto"):
+    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="auto", sparse_rows=()):
         self.group = process_group
+        self.sparse = {p for p in sparse_rows if p.requires_grad and p.dim() == 2}
+        self._rows = {}           # row-sparse parameter -> list of id tensors noted for this step
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -77,6 +88,13 @@ class GradSync:
         for group, is_hot in ((hot, True), (cold, False)):
             cur, cur_n = [], 0
             for p in group:
+                if p in self.sparse:      # a bucket of its own, exchanged by rows
+                    if cur:
+                        self._close(cur, cur_n, is_hot)
+                        cur, cur_n = [], 0
+                    self._close([(p, 0, p.numel())], p.numel(), is_hot)
+                    self.buckets[-1]["rows_of"] = p
+                    continue
                 if cur and cur_n + p.numel() > self.cap:
                     self._close(cur, cur_n, is_hot)
                     cur, cur_n = [], 0
@@ -90,7 +108,8 @@ class GradSync:
         p0 = items[0][0]
         idx = len(self.buckets)
         flat = torch.zeros(n, device=p0.device, dtype=torch.float32)
-        self.buckets.append(dict(flat=flat, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set()))
+        self.buckets.append(dict(flat=flat, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set(),
+                                 rows_of=None, union=None))
         for p, off, k in items:
             self.where[p] = idx
             self.span[p] = (off, k, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
@@ -107,7 +126,7 @@ class GradSync:
             self._build()
         for b in self.buckets:
             b["flat"].zero_()
-            b["work"] = b["wire"] = None
+            b["work"] = b["wire"] = b["union"] = None
             b["streams"] = set()
             for p, off, n in b["items"]:
                 view = b["flat"][off:off + n].view_as(p)
@@ -115,7 +134,46 @@ class GradSync:
                     p.grad = view
             b["pending"] = len(b["items"])
         self._ready = set()
+        self._rows = {}
         self._next = 0            # buckets [0, _next) have been launched this step
+
+    def note_rows(self, param, ids):
+        """Tell the exchange which rows of a row-sparse parameter this rank's step looks up (every id
+        tensor that indexes the table: call once per tensor or pass a list), BEFORE the backward pass
+        (a hot bucket is launched from the hook of its last gradient).  Without it the bucket is
+        reduced densely."""
+        if self.world == 1 or param not in self.sparse:
+            return
+        ids = ids if isinstance(ids, (list, tuple)) else [ids]
+        self._rows.setdefault(param, []).extend(t.reshape(-1) for t in ids if t is not None)
+
+    def _row_union(self, b):
+        """All ranks' unique row ids of this step -> the sorted union (identical on every rank), or
+        None when some rank has no ids noted (dense fallback, decided from the gathered data alone)."""
+        p = b["rows_of"]
+        dev = b["flat"].device
+        noted = self._rows.get(p)
+        mine = torch.unique(torch.cat(noted).to(dev)) if noted else None
+        cnt = torch.tensor([-1 if mine is None else mine.numel()], dtype=torch.int64, device=dev)
+        cnts = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        cnts = [int(c.item()) for c in cnts]
+        if min(cnts) < 0:
+            return None
+        cap = max(1, max(cnts))
+        pad = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        if mine is not None and mine.numel():
+            pad[:mine.numel()] = mine
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        allids = torch.cat([q[:c] for q, c in zip(parts, cnts)])
+        union = torch.unique(allids)
+        rows = p.shape[0]
+        if union.numel() and (int(union.min()) < 0 or int(union.max()) >= rows):
+            raise RuntimeError("GradSync.note_rows: row id outside the table")
+        if union.numel() == 0 or union.numel() * 2 > rows:
+            return None               # nothing to gain: dense exchange (same decision on every rank)
+        return union
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -165,7 +223,13 @@ class GradSync:
             for st in b["streams"]:
                 if st != cur:
                     cur.wait_stream(st)   # everything queued there so far includes the gradients
-        wire = b["flat"] if self.comm_dtype == torch.float32 else b["flat"].to(self.comm_dtype)
+        src = b["flat"]
+        if b["rows_of"] is not None:
+            union = self._row_union(b)     # two small all-gathers; every rank takes the same branch
+            if union is not None:
+                b["union"] = union
+                src = b["flat"].view_as(b["rows_of"]).index_select(0, union)
+        wire = src if (self.comm_dtype == torch.float32 and src is b["flat"]) else src.to(self.comm_dtype)
         b["wire"] = wire
         b["work"] = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
         self._next = idx + 1
@@ -185,6 +249,16 @@ class GradSync:
         used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             b["work"].wait()
+            if b["union"] is not None:
+                # compact rows back into the table gradient (rows outside the union are zero everywhere)
+                if b["wire"].is_cuda:
+                    b["wire"].record_stream(torch.cuda.current_stream(b["wire"].device))
+                red = b["wire"].to(torch.float32)
+                if not self._avg:
+                    red = red * (1.0 / self.world)
+                b["flat"].view_as(b["rows_of"]).index_copy_(0, b["union"], red)
+                b["wire"] = b["union"] = None
+                continue
             if b["wire"] is not b["flat"]:
                 if b["wire"].is_cuda:
                     b["wire"].record_stream(torch.cuda.current_stream(b["wire"].device))

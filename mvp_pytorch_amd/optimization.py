@@ -122,15 +122,39 @@ class AdamW(Optimizer):
                     co.append(off)
             ent = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev), len(ct))
             cache[key] = ent
-        tab = np.zeros(len(ps), dtype=self._TABLE_DT)
-        tab["p"] = [p.data_ptr() for p in ps]
-        tab["g"] = [g.data_ptr() for g in gs]
-        tab["m"] = [m.data_ptr() for m in ms]
-        tab["v"] = [v.data_ptr() for v in vs]
-        tab["n"] = [p.numel() for p in ps]
+        # descriptor table: two PINNED host copies (used in turn, each guarded by the event of the upload
+        # that last read it) and a device copy, kept per parameter group.  The
+        # pointer columns are rewritten only when a pointer changed (gradient tensors are reallocated
+        # by zero_grad(set_to_none) unless a GradSync pins them into its buckets); step_size / decay
+        # change every step.  The upload is an asynchronous copy from pinned memory on the launch
+        # stream (a pageable source would make it a blocking copy).
+        if len(ent) == 3:
+            nbytes = len(ps) * self._TABLE_DT.itemsize
+            hosts = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            ent = ent + (dict(hosts=hosts, events=[None, None], ptrs=[None, None], turn=0,
+                              dev=torch.empty(nbytes, dtype=torch.uint8, device=dev)),)
+            cache[key] = ent
+        st = ent[3]
+        i = st["turn"]
+        st["turn"] = i ^ 1
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()   # the upload that last read this host buffer (two steps ago) is done
+        host, tab_dev = st["hosts"][i], st["dev"]
+        tab = host.numpy().view(self._TABLE_DT)
+        ptrs = (tuple(g.data_ptr() for g in gs), tuple(m.data_ptr() for m in ms), tuple(v.data_ptr() for v in vs))
+        if st["ptrs"][i] != ptrs:
+            tab["p"] = [p.data_ptr() for p in ps]
+            tab["g"] = ptrs[0]
+            tab["m"] = ptrs[1]
+            tab["v"] = ptrs[2]
+            tab["n"] = [p.numel() for p in ps]
+            st["ptrs"][i] = ptrs
         tab["step_size"] = step_size
         tab["decay"] = decay
-        tab_dev = torch.from_numpy(tab.view(np.uint8)).to(dev, non_blocking=True)
+        tab_dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
         hip.adamw_multi(tab_dev, ent[0], ent[1], ent[2], b1, b2, eps)
         # the kernel updated the parameters outside autograd's view; the bf16 weight caches key on
         # Tensor._version, so mark the tensors as modified

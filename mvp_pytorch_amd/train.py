@@ -36,6 +36,12 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
                   grad_sync=None, return_losses=False):
     """One optimisation step.  grad_sync: optional callable run between backward and the
     optimizer (the data-parallel all-reduce, mvp_pytorch_amd.dp.GradSync)."""
+    if grad_sync is not None and getattr(grad_sync, "sparse", None):
+        # the word table's gradient is row-sparse: tell the exchange which rows this shard looks up
+        # (before backward: a hot bucket goes out from the hook of its last gradient)
+        emb = getattr(getattr(getattr(model, "bert", None), "embeddings", None), "word_embeddings", None)
+        if emb is not None and emb.weight in grad_sync.sparse:
+            grad_sync.note_rows(emb.weight, [batch.get("input_ids_a"), batch.get("input_ids_b"), batch.get("input_ids")])
     outputs = model(**model_inputs(batch, max_tag_length))
     loss = loss_weight * outputs[0]
     loss.backward()

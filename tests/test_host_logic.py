@@ -287,6 +287,86 @@ def test_grad_sync_two_ranks_gloo(comm_dtype):
     assert v0 == v1 == [3.0, 4.0, 6.0]
 
 
+def _dp_sparse_worker(rank, world, port, q, comm_dtype):
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(400, 8)      # the "word table": only the looked-up rows get a gradient
+    head = torch.nn.Linear(8, 3)
+    m = torch.nn.ModuleDict(dict(emb=emb, head=head))
+    sync = dp.GradSync(m, bucket_mb=0.0001, comm_dtype=comm_dtype, sparse_rows=[emb.weight])
+    assert sum(1 for b in sync.buckets if b["rows_of"] is not None) == 1
+    out = []
+    for step in range(4):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        ids_a = torch.randint(0, 400, (6, 5), generator=g)
+        ids_b = torch.randint(0, 60, (6, 3), generator=g)
+        # the ids are known before the step: note them BEFORE backward (a hot bucket is launched from
+        # the gradient hook as soon as the table's gradient has landed)
+        if step == 1 and rank == 1:
+            pass                          # a rank that notes nothing: every rank falls back to the dense exchange
+        elif step == 2:
+            sync.note_rows(emb.weight, [torch.arange(400)])   # union > half the table: dense is chosen
+        else:
+            sync.note_rows(emb.weight, ids_a)
+            sync.note_rows(emb.weight, [ids_b, None])
+        used_union = None
+        local = None
+        orig = sync._row_union
+
+        def spy(b):
+            nonlocal used_union, local
+            local = emb.weight.grad.detach().clone()   # this rank's own gradient, just before the exchange
+            used_union = orig(b)
+            return used_union
+
+        sync._row_union = spy
+        loss = head(emb(ids_a)).pow(2).sum() + head(emb(ids_b)).sum()
+        loss.backward()
+        sync()
+        sync._row_union = orig
+        out.append((local.numpy(), emb.weight.grad.detach().clone().numpy(), head.weight.grad.detach().clone().numpy(),
+                    None if used_union is None else used_union.numpy()))
+        sync.zero_grad()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
+def test_grad_sync_row_sparse_gloo(comm_dtype):
+    """Row-sparse exchange of an embedding-table gradient (world_size 2, gloo): only the union of the
+    looked-up rows travels, the result equals the dense average; a rank without noted ids and a union
+    larger than half the table both fall back to the dense all-reduce on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (7 if comm_dtype == torch.bfloat16 else 0)
+    tol = 1e-6 if comm_dtype == torch.float32 else 2e-2
+    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q, comm_dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0), (_, r1) = res
+    for step in range(4):
+        (l0, g0, h0, u0), (l1, g1, h1, u1) = r0[step], r1[step]
+        want = (l0 + l1) / 2
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.allclose(g0, want, atol=tol * scale), step
+        assert np.array_equal(g0, g1) and np.array_equal(h0, h1), step
+        if step in (1, 2):
+            assert u0 is None and u1 is None, step          # dense fallback on both ranks
+        else:
+            assert u0 is not None and np.array_equal(u0, u1), step
+            touched = np.nonzero(np.abs(l0).sum(1) + np.abs(l1).sum(1))[0]
+            assert set(touched) <= set(u0.tolist()) and len(u0) < 200
+
+
 def test_flops_formula_matches_survey():
     import bench
     fwd, fb = bench.flops_per_pair(dict(B=256, T=70, P=5, G=20, R=50), bench.BASE_CFG, 11, 3)
