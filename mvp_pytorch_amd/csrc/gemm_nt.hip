@@ -355,6 +355,10 @@ void gemm_nt_kernel(GemmNtArgs p) {
     long long d = 0;
     if (p.delay_hi >= 0) {
       if ((int)blockIdx.x >= p.delay_lo && (int)blockIdx.x < p.delay_hi) d = p.delay_cycles;
+    } else if (p.delay_hi == -1000) {
+      // phases spread BETWEEN the 8 XCD groups (blockIdx % 8), equal inside a group: the workgroups that
+      // share an L2 keep sweeping K together while the groups' output bursts come at different times
+      if ((int)blockIdx.x < p.delay_lo) d = (long long)p.delay_cycles * ((int)blockIdx.x & 7) / 8;
     } else if ((int)blockIdx.x < p.delay_lo) {
       const int P = -p.delay_hi;
       d = (long long)p.delay_cycles * (((int)blockIdx.x >> 3) % P) / P;
@@ -1222,8 +1226,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
       read_quarter(cur, 1, j, wf1, xf1);
       mma_row(j, wf0, xf0, first_tag);
       if constexpr (G >= 0) {
-        if (j == 1) drip_group_unit(G, 0);
-        if (j == 3) drip_group_unit(G, 1);
+        if (j == 0) drip_group_unit(G, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1232,8 +1235,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
       read_quarter(cur, 2, j, wf0, xf0);
       mma_row(j, wf1, xf1, std::false_type{});
       if constexpr (G >= 0) {
-        if (j == 1) drip_group_unit(G, 2);
-        if (j == 3) drip_group_unit(G, 3);
+        if (j == 0) drip_group_unit(G, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1241,17 +1243,25 @@ __global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
     for (int j = 0; j < 4; ++j) {
       read_quarter(cur, 3, j, wf1, xf1);
       mma_row(j, wf0, xf0, std::false_type{});
+      if constexpr (G >= 0) {
+        if (j == 0) drip_group_unit(G, 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are done
     // the next stage's loads are older than this stage's deferred stores, which may stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G >= 0 ? 4 * ntqp_stores_per_unit<EPI>() : 0) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G >= 0 ? 3 * ntqp_stores_per_unit<EPI>() : 0) : "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) stage_piece(bufsel, 4 * j + i);
       read_quarter(nxt, 0, j, wf0, xf0);
       mma_row(j, wf1, xf1, std::false_type{});
+      if constexpr (G >= 0) {
+        // the group's last unit goes out behind the stage's LDS-DMA issue: its stores are OLDER than
+        // nothing the next barrier waits for except themselves (counted there as in-flight-allowed)
+        if (j == 3) drip_group_unit(G, 3);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (FIRST) {
@@ -1276,19 +1286,33 @@ __global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
     for (int kk = 8; kk < nk; ++kk)
       stage_body(std::integral_constant<int, -1>{}, std::false_type{}, std::false_type{});
     // tile end: accumulators + bias -> bf16 pending registers
+    // (speed ablations, wrong results: MVPTR_QP_EXP 1 no bias reads, 2 no accumulator reads, 3 no conversion)
+#if !defined(MVPTR_QP_EXP) || MVPTR_QP_EXP != 3
     {
       const char* brow = lds + BIAS_OFF + (round & 1) * 1024 + (wn * 128 + 4 * h) * 4;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         f32x4 b[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(brow + (nb * 32 + 8 * g) * 4);
+        for (int g = 0; g < 4; ++g) {
+#if defined(MVPTR_QP_EXP) && MVPTR_QP_EXP == 1
+          b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          (void)brow;
+#else
+          b[g] = *reinterpret_cast<const f32x4*>(brow + (nb * 32 + 8 * g) * 4);
+#endif
+        }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int r = 2 * e;
-            const bf16x2 t2 = {f2bf(acc[nb][mb][r] + b[r >> 2][r & 3]), f2bf(acc[nb][mb][r + 1] + b[r >> 2][(r & 3) + 1])};
+#if defined(MVPTR_QP_EXP) && MVPTR_QP_EXP == 2
+            float a0 = __builtin_bit_cast(float, pend[nb][mb][e]), a1 = a0 * 0.5f;
+#else
+            const float a0 = acc[nb][mb][r], a1 = acc[nb][mb][r + 1];
+#endif
+            const bf16x2 t2 = {f2bf(a0 + b[r >> 2][r & 3]), f2bf(a1 + b[r >> 2][(r & 3) + 1])};
             pend[nb][mb][e] = __builtin_bit_cast(uint32_t, t2);
           }
           // one block at a time: hipcc otherwise reads all 256 accumulators first and spills the
@@ -1297,6 +1321,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
         }
       }
     }
+#endif
     pm0 = m0;
     pn0 = n0;
     ++round;

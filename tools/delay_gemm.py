@@ -37,7 +37,7 @@ for M in (64000, 32000):
         out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
         vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
         line = "%-8s M=%d N=%d K=%d:" % (name, M, N, K)
-        settings = ("0", "60000,256,-8", "40000,256,-4", "30000,256,-8", "0")
+        settings = tuple(sys.argv[1].split(";")) if len(sys.argv) > 1 else ("0", "60000,256,-8", "40000,256,-4", "30000,256,-8", "0")
         best = {}
         for rep in range(3):  # interleave the settings so clock / cache state is shared
             for d in settings:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""profiles/r02_roofline.json: the dominant kernel's roofline numbers recomputed from the rocprofv3
+kernel summaries of tools/prof_dominant.py (launch mix of one step) and the PMC traffic file:
+    roofline_json.py OUT.json MIX_PACKED_STATS.csv MIX_FULL_STATS.csv TRAFFIC.json"""
+import csv
+import json
+import sys
+
+H, I = 768, 3072
+PEAK = 2500.0
+out, packed_csv, full_csv, traffic = sys.argv[1:5]
+tr = json.load(open(traffic))
+
+
+def avg_us(path, frag):
+    for r in csv.DictReader(open(path)):
+        if frag in r["Name"]:
+            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    return None, 0
+
+
+def mix(Ms):
+    fl, by = [], []
+    for M in Ms:
+        fl += [2.0 * M * 2 * H * I, 2.0 * M * 4 * H * H]
+        by += [2.0 * M * (H + I) * 2 + 2 * H * I * 4, 2.0 * M * (H + H + 3 * H + H) + 4 * H * H * 4]
+    return sum(fl) / len(fl), sum(by) / len(by)
+
+
+res = {"_what": "gemm_tn_q_kernel<4> (grouped weight gradients, 36 launches per step), mean over the step's launch mix; "
+                "duration = rocprofv3 --kernel-trace --stats AverageNs of tools/prof_dominant.py; FLOPs = 2MNK summed over the "
+                "problems of a launch; algorithmic bytes = operands read once + f32 outputs accumulated once; peak = 2500 TFLOP/s "
+                "dense bf16 MFMA (MI355X_MICROARCH.md)",
+       "peak_tflops": PEAK}
+rows_packed = tr.get("row_packed_batch", {}).get("rows_per_launch_group", [10917, 11143, 37748])
+for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
+    us, calls = avg_us(path, "gemm_tn_q_kernel")
+    flop, alg = mix(Ms)
+    t = tr.get(key, {}).get("gemm_tn_q_kernel", {})
+    res[key] = {"rows_per_launch_group": Ms, "avg_launch_us": us, "launches_profiled": calls, "flop_per_launch": flop,
+                "achieved_tflops": flop / us / 1e6 if us else None, "frac_of_peak": flop / us / 1e6 / PEAK if us else None,
+                "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
+                "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))

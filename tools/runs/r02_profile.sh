@@ -17,6 +17,7 @@ rocprofv3 --pmc WRITE_SIZE $Q -d $O/pmc_full_write -- python3 tools/prof_dominan
 rocprofv3 $P -d $O/mix_packed -o mix_packed -- python3 tools/prof_dominant.py 6 >> $O/pmc.log 2>&1
 rocprofv3 $P -d $O/mix_full -o mix_full -- python3 tools/prof_dominant.py 6 full >> $O/pmc.log 2>&1
 python3 tools/traffic_json.py $O/r02_dominant_traffic.json $O/calib_fetch $O/pmc_packed_fetch $O/pmc_packed_write $O/pmc_full_fetch $O/pmc_full_write > $O/traffic.log 2>&1
+python3 tools/roofline_json.py $O/r02_roofline.json $O/mix_packed/mix_packed_kernel_stats.csv $O/mix_full/mix_full_kernel_stats.csv $O/r02_dominant_traffic.json > $O/roofline.log 2>&1
 # keep only the summaries (the traces are tens of MB)
 find $O -name "*kernel_trace.csv" -size +2M -delete
 find $O -name "*counter_collection.csv" -size +8M -delete

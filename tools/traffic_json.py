@@ -50,6 +50,8 @@ for key, fd, wd in (("row_packed_batch", pf, pw), ("all_slots_valid", ff, fw)):
         ent[name] = {"fetch_size_raw_bytes": fr, "fetch_bytes_calibrated": fr / f_lds if f_lds > 0 else None,
                      "write_size_bytes": wr, "bytes_per_launch": round(fr / f_lds + wr) if f_lds > 0 else None,
                      "launches": len(f)}
+    if key == "row_packed_batch":
+        ent["rows_per_launch_group"] = [10917, 11143, 37748]   # bench.py's timed batch (seed 1234), printed by prof_dominant.py
     res[key] = ent
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
