@@ -317,6 +317,22 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                                    traffic=(t_nt or {}).get("bytes_per_launch")))
 
 
+def _single_stream_line(args):
+    """Second line: BertImgForPreTraining (a17) at the same batch, timed by a child
+    `bench.py --model single --no-extras` with the same step count (a child process: the parent's
+    model stays resident, nothing is re-exec'd)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", "single", "--steps", str(args.steps), "--warmup", "2",
+           "--batch", str(args.batch), "--no-extras"]
+    try:
+        o = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+        d = json.loads(o.stdout.decode().strip().splitlines()[-1])
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "steps": d["steps"],
+                "step_frac": d["roofline"]["step_frac"], "workload": d["config"]["workload"]}
+    except (subprocess.TimeoutExpired, ValueError, IndexError, KeyError) as e:
+        return {"error": type(e).__name__}
+
+
 def _spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL) as
     CHILDREN before this process has touched the GPU, relay rank 0's JSON line, exit with the worst
@@ -493,6 +509,8 @@ def main():
                        "all_slots_valid": full},
             "roofline": roof,
         }
+        if world == 1 and not args.no_extras and not single:
+            out["config"]["single_stream_model"] = _single_stream_line(args)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(single=single)
         print(json.dumps(out), flush=True)

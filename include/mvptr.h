@@ -371,6 +371,11 @@ int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights
  * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,
  * so that rocprofv3's FETCH_SIZE can be calibrated against a known byte count (tools/calib_fetch.py). */
 int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, float* sink, void* stream);
+/* Measurement helper: per-CU store rate by access shape.  `blocks` 512-thread workgroups; every wave
+ * instruction writes 1 KiB as rows_per_instr segments of 1024 / rows_per_instr bytes, `stride` bytes apart
+ * (8 x 128 B at the output row stride = the GEMM epilogues' shape); tools/store_probe.py. */
+int mvptr_diag_store_probe(void* dst, int64_t dst_bytes, int blocks, int64_t bytes_per_wave, int rows_per_instr,
+                           int64_t stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,36 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const char* src, int64
   if (acc == 12345.678f) *sink = acc;
 }
 
+// Store-path probe: every wave instruction writes 1 KiB as R row segments of 1024 / R bytes, the rows
+// `stride` bytes apart (R = 1: one contiguous KiB; R = 8: eight whole 128-byte lines, the GEMM
+// epilogues' shape; R = 32: 32-byte segments).  grid = one 512-thread workgroup per CU-slot, each
+// wave sweeps its own row range, so the figure is the per-CU store rate the epilogues see.
+__global__ __launch_bounds__(512) void store_probe_kernel(char* dst, int64_t bytes_per_wave, int rows_per_instr, int64_t stride) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int seg = 1024 / rows_per_instr;            // bytes per row segment
+  const int lanes_per_row = seg / 16;
+  const int r = lane / lanes_per_row, c = lane % lanes_per_row;
+  char* base = dst + ((int64_t)blockIdx.x * 8 + wave) * (bytes_per_wave / 1024) * rows_per_instr * stride;
+  const u32x4 v = {(uint32_t)lane, 1u, 2u, 3u};
+  const int64_t n = bytes_per_wave / 1024;
+  for (int64_t i = 0; i < n; ++i)
+    *reinterpret_cast<u32x4*>(base + (i * rows_per_instr + r) * stride + c * 16) = v;
+}
+
 }  // namespace
+
+extern "C" int mvptr_diag_store_probe(void* dst, int64_t dst_bytes, int blocks, int64_t bytes_per_wave, int rows_per_instr,
+                                      int64_t stride, void* stream) {
+  if (!dst || blocks <= 0 || bytes_per_wave < 1024 || (bytes_per_wave & 1023)) MVPTR_FAIL(MVPTR_BAD_ARG, "diag_store_probe: bad argument");
+  if (rows_per_instr < 1 || rows_per_instr > 64 || (64 % rows_per_instr) || stride < 1024 / rows_per_instr || (stride & 15))
+    MVPTR_FAIL(MVPTR_BAD_ARG, "diag_store_probe: rows_per_instr must divide 64, stride >= segment");
+  const int64_t need = (int64_t)blocks * 8 * (bytes_per_wave / 1024) * rows_per_instr * stride;
+  if (need > dst_bytes) MVPTR_FAIL(MVPTR_BAD_ARG, "diag_store_probe: destination too small (%ld > %ld)", (long)need, (long)dst_bytes);
+  hipLaunchKernelGGL(store_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (char*)dst, bytes_per_wave, rows_per_instr, stride);
+  MVPTR_CHECK_LAUNCH("diag_store_probe");
+  return MVPTR_OK;
+}
 
 extern "C" int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, float* sink, void* stream) {
   if (!src || !sink || bytes < 4096 || (bytes & 4095)) MVPTR_FAIL(MVPTR_BAD_ARG, "diag_stream_read: bytes must be a positive multiple of 4096");

@@ -130,7 +130,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      *reinterpret_cast<bf16x8*>(op) = o;
+      if (p.exp_flags & 256) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(op));  // A/B knob (MVPTR_NT_EXP bit 8)
+      else *reinterpret_cast<bf16x8*>(op) = o;
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -1384,6 +1385,401 @@ inline bool q_eligible(const GemmNtArgs& a) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// "pd": persistent kernel with a DEFERRED epilogue and TWO waves per SIMD.
+//
+// What bounds the K = 768 GEMMs: a CU can store ~24 GB/s, so the 128-256 KiB
+// of a tile's outputs take 5-11 us during which the default kernel runs no MFMA; a one-wave-per-SIMD
+// kernel ("qp") can overlap the stores but not the epilogue's VALU work with its own MFMAs.  Here the
+// default kernel's loop (8 waves as 2 x 4, 16x16x32 MFMA, BK 64 double buffer, builtin LDS-DMA) runs
+// persistently over 192 x 256 tiles: a wave owns 96 x 64 = 96 accumulator registers, which leaves room
+// for the previous tile's outputs as 48 "pending" registers (bf16 of acc + bias).  At the end of a
+// tile the next tile's first two K-steps are requested, the accumulators are packed into the pending
+// registers (~200 VALU per wave) and the K-loop of the next tile starts; its first six K-steps each
+// finish one 16-row block of the pending tile — unpack, restage through the wave's 4-KiB LDS area
+// into row-chunk form, bias/GELU/dropout/residual math, 16-byte full-line stores — between their
+// MFMAs, where the SIMD's other wave keeps the matrix pipe busy.
+//  * vmcnt completes in issue order: a block's aux rows are requested BEFORE the K-step's LDS-DMA
+//    issue (waiting for them then does not wait for the loads of the next K-step), its stores come
+//    after it and may stay in flight across the next barrier (counted wait: every wave issues the
+//    same number of store instructions per block, masked lanes take an out-of-range buffer offset).
+//  * EPI_BIAS output is bit-identical to the default kernel (bias added in f32 before the rounding);
+//    epilogues with an aux operand or GELU see one extra bf16 rounding of acc + bias.
+//  * needs K >= 384 (six K-steps to drip into), N % 8 == 0 and 16-byte aligned operands.
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_aux(const GemmNtArgs& p, int mrow0, int ncol0, int lane, bf16x8 (&auxv)[2]) {
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+  if (!kNeedsAux) return;
+  const int n = ncol0 + (lane & 7) * 8, rsub = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int mj = mrow0 + it * 8 + rsub;
+    bf16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
+    if (p.aux != nullptr && mj < p.M && n < p.N) x = *reinterpret_cast<const bf16x8*>(p.aux + (int64_t)mj * p.ld_aux + n);
+    auxv[it] = x;
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_block(const GemmNtArgs& p, const NtqpOut& outs, const f32x4 (&blk)[4], float* st,
+                                                  int mrow0, int ncol0, int lane, float (&cs)[8], const bf16x8 (&auxv)[2]) {
+  // blk[nt] = 4 consecutive columns (16 nt + 4 (lane >> 4) ..) of row lane & 15 of a 16 x 64 block
+  // whose bias has been added already; finished in row-chunk form (lane: row it*8 + lane>>3, 8 columns)
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int ch = lane & 7, rsub = lane >> 3;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+    *reinterpret_cast<f32x4*>(st + c16 * 64 + (((nt * 4 + q4) ^ c16) << 2)) = blk[nt];
+  const int n = ncol0 + ch * 8;
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int lrow = it * 8 + rsub;
+    const int m = mrow0 + lrow;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch) ^ lrow) << 2));
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch + 1) ^ lrow) << 2));
+    // every lane runs the math and every wave issues the same number of store instructions (masked
+    // lanes take the always-out-of-range offset): the K-loop's counted vmcnt relies on it
+    const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : MVPTR_OOB;
+    float v[8], a[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = v0[e];
+      v[4 + e] = v1[e];
+    }
+    if (kNeedsAux) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it][e]);
+    }
+    auto store_bf8 = [&](const __amdgpu_buffer_rsrc_t& rs, const float (&o)[8]) {
+      bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = f2bf(o[e]);
+      // MVPTR_NT_EXP bit 9: sc1 (write-through, line not kept in the XCD's L2) instead of a plain store
+      if (p.exp_flags & 512) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, off, 0, 16);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, off, 0, 0);
+    };
+    if (EPI == MVPTR_EPI_BIAS) {
+      store_bf8(outs.out0, v);
+    } else if (EPI == MVPTR_EPI_BIAS_GELU) {
+      float g[8], dg[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 a2, d2;
+        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+        g[e] = a2.x;
+        g[e + 1] = a2.y;
+        dg[e] = d2.x;
+        dg[e + 1] = d2.y;
+      }
+      store_bf8(outs.out0, dg);
+      store_bf8(outs.out1, g);
+    } else if (EPI == MVPTR_EPI_BIAS_RESID) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
+      store_bf8(outs.out0, v);
+    } else if (EPI == MVPTR_EPI_GELU_BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] *= a[e];
+        if (off != MVPTR_OOB) cs[e] += v[e];
+      }
+      store_bf8(outs.out0, v);
+    } else if (EPI == MVPTR_EPI_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += a[e];
+      store_bf8(outs.out0, v);
+    } else if (EPI == MVPTR_EPI_BIAS_TANH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      store_bf8(outs.out0, v);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pd_kernel(GemmNtArgs p) {
+  constexpr int BM = 192, BN = 256, BK = 64, WN = 4, MT = 6, WROWS = 96, NWAVES = 8;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int ROW_B = 128, NA = 3, NB = 4, KS = 2;
+  constexpr int STORES_PER_BLOCK = (EPI == MVPTR_EPI_BIAS_GELU) ? 4 : 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int grid = gridDim.x;
+  const int srow = wave * 8 + (lane >> 3);
+  const int kc = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * 8;
+  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
+  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
+  const uint32_t stepA = 64u * (uint32_t)p.lda * 2u, stepB = 64u * (uint32_t)p.ldb * 2u;
+  const int wm = wave / WN, wn = wave % WN;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  uint32_t fx0[KS], fw0[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int sw = (c16 >> 1) & 7;   // (row >> 1) & 7 of every fragment row this lane reads
+    fx0[ks] = (uint32_t)((wm * WROWS + c16) * ROW_B + (((ks * 4 + q4) ^ sw) << 4));
+    fw0[ks] = (uint32_t)((wn * 64 + c16) * ROW_B + (((ks * 4 + q4) ^ sw) << 4));
+  }
+  float* st = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * (16 * 64);
+  const int nk = (p.K + BK - 1) / BK;
+
+  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
+    const int base = round * grid;
+    const int left = ntiles - base;
+    if (left <= 0) return false;
+    const int nthis = min(left, grid);
+    if ((int)blockIdx.x >= nthis) return false;
+    const int t = base + xcd_remap(blockIdx.x, nthis);
+    const int gsz = GROUP_M * p.tiles_n;
+    const int grp = t / gsz;
+    const int first_m = grp * GROUP_M;
+    const int gm = min(GROUP_M, p.tiles_m - first_m);
+    const int in_g = t - grp * gsz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+    return true;
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int buf, int k0) {
+    char* la = lds + buf * STAGE_BYTES;
+    char* lb = la + A_BYTES;
+    const bool in_k = (k0 + kc < p.K);
+    uint32_t oa = offA0, ob = offB0;
+    asm volatile("" : "+v"(oa), "+v"(ob));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const uint32_t va = in_k ? oa + (uint32_t)i * stepA + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const uint32_t vb = in_k ? ob + (uint32_t)i * stepB + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+  auto rsrc_a = [&](int m0) {
+    const int rows_a = min(BM, p.M - m0);
+    return make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+  };
+  auto rsrc_b = [&](int n0) {
+    const int rows_b = min(BN, p.N - n0);
+    return make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
+  };
+
+  int m0 = 0, n0 = 0;
+  if (!tile_origin(0, m0, n0)) return;
+  __amdgpu_buffer_rsrc_t rsA = rsrc_a(m0), rsB = rsrc_b(n0);
+  f32x4 acc[4][MT];
+  uint32_t pend[MT][4][2];   // previous tile: bf16(acc + bias), [16-row block][16-column block][pair]
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pend[i][j][0] = pend[i][j][1] = 0u;
+  int pm0 = 0x40000000, pn0 = 0;  // origin of the pending tile (none yet: every row fails m < M)
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint32_t out_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);  // < 4 GiB (launch condition)
+  NtqpOut outs;
+  outs.out0 = make_rsrc_uniform(p.out0, out_bytes);
+  outs.out1 = make_rsrc_uniform(p.out1 != nullptr ? p.out1 : p.out0, p.out1 != nullptr ? out_bytes : 0u);
+
+  // finish 16-row block `mt` of the pending tile: drip_load (aux rows) ahead of the K-step's LDS-DMA
+  // issue, drip (math + stores) between its MFMAs
+  bf16x8 auxv[2];
+  auto drip_load = [&](int mt) {
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    nt_epilogue_aux<EPI>(p, pm0 + wm * WROWS + mt * 16, pn0 + wn * 64, lane_e, auxv);
+  };
+  auto drip = [&](int mt) {
+    if (p.exp_flags & 128) {   // ablation (MVPTR_NT_EXP bit 7): no deferred epilogue work; keeps the store count
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < STORES_PER_BLOCK; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, outs.out0, MVPTR_OOB, 0, 0);
+      return;
+    }
+    f32x4 blk[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      blk[nt][0] = __builtin_bit_cast(float, pend[mt][nt][0] << 16);
+      blk[nt][1] = __builtin_bit_cast(float, pend[mt][nt][0] & 0xffff0000u);
+      blk[nt][2] = __builtin_bit_cast(float, pend[mt][nt][1] << 16);
+      blk[nt][3] = __builtin_bit_cast(float, pend[mt][nt][1] & 0xffff0000u);
+    }
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));   // epilogue constants re-derived here, not kept across the MFMA loop
+    nt_epilogue_block<EPI>(p, outs, blk, st, pm0 + wm * WROWS + mt * 16, pn0 + wn * 64, lane_e, cs, auxv);
+    if (EPI == MVPTR_EPI_GELU_BWD && mt == MT - 1 && p.vec_out != nullptr) {
+      const int ch = lane_e & 7, rsub = lane_e >> 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float sum = cs[e];
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const int n = pn0 + wn * 64 + ch * 8 + e;
+        if (rsub == 0 && n < p.N && pm0 < p.M) atomicAdd(p.vec_out + n, sum);
+        cs[e] = 0.f;
+      }
+    }
+  };
+
+  bool prefetched = false;
+  for (int round = 0;; ++round) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!prefetched) stage(rsA, rsB, 0, 0);
+    // DRIP: pending block finished in this K-step (-1: none; -2: none, but the previous K-step's block
+    // stores may still be in flight)
+    auto kstep = [&](int kt, auto drip_tag) {
+      constexpr int DRIP = decltype(drip_tag)::value;
+      // K-step kt has landed once only the deferred stores issued AFTER its loads (the previous
+      // K-step's block: a fixed number of store instructions per wave) remain outstanding; after the
+      // block that ends with the column-sum atomics everything is waited for
+      constexpr bool kCounted = (DRIP >= 1 || DRIP == -2) && !(EPI == MVPTR_EPI_GELU_BWD && (DRIP == -2));
+      if constexpr (kCounted) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STORES_PER_BLOCK) : "memory");
+      } else if constexpr (DRIP == 0) {
+        // first K-step of a tile: when the previous tile's end requested K-steps 0 AND 1, only K-step 0
+        // has to have landed (the LDS-DMA instructions of K-step 1 may stay in flight)
+        if (prefetched) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NA + NB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      if constexpr (DRIP >= 0) drip_load(DRIP);
+      const int buf = kt & 1;
+      const char* la = lds + buf * STAGE_BYTES;
+      const char* lb = la + A_BYTES;
+      bf16x8 xf[MT], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[0] + i * 16 * ROW_B);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[0] + i * 16 * ROW_B);
+      if (kt + 1 < nk && !(prefetched && kt == 0)) stage(rsA, rsB, buf ^ 1, (kt + 1) * BK);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks > 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[ks] + i * 16 * ROW_B);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[ks] + i * 16 * ROW_B);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (DRIP >= 0) {
+          if (ks == 0) drip(DRIP);
+        }
+      }
+    };
+    kstep(0, std::integral_constant<int, 0>{});
+    kstep(1, std::integral_constant<int, 1>{});
+    kstep(2, std::integral_constant<int, 2>{});
+    kstep(3, std::integral_constant<int, 3>{});
+    kstep(4, std::integral_constant<int, 4>{});
+    kstep(5, std::integral_constant<int, 5>{});
+    if (nk > 6) kstep(6, std::integral_constant<int, -2>{});
+    for (int kt = 7; kt < nk; ++kt) kstep(kt, std::integral_constant<int, -1>{});
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand ring
+    int m1 = 0, n1 = 0;
+    const bool more = tile_origin(round + 1, m1, n1);
+    __amdgpu_buffer_rsrc_t rsA1 = rsA, rsB1 = rsB;
+    // the tile's bias quads first (their wait must not include the next tile's loads), then the next
+    // tile's first two K-steps, then accumulators (+ bias in f32) -> bf16 pending registers
+    f32x4 b4[4];
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int nb0 = n0 + wn * 64 + (lane_e >> 4) * 4;
+      constexpr bool kBias = (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        b4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = nb0 + nt * 16;
+        if (kBias && p.bias != nullptr && n < p.N) b4[nt] = *reinterpret_cast<const f32x4*>(p.bias + n);  // N % 8 == 0: whole quads
+      }
+      asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));   // landed before the loads below are issued
+    }
+    if (more) {
+      rsA1 = rsrc_a(m1);
+      rsB1 = rsrc_b(n1);
+      stage(rsA1, rsB1, 0, 0);
+      stage(rsA1, rsB1, 1, BK);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x2 lo = {f2bf(acc[nt][mt][0] + b4[nt][0]), f2bf(acc[nt][mt][1] + b4[nt][1])};
+        const bf16x2 hi = {f2bf(acc[nt][mt][2] + b4[nt][2]), f2bf(acc[nt][mt][3] + b4[nt][3])};
+        pend[mt][nt][0] = __builtin_bit_cast(uint32_t, lo);
+        pend[mt][nt][1] = __builtin_bit_cast(uint32_t, hi);
+      }
+    pm0 = m0;
+    pn0 = n0;
+    if (!more) break;
+    m0 = m1;
+    n0 = n1;
+    rsA = rsA1;
+    rsB = rsB1;
+    prefetched = true;
+  }
+  // the last tile's epilogue
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    drip_load(mt);
+    drip(mt);
+  }
+}
+
+template <int EPI>
+int launch_pd(GemmNtArgs a, hipStream_t s) {
+  constexpr int LDS_BYTES = 2 * (192 + 256) * 64 * 2 + 8 * 16 * 64 * 4;  // 112 KiB ring + 32 KiB staging
+  a.tiles_m = (a.M + 191) / 192;
+  a.tiles_n = (a.N + 255) / 256;
+  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff ||
+      (int64_t)a.M * a.ldc * 2 >= (int64_t)0x7fffffff)
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pd_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
+    num_cu = prop.multiProcessorCount;
+  }
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int grid = ntiles < num_cu ? ntiles : num_cu;
+  hipLaunchKernelGGL((gemm_nt_pd_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
+}
+template <int EPI>
+constexpr bool pd_has_epilogue() {
+  return EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD ||
+         EPI == MVPTR_EPI_ADD || EPI == MVPTR_EPI_BIAS_TANH;
+}
+// whole 8-column runs, 16-byte accesses, six K-steps to drip into
+inline bool pd_eligible(const GemmNtArgs& a) {
+  if ((a.N & 7) || !a.vec_out_ok || a.K < 384) return false;
+  if (a.aux != nullptr && !a.vec_aux_ok) return false;
+  if (a.bias != nullptr && !a.vec_bias_ok) return false;
+  return true;
+}
+
 template <int EPI>
 int launch_persist(GemmNtArgs a, hipStream_t s) {
   using C = Cfg<64, 2, 2, 4, 8>;
@@ -1444,6 +1840,14 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
     const size_t n = strlen(env);
+    if (env[0] == 'p' && env[1] == 'd') {
+      if constexpr (pd_has_epilogue<EPI>()) {
+        if (!pd_eligible(a)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=pd needs N %% 8 == 0, K >= 384, 16-byte aligned operands");
+        return launch_pd<EPI>(a, s);
+      } else {
+        MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=pd: epilogue not supported");
+      }
+    }
     if (env[0] == 'q' && env[1] == 'p') {
       if constexpr (qp_has_epilogue<EPI>()) {
         if (!q_eligible(a) || a.K < 512) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=qp needs the Q conditions and K >= 512");

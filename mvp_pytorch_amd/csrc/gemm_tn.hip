@@ -703,7 +703,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
-  if (pick == 4) return launch_tn_q<4>(g, stream);
+  if (pick == 4) return (mvptr_knobs().nt_exp & 64) ? launch_tn_q<5>(g, stream) : launch_tn_q<4>(g, stream);  // bit 6: 5-stage ring (160 KiB), A/B knob
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
   if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);

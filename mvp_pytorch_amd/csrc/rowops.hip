@@ -209,8 +209,18 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* parti
   // blockIdx.y slices the partial rows; 32 slices -> 32 adds per address, no contention to speak of
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  // eight independent loads in flight per thread: the serial form paid a full memory latency per
+  // partial row (21 us per call, 0.9 ms per step)
   float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += partial[(int64_t)b * 3 * H + i];
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u) * 3 * H + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < b1; ++b) s += partial[(int64_t)b * 3 * H + i];
   if (b1 > b0) atomicAdd(dst + col, s);
 }
 

@@ -103,6 +103,51 @@ def test_gemm_nt_qp_config(dev, M, N, K):
     assert _rel(act[:2048], torch.nn.functional.gelu(base)) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(192, 768, 768), (300, 2304, 768), (777, 768, 3072), (500, 768, 2056), (70000, 512, 512), (1030, 520, 1000), (50, 3072, 768)])
+def test_gemm_nt_pd_config(dev, M, N, K):
+    """The persistent 8-wave kernel with the deferred epilogue ("pd"): EPI_BIAS bit-identical to the
+    default configuration, the other epilogues within bf16 rounding of it and of the f32 reference;
+    several tiles per workgroup (M = 70000), ragged M / N / K edges, dropout, column sums."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(13)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = _bf(torch.randn(M, N, generator=g)).to(dev)
+    drop = hip.make_dropout(0.1, 0x1234567890)
+
+    def run_all():
+        vec = torch.zeros(N, device=dev)
+        r = dict(bias=hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias), nobias=hip.gemm_nt(a, b, hip.EPI_BIAS),
+                 gelu=hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias),
+                 resid=hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux),
+                 rdrop=hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux, drop=drop),
+                 tanh=hip.gemm_nt(a, b, hip.EPI_BIAS_TANH, bias=bias), add=hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux),
+                 add0=hip.gemm_nt(a, b, hip.EPI_ADD), gbwd=hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=aux, vec_out=vec))
+        r["vec"] = vec
+        return r
+
+    ref = run_all()
+    hip.set_knob("MVPTR_GEMM_CFG", "pd")
+    try:
+        out = run_all()
+    finally:
+        hip.set_knob("MVPTR_GEMM_CFG", "")
+    assert torch.equal(out["bias"], ref["bias"]) and torch.equal(out["nobias"], ref["nobias"])
+    assert torch.equal(out["add0"], ref["add0"])
+    for k in ("resid", "rdrop", "tanh", "add", "gbwd"):
+        assert _rel(out[k], ref[k]) < 4e-3, k
+    assert _rel(out["gelu"][0], ref["gelu"][0]) < 4e-3 and _rel(out["gelu"][1], ref["gelu"][1]) < 4e-3
+    assert _rel(out["vec"], ref["vec"]) < 2e-3
+    n_rows = min(M, 1024)
+    base = a[:n_rows].float() @ b.float().t()
+    assert _rel(out["resid"][:n_rows], base + bias + aux[:n_rows].float()) < 5e-3
+    assert _rel(out["gbwd"][:n_rows], base * aux[:n_rows].float()) < 5e-3
+    keep = hip.dropout_mask(drop, M * N, dev).reshape(M, N).float()[:n_rows]
+    scale = 65536.0 / (65536.0 - drop.thresh16)
+    assert _rel(out["rdrop"][:n_rows], (base + bias) * keep * scale + aux[:n_rows].float()) < 5e-3
+
+
 def test_gemm_nt_q_identity_layout(dev):
     from mvp_pytorch_amd import hip
     K = 128

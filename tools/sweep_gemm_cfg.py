@@ -54,9 +54,9 @@ for M in MS:
         for cfg in CFGS:
             hip.set_knob("MVPTR_GEMM_CFG", cfg)
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            vec = torch.zeros(N, device=dev) if (epi == hip.EPI_GELU_BWD and cfg != "q") else None
+            vec = torch.zeros(N, device=dev) if (epi == hip.EPI_GELU_BWD and cfg not in ("q", "qp")) else None
             us = timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec))
-            ok = torch.equal(out.float(), ref)
+            ok = torch.equal(out.float(), ref) or ((out.float() - ref).norm() / ref.norm()).item() < 4e-3
             line += "  %s %6.1fus %6.1fTF%s" % (cfg, us, 2.0 * M * N * K / us / 1e6, "" if ok else " MISMATCH")
         print(line, flush=True)
 hip.set_knob("MVPTR_GEMM_CFG", "")
