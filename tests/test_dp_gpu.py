@@ -12,7 +12,7 @@ import golden_util as gu
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sparse):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -25,7 +25,8 @@ def _worker(rank, world, port, q):
     model = modeling.BiBertImgForPreTraining(modeling.make_config(cfg)).to(dev)
     model.train()
     opt, sched = train.build_optimizer(model, lr=1e-3, t_total=10)
-    sync = dp.GradSync(model, bucket_mb=0.25)
+    sparse_rows = [model.bert.embeddings.word_embeddings.weight] if sparse else []
+    sync = dp.GradSync(model, bucket_mb=0.25, sparse_rows=sparse_rows)
     dims = dict(B=4, T=12, P=3, G=6, R=5)
     losses = []
     for step in range(3):
@@ -37,26 +38,40 @@ def _worker(rank, world, port, q):
     probe = {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()
              if n in ("bert.txt_encoder.layer.0.attention.self.query.weight", "bert.embeddings.word_embeddings.weight",
                       "cls.predictions.decoder.weight", "logit_scale", "qa_head.weight")}
-    q.put((rank, losses, probe, len(sync.buckets)))
+    n_sparse = sum(1 for b in sync.buckets if b["rows_of"] is not None)
+    q.put((rank, losses, probe, len(sync.buckets), n_sparse))
     dist.destroy_process_group()
 
 
-def test_two_rank_training_step_keeps_replicas_identical(dev):
-    import numpy as np
+def _run(sparse):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 1000) + (11 if sparse else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sparse)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, p0, nb), (_, l1, p1, _) = res
-    assert nb > 1
-    assert all(np.isfinite(l0)) and all(np.isfinite(l1))
-    for k in p0:
-        assert np.array_equal(p0[k], p1[k]), k   # same averaged gradients -> identical replicas
-    print("two-rank losses", l0, l1)
+    return res
+
+
+def test_two_rank_training_step_keeps_replicas_identical(dev):
+    """Dense exchange, then the row-sparse exchange of the word-embedding gradient (GradSync.note_rows from
+    train.pretrain_step): replicas identical in both, and both modes give the same parameters."""
+    import numpy as np
+    probes = []
+    for sparse in (False, True):
+        (_, l0, p0, nb, ns), (_, l1, p1, _, _) = _run(sparse)
+        assert nb > 1 and ns == (1 if sparse else 0)
+        assert all(np.isfinite(l0)) and all(np.isfinite(l1))
+        for k in p0:
+            assert np.array_equal(p0[k], p1[k]), k   # same averaged gradients -> identical replicas
+        print("two-rank losses", "sparse" if sparse else "dense", l0, l1)
+        probes.append((l0, p0))
+    (ld, pd_), (ls, ps) = probes
+    assert ld == ls
+    for k in pd_:
+        assert np.array_equal(pd_[k], ps[k]), k     # rows outside the union are zero on both ranks: same sums
