@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""GPU idle share of a bench run from a rocprofv3 kernel trace: union of the kernel intervals against the
+span of the last N steps' kernels:  gpu_idle.py KERNEL_TRACE.csv"""
+import csv
+import sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+# steps are delimited by the AdamW launches (two parameter groups per step)
+adam = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r[2]]
+steps = adam[1::2]
+if len(steps) < 6:
+    raise SystemExit("not enough steps in the trace")
+lo, hi = steps[-6], steps[-1]          # five whole steps
+seg = rows[lo + 1:hi + 1]
+t0, t1 = seg[0][0], max(e for _, e, _ in seg)
+busy, cur_s, cur_e = 0, None, None
+for s, e, _ in seg:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+span = t1 - t0
+gaps = sorted(((seg[i + 1][0] - max(e for _, e, _ in seg[max(0, i - 8):i + 1])) for i in range(len(seg) - 1)), reverse=True)
+print("5 steps: span %.2f ms (%.2f ms/step), GPU busy %.2f ms = %.1f %%, idle %.2f ms/step, kernels/step %d, sum of kernel time %.2f ms/step"
+      % (span / 1e6, span / 5e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 5e6, len(seg) // 5,
+         sum(e - s for s, e, _ in seg) / 5e6))
+print("largest gaps (us):", [round(g / 1e3, 1) for g in gaps[:12]])
