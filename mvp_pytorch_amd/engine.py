@@ -303,6 +303,34 @@ def side_stream(device):
         return SIDE_STREAMS[key]
 
 
+class AsyncCounts:
+    """A few device-side integers (row counts that size later tensors) on their way to the host.
+    `tolist()` on the device tensor would wait for EVERYTHING queued on the stream and hand the GPU an
+    empty queue; here the copy goes to pinned memory right away and is awaited through an event, so
+    the kernels queued after it (embeddings, index_select / cat of the hard batch) keep the GPU busy
+    while the host reads the counts and starts queueing the next stage."""
+    _pins = {}
+
+    def __init__(self, values):
+        t = torch.stack([v.reshape(()) for v in values]).to(torch.int64)
+        if not t.is_cuda:
+            self._host, self._event = t, None
+            return
+        key = (t.device.index, t.numel(), threading.get_ident())
+        with _state_lock:
+            bufs = AsyncCounts._pins.setdefault(key, [torch.empty(t.numel(), dtype=torch.int64).pin_memory() for _ in range(4)])
+            bufs.append(bufs.pop(0))       # rotate: a buffer is reused four requests later at the earliest
+            self._host = bufs[-1]
+        self._host.copy_(t, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def get(self):
+        if self._event is not None:
+            self._event.synchronize()
+        return [int(v) for v in self._host.tolist()]
+
+
 class PackRows(torch.autograd.Function):
     """x [n, H] -> x[idx] for a strictly increasing idx (the valid rows of a padded batch).  idx has no
     duplicates, so the backward pass is a plain scatter into zeros (index_copy), not the atomic

@@ -218,7 +218,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
 
     # -- stage 1: uni-modal encoders (vl:479-513)
     def _uni(self, input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a, input_ids_b,
-             token_type_ids_b, attention_mask_b, position_ids_b, img_feats):
+             token_type_ids_b, attention_mask_b, position_ids_b, img_feats, pack_hints=None):
         if attention_mask_a is None:
             attention_mask_a = torch.ones_like(input_ids_a)
         if attention_mask_b is None:
@@ -233,7 +233,14 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self, share)
         xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self, share)
         hint_a = hint_b = None
-        if self.txt_encoder.unpad is True or (self.txt_encoder.unpad == "train" and self.training):
+        if pack_hints is not None:
+            # fetched by the caller together with its other counts; an AsyncCounts is awaited only now,
+            # with the embedding kernels already queued behind the copy
+            if isinstance(pack_hints, engine.AsyncCounts):
+                c = pack_hints.get()
+                pack_hints = ((c[2], c[3]), (c[4], c[5]))
+            hint_a, hint_b = pack_hints
+        elif self.txt_encoder.unpad is True or (self.txt_encoder.unpad == "train" and self.training):
             # the valid-row counts of both uni-modal passes in ONE device->host copy, issued before any
             # encoder work is queued (a sync in the middle of the forward pass drains the launch queue)
             la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
@@ -285,11 +292,13 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
     def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
                 use_b=False, position_ids_a=None, input_ids_b=None, token_type_ids_b=None,
                 attention_mask_b=None, phrase_layer=None, position_ids_b=None, head_mask=None,
-                img_feats=None, encoder_history_states=None, encode_hn=False, hn_mod="hard", logit=None):
+                img_feats=None, encoder_history_states=None, encode_hn=False, hn_mod="hard", logit=None,
+                pack_hints=None):
         if head_mask is not None or encoder_history_states or phrase_layer is not None:
             raise NotImplementedError("head_mask / encoder_history_states / phrase_layer are outside the accelerated path")
         txt, vis, mask_a, mask_b = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
-                                             input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats)
+                                             input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats,
+                                             pack_hints)
         cut = 1 if use_b else max_tag_length
         only_vis = vis[:, cut:, :]
         only_vis_mask = mask_b[:, cut:]
@@ -308,18 +317,32 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             #                         (text hard_txt[j], image j)  for j in second       (vl:544-566)
             hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
             hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
-            hard_seqs = torch.cat([txt.index_select(0, hard_txt_full), only_vis.index_select(0, hard_img_full)], 1)
             hard_mask = torch.cat([mask_a.index_select(0, hard_txt_full), only_vis_mask.index_select(0, hard_img_full)], 1)
-
-        joint = torch.cat([txt, only_vis], dim=1)
         joint_mask = torch.cat([mask_a, only_vis_mask], dim=-1)
+        cnt = None
+        enc = self.mul_encoder
+        if encode_hn and txt.is_cuda and (enc.unpad is True or (enc.unpad == "train" and self.training)):
+            # rows / longest sequence of the 2n-row pass depend on the mined hard negatives: request them
+            # from the (small) masks now, queue the gathers and concatenations of the activations behind
+            # the copy, and read the two numbers while the GPU is still busy with those
+            both_mask = torch.cat([joint_mask, hard_mask], 0)
+            lens = (both_mask == 0).sum(1)
+            cnt = engine.AsyncCounts([lens.sum(), lens.max()])
+        if encode_hn:
+            hard_seqs = torch.cat([txt.index_select(0, hard_txt_full), only_vis.index_select(0, hard_img_full)], 1)
+        joint = torch.cat([txt, only_vis], dim=1)
         if encode_hn:
             # The reference runs mul_encoder twice (hard batch vl:567, matched batch vl:577); the two
             # passes share weights and do not depend on each other, so they go through the layer
             # stack as ONE 2n-row batch: at configs[1] that is 250 row tiles of 256 instead of
             # 2 x 125, which fills whole rounds of the 256 CUs (375 tiles = 1.46 rounds before).
             n = joint.shape[0]
-            both = self.mul_encoder(torch.cat([joint, hard_seqs], 0), torch.cat([joint_mask, hard_mask], 0))[0]
+            both_in = torch.cat([joint, hard_seqs], 0)
+            if cnt is None:
+                both_mask, hint = torch.cat([joint_mask, hard_mask], 0), None
+            else:
+                hint = tuple(cnt.get())
+            both = self.mul_encoder(both_in, both_mask, pack_hint=hint)[0]
             sequence_output, hard_out = both[:n], both[n:]
             hard_pooled = self.pooler(hard_out)
         else:
@@ -431,10 +454,12 @@ class BertVQAHeads(nn.Module):
         return self.predictions(sequence_output)
 
 
-def _masked_rows(seq, labels):
-    """rows of seq [B,L,H] whose label > -1 (vl:1231-1234 masked_select + reshape) and their labels."""
-    keep = (labels > -1).reshape(-1)
-    idx = torch.nonzero(keep).squeeze(1)
+def _masked_rows(seq, labels, idx=None):
+    """rows of seq [B,L,H] whose label > -1 (vl:1231-1234 masked_select + reshape) and their labels.
+    idx: their flat positions when the caller has them already (torch.nonzero is a host sync)."""
+    if idx is None:
+        keep = (labels > -1).reshape(-1)
+        idx = torch.nonzero(keep).squeeze(1)
     rows = seq.reshape(-1, seq.shape[-1]).index_select(0, idx)
     return rows, labels.reshape(-1).index_select(0, idx)
 
@@ -663,15 +688,31 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 masked_lm_labels_b=None, max_tag_length=20, position_ids_a=None, position_ids_b=None,
                 head_mask=None, img_feats=None, is_img_match=None, img_index=None, phrase_index=None,
                 phrase_mod="sample"):
+        # Every data-dependent COUNT that only depends on the inputs (scored rows of the two MLM heads,
+        # valid rows / longest sequence of the two uni-modal stacks) is fetched in ONE device->host copy
+        # here, before any encoder work is queued: a sync in the middle of the step drains the launch
+        # queue and leaves the GPU idle until the host has caught up (four of them: ~1 ms per step).
+        idx_a = idx_b = pack_hints = None
+        enc = self.bert.txt_encoder
+        if (masked_lm_labels_a is not None and masked_lm_labels_b is not None and masked_lm_labels_a.is_cuda and
+                attention_mask_a is not None and attention_mask_b is not None and
+                (enc.unpad is True or (enc.unpad == "train" and self.training))):
+            keep_a, keep_b = (masked_lm_labels_a > -1).reshape(-1), (masked_lm_labels_b > -1).reshape(-1)
+            la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
+            pack_hints = engine.AsyncCounts([keep_a.sum(), keep_b.sum(), la.sum(), la.max(), lb.sum(), lb.max()])
         outputs, single, hard_indexes = self.bert(
             input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
             attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats, input_ids_b=input_ids_b,
             position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b, attention_mask_b=attention_mask_b,
-            max_tag_length=max_tag_length, encode_hn=True)
+            max_tag_length=max_tag_length, encode_hn=True, pack_hints=pack_hints)
         txt_out, vis_out, sim_mat = single
         ce_loss = CrossEntropyLoss(ignore_index=-1)
+        if pack_hints is not None:
+            c = pack_hints.get()      # landed long ago (awaited in the backbone)
+            idx_a = torch.nonzero_static(keep_a, size=c[0]).view(-1)
+            idx_b = torch.nonzero_static(keep_b, size=c[1]).view(-1)
 
-        vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b)
+        vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b, idx_b)
         vis_mlm_loss, _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels, want_scores=False)
 
         logits = sim_mat * self.logit_scale.exp()
@@ -679,11 +720,12 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         retrieval_loss = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
 
         sequence_output, pooled_output, hard_sequence_output, hard_pooled_output = outputs
-        rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a)
+        rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a, idx_a)
         masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels, want_scores=False)
         seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
         n = pooled_output.shape[0]
-        next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long), torch.ones(n, dtype=torch.long)]).to(seq_relationship_score.device)
+        dev = seq_relationship_score.device      # built on the device: a pageable host->device copy is a sync
+        next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
         next_sentence_loss = ce_loss(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
 
         total_loss = vis_mlm_loss + retrieval_loss + masked_lm_loss + next_sentence_loss
@@ -785,7 +827,7 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
         _, pooled, _, hard_pooled = outputs
         score = self.classifier(self.dropout(torch.cat([pooled, hard_pooled], dim=0)))
         n = pooled.shape[0]
-        label = torch.cat([torch.ones(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)]).to(score.device)
+        label = torch.cat([torch.ones(n, dtype=torch.long, device=score.device), torch.zeros(n, dtype=torch.long, device=score.device)])
         itm_loss = ce_loss(score.view(-1, self.num_labels), label.view(-1))
         return (retrieval_loss + itm_loss, score, retrieval_loss, itm_loss, label)
 

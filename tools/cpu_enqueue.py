@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Host time spent inside train.pretrain_step (kernel enqueue + Python) against the wall time per
+step: how close the step is to being launch-bound."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from mvp_pytorch_amd import hip, modeling, train  # noqa: E402
+from mvp_pytorch_amd.synthetic import synthetic_batch  # noqa: E402
+
+dev = torch.device("cuda:0")
+hip.load()
+fixed = len(sys.argv) > 1 and sys.argv[1] == "fixed"
+dims = dict(B=256, T=70, P=5, G=20, R=50)
+torch.manual_seed(1234)
+model = modeling.BiBertImgForPreTraining(modeling.make_config(bench.BASE_CFG)).to(dev).train()
+opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
+b = synthetic_batch(dims, bench.BASE_CFG, 1234, fixed_length=fixed, device=dev)
+for _ in range(3):
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])
+torch.cuda.synchronize()
+host, n = 0.0, 10
+t0 = time.perf_counter()
+for _ in range(n):
+    h0 = time.perf_counter()
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])
+    host += time.perf_counter() - h0
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+print("%s: wall %.2f ms/step, host time inside pretrain_step %.2f ms/step (includes waiting at the step's host syncs)"
+      % ("fixed" if fixed else "packed", wall / n * 1e3, host / n * 1e3))
+from torch.profiler import profile, ProfilerActivity  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU]) as prof:
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])
+    torch.cuda.synchronize()
+ev = prof.key_averages()
+tot = sum(e.self_cpu_time_total for e in ev) / 1e3
+print("torch profiler: self CPU time of all torch ops in one step %.2f ms; top ops:" % tot)
+for e in sorted(ev, key=lambda e: -e.self_cpu_time_total)[:14]:
+    print("   %-50s calls %5d  self cpu %.2f ms" % (e.key[:50], e.count, e.self_cpu_time_total / 1e3))
