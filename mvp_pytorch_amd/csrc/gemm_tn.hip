@@ -12,7 +12,10 @@
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -41,6 +44,10 @@ struct GemmTnGroup {
   GemmTnArgs prob[MVPTR_TN_MAX_GROUP];
   int base[MVPTR_TN_MAX_GROUP + 1];
   int count;
+  // "Q" kernel only: per-workgroup 256x256 f32 slabs (workgroup g writes slab g, 256 KiB, in register
+  // order) that tn_reduce_kernel sums over the M-splits; nullptr = f32 atomics straight into dW
+  float* slab;
+  int splits;
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 // certifies stage st+1 sits between the two 16-row halves of stage st, and what follows it (issue of
 // stage st+STAGES into the buffer just freed, fragment reads of the next stage's first half) runs
 // under the 16 MFMAs of the second half, whose fragments are already in registers.
-template <int STAGES>
+template <int STAGES, bool SLAB>
 __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   constexpr int TM_ = 32;
   constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
@@ -526,6 +533,31 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, hh = lane_e >> 5;
+  if constexpr (SLAB) {
+    // slab mode: the partial tile goes out as plain 16-byte stores, 1 KiB contiguous per wave
+    // instruction (float index ((((wave*4 + nb)*4 + kb)*4 + i)*64 + lane)*4 + j holds accumulator
+    // register r = 4 i + j).  Plain stores run at the chip's write rate (~6.5 TB/s measured) where
+    // f32 atomics reach ~1.3 TB/s, and the sum over the splits is taken in a fixed order.
+    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 16384 + lane_e * 4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = {acc[nb][kb][4 * i], acc[nb][kb][4 * i + 1], acc[nb][kb][4 * i + 2], acc[nb][kb][4 * i + 3]};
+          *reinterpret_cast<f32x4*>(sl + ((nb * 4 + kb) * 4 + i) * 256) = v;
+        }
+    if (do_bias) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
+        const int n = n0 + wn * 128 + nb * 32 + l31;
+        if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
+      }
+    }
+    return;
+  }
   const int nw = n0 + wn * 128 + 4 * hh, kw = k0 + wk * 128 + l31;
   const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
   float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
@@ -557,6 +589,319 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
       const int n = n0 + wn * 128 + nb * 32 + l31;
       if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
     }
+  }
+}
+
+
+// "H" configuration: the "Q" tile (256 x 256 per 256-thread workgroup, four waves of 128 x 128, 32
+// token rows per stage, STAGES-deep LDS-DMA ring) on v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of
+// 16 x 16 per wave, one MFMA per block and 32-row stage.  LDS bytes, LDS instructions and cycles per
+// FLOP equal "Q"'s; what differs is that a 16x16x32 MFMA reads and writes a quarter of the
+// accumulator values of a 32x32x16 per instruction (half per FLOP), and the chip holds a higher
+// clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7).  The fragments of stage
+// st+1 are read during the MFMAs of stage st (two fragment sets, 128 registers), so a stage's
+// buffer is free — and refilled with stage st+STAGES — from the barrier at the START of its MFMAs.
+template <int STAGES, bool SLAB>
+__global__ __launch_bounds__(256, 1) void gemm_tn_h_kernel(GemmTnGroup grp) {
+  constexpr int TM_ = 32;
+  constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
+  constexpr int STAGE_B = 4 * SUB_B;   // A: 2 sub-tiles (256 n), B: 2 sub-tiles (256 k)
+  constexpr int NI = 4, LPS = 8;
+  constexpr int TKW = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gidx = xcd_remap(blockIdx.x, gridDim.x);
+  GemmTnArgs p = grp.prob[0];
+  int pbase = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
+    if (i < grp.count && gidx >= grp.base[i]) {
+      p = grp.prob[i];
+      pbase = grp.base[i];
+    }
+  const int nt = p.tiles_n * p.tiles_k;
+  const int idx = gidx - pbase;
+  const int split = idx / nt;
+  const int t = idx - split * nt;
+  int tn, tk;
+  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
+    tk = t / p.tiles_n;
+    tn = t - tk * p.tiles_n;
+  } else {
+    tn = t / p.tiles_k;
+    tk = t - tn * p.tiles_k;
+  }
+  const int n0 = tn * TN_, k0 = tk * TKW;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int rows = m_end - m_begin;
+  if (rows <= 0) return;
+  const int ncols = min(TN_, p.N - n0);
+  const int kcols = min(TKW, p.K - k0);
+  const int ncols8 = (int)min((int64_t)((ncols + 7) & ~7), p.lda - n0);
+  const int kcols8 = (int)min((int64_t)((kcols + 7) & ~7), p.ldb - k0);
+  const u32x4 rsA = make_rsrc_words(
+      p.A + (int64_t)m_begin * p.lda + n0, (uint32_t)(((int64_t)(rows - 1) * p.lda + ncols8) * 2));
+  const u32x4 rsB = make_rsrc_words(
+      p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
+  const uint32_t lds0 = lds_addr(lds);
+
+  uint32_t offA[NI], offB[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = i * 4 + wave;
+    const int row = (j & 7) * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ swz256(row);
+    const int col = (j >> 3) * 128 + ch * 8;
+    offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
+    offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
+  }
+  const uint32_t stepA = (uint32_t)(TM_ * p.lda * 2), stepB = (uint32_t)(TM_ * p.ldb * 2);
+  auto stage_piece = [&](int buf, int st, int i) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
+    if (i < NI) {
+      const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)st * stepA;
+      lds_dma16(rsA, va, la + i * 4096);
+    } else {
+      const int j = i - NI;
+      const uint32_t vb = (offB[j] == MVPTR_OOB) ? MVPTR_OOB : offB[j] + (uint32_t)st * stepB;
+      lds_dma16(rsB, vb, la + 2 * SUB_B + j * 4096);
+    }
+  };
+  auto stage = [&](int buf, int st) {
+#pragma unroll
+    for (int i = 0; i < 2 * NI; ++i) stage_piece(buf, st, i);
+  };
+
+  const int wn = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int q = i16 >> 2, pp = i16 & 3;
+  // fragment b = 16 columns x 32 token rows: lane (g, i16) holds column i16, rows 8 g .. 8 g + 7 =
+  // two transposed 8-byte reads (rows 8g + q and 8g + 4 + q of the 4 x 16 block a lane group loads).
+  // Block b's offsets are block 0's with b XORed into chunk bits 1-3 (the swizzle is an XOR too).
+  uint32_t ta0[2], tb0[2];
+#pragma unroll
+  for (int hl = 0; hl < 2; ++hl) {
+    const int row = 8 * g + 4 * hl + q;
+    const uint32_t o = row * 256 + ((((pp >> 1)) ^ swz256(row)) << 4) + 8 * (pp & 1);
+    ta0[hl] = (uint32_t)wn * SUB_B + o;
+    tb0[hl] = (uint32_t)(2 + wk) * SUB_B + o;
+  }
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
+  float bsum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+  auto frag = [&](const char* base, const uint32_t(&t0)[2], int b) {
+    return tr_frag(base, t0[0] ^ (uint32_t)(b << 5), t0[1] ^ (uint32_t)(b << 5));
+  };
+  // piece j of a stage's 16 fragments: B 0-1, 2-3, 4-5, 6-7, then A 0-1 ... 6-7 (row 0 of the next
+  // stage needs every B fragment and A fragment 0)
+  auto read_piece = [&](const char* base, int j, bf16x8(&fa)[8], bf16x8(&fb)[8]) {
+    if (j < 4) {
+      fb[2 * j] = frag(base, tb0, 2 * j);
+      fb[2 * j + 1] = frag(base, tb0, 2 * j + 1);
+    } else {
+      fa[2 * j - 8] = frag(base, ta0, 2 * j - 8);
+      fa[2 * j - 7] = frag(base, ta0, 2 * j - 7);
+    }
+  };
+  auto mma_row = [&](int nb, const bf16x8(&fa)[8], const bf16x8(&fb)[8], auto bias_tag) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+      acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nb], fb[kb], acc[nb][kb], 0, 0, 0);
+    if constexpr (decltype(bias_tag)::value) {
+      const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
+        bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
+      }
+    }
+  };
+
+  const int nsteps = (rows + TM_ - 1) / TM_;
+#pragma unroll
+  for (int i = 0; i < STAGES; ++i)
+    if (i < nsteps) stage(i, i);
+  {
+    const int younger = min(STAGES, nsteps) - 1;
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) read_piece(lds, j, fa0, fb0);
+  auto main_loop = [&](auto bias_tag) {
+    int buf = 0;
+    // one stage = 8 rows of 8 MFMAs.  At its start: this wave's fragments of the stage have landed
+    // (lgkmcnt(0)), stage st+1 has landed (counted vmcnt), barrier -> every wave is done with the
+    // stage's buffer.  Each row then carries one LDS-DMA piece of stage st+STAGES (into that buffer)
+    // and two fragments of stage st+1 (into the other fragment set).
+    auto step = [&](int st, auto steady_tag, const bf16x8(&fa)[8], const bf16x8(&fb)[8], bf16x8(&na)[8], bf16x8(&nb_)[8]) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      const bool more = STEADY || st + 1 < nsteps;
+      const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+      if (more) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if constexpr (STEADY) {
+          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
+        } else {
+          const int younger = min(STAGES - 2, nsteps - 2 - st);
+          if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+          else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+      }
+      const char* nxt = lds + nbuf * STAGE_B;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (STEADY) stage_piece(buf, st + STAGES, j);
+        if (more) read_piece(nxt, j, na, nb_);
+        mma_row(j, fa, fb, bias_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      buf = nbuf;
+    };
+    const std::true_type T{};
+    const std::false_type F{};
+    int st = 0;
+    for (; st + STAGES + 1 < nsteps; st += 2) {
+      step(st, T, fa0, fb0, fa1, fb1);
+      step(st + 1, T, fa1, fb1, fa0, fb0);
+    }
+    if (st + STAGES < nsteps) {      // one more stage has a successor STAGES ahead: odd parity from here
+      step(st, T, fa0, fb0, fa1, fb1);
+      ++st;
+      for (; st < nsteps; st += 2) {
+        step(st, F, fa1, fb1, fa0, fb0);
+        if (st + 1 < nsteps) step(st + 1, F, fa0, fb0, fa1, fb1);
+      }
+    } else {
+      for (; st < nsteps; st += 2) {
+        step(st, F, fa0, fb0, fa1, fb1);
+        if (st + 1 < nsteps) step(st + 1, F, fa1, fb1, fa0, fb0);
+      }
+    }
+  };
+  if (do_bias) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+
+  // write-out.  Accumulator block (nb, kb), register r of lane (g, i16): dW[n0 + wn*128 + nb*16 + 4g + r][k0 + wk*128 + kb*16 + i16]
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int ge = lane_e >> 4, ie = lane_e & 15;
+  if (do_bias) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      float tot = bsum[nb] + __shfl_xor(bsum[nb], 16);
+      tot += __shfl_xor(tot, 32);
+      const int n = n0 + wn * 128 + nb * 16 + ie;
+      if (ge == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
+    }
+  }
+  if constexpr (SLAB) {
+    // float index (((wave*8 + nb)*8 + kb)*64 + lane)*4 + r: 1 KiB contiguous per wave instruction
+    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 16384 + lane_e * 4;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) *reinterpret_cast<f32x4*>(sl + (nb * 8 + kb) * 256) = acc[nb][kb];
+  } else {
+    const int nw = n0 + wn * 128 + 4 * ge, kw = k0 + wk * 128 + ie;
+    const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
+    float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
+    if (full) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* rowp = wbase + (int64_t)(nb * 16 + r) * p.ldw;
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
+        }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = nb * 16 + r;
+          float* rowp = wbase + (int64_t)nn * p.ldw;
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb)
+            if (nw + nn < p.N && kw + kb * 16 < p.K) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
+        }
+    }
+  }
+}
+
+// Sum of the M-splits' slabs of gemm_tn_q_kernel / gemm_tn_h_kernel into dW (+=), splits in ascending order: the
+// result does not depend on the order in which workgroups finished (bitwise reproducible, unlike
+// the atomic write-out).  One thread per 16-byte slab position = four rows n..n+3 of one column k;
+// a wave reads 1 KiB contiguous per split and updates 2 x 128-byte row segments per row.
+template <bool HLAYOUT>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
+  const int splits = grp.splits;
+  const int tile_lin = blockIdx.x >> 6;
+  GemmTnArgs p = grp.prob[0];
+  int pbase = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
+    if (i < grp.count && tile_lin * splits >= grp.base[i]) {
+      p = grp.prob[i];
+      pbase = grp.base[i];
+    }
+  const int nt = p.tiles_n * p.tiles_k;
+  const int t = tile_lin - pbase / splits;
+  int tn, tk;
+  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
+    tk = t / p.tiles_n;
+    tn = t - tk * p.tiles_n;
+  } else {
+    tn = t / p.tiles_k;
+    tk = t - tn * p.tiles_k;
+  }
+  const int e4 = (blockIdx.x & 63) * 256 + threadIdx.x;   // 16-byte position inside the tile's slab
+  const int lane = e4 & 63, wave = e4 >> 12;
+  const f32x4* src = reinterpret_cast<const f32x4*>(grp.slab) + ((int64_t)(pbase + t) * 16384 + e4);
+  const int64_t sstride = (int64_t)nt * 16384;
+  // rows_per_split covers M with `active` splits (the planner's count may leave trailing ones empty)
+  const int active = min(splits, (p.M + p.rows_per_split - 1) / p.rows_per_split);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int sidx = 0;
+  for (; sidx + 4 <= active; sidx += 4) {
+    const f32x4 a = src[(int64_t)sidx * sstride], b = src[(int64_t)(sidx + 1) * sstride];
+    const f32x4 c = src[(int64_t)(sidx + 2) * sstride], d = src[(int64_t)(sidx + 3) * sstride];
+    sum += a;
+    sum += b;
+    sum += c;
+    sum += d;
+  }
+  for (; sidx < active; ++sidx) sum += src[(int64_t)sidx * sstride];
+  int n, k;
+  if constexpr (HLAYOUT) {   // gemm_tn_h_kernel: e4 = ((wave*8 + nb)*8 + kb)*64 + lane, rows 4 (lane>>4) + j, column lane & 15
+    const int kb = (e4 >> 6) & 7, nb = (e4 >> 9) & 7;
+    n = tn * TN_ + (wave >> 1) * 128 + nb * 16 + 4 * (lane >> 4);
+    k = tk * 256 + (wave & 1) * 128 + kb * 16 + (lane & 15);
+  } else {                   // gemm_tn_q_kernel: e4 = (((wave*4 + nb)*4 + kb)*4 + i)*64 + lane
+    const int i = (e4 >> 6) & 3, kb = (e4 >> 8) & 3, nb = (e4 >> 10) & 3;
+    n = tn * TN_ + (wave >> 1) * 128 + nb * 32 + 8 * i + 4 * (lane >> 5);
+    k = tk * 256 + (wave & 1) * 128 + kb * 32 + (lane & 31);
+  }
+  if (k < p.K) {
+    float* o = p.dW + (int64_t)n * p.ldw + k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n + j < p.N) o[(int64_t)j * p.ldw] += sum[j];
   }
 }
 
@@ -593,14 +938,54 @@ int launch_tn(const GemmTnGroup& g, hipStream_t stream) {
   return MVPTR_OK;
 }
 
-template <int STAGES>
-int launch_tn_q(const GemmTnGroup& g, hipStream_t stream) {
+// Slab workspace of the "Q" write-out: one buffer per (device, stream), grown on demand and kept
+// for the life of the process.  Launches on one stream are ordered, so the next launch's slabs
+// overwrite the buffer only after the previous reduce kernel has read it; streams that run
+// concurrently (the text / visual stacks) get separate buffers.
+constexpr size_t TN_SLAB_MAX_BYTES = (size_t)1 << 30;
+float* tn_slab_workspace(hipStream_t stream, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& slot = pool[std::make_pair(dev, stream)];
+  if (slot.second >= bytes) return slot.first;
+  if (slot.first != nullptr) {
+    (void)hipFree(slot.first);   // waits for the work that may still read it
+    slot = std::make_pair((float*)nullptr, (size_t)0);
+  }
+  const size_t want = (bytes + ((size_t)32 << 20) - 1) & ~(((size_t)32 << 20) - 1);
+  void* ptr = nullptr;
+  if (hipMalloc(&ptr, want) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;               // caller falls back to the atomic write-out
+  }
+  slot = std::make_pair((float*)ptr, want);
+  return slot.first;
+}
+
+template <int STAGES, bool HSHAPE>
+int launch_tn_q(GemmTnGroup& g, hipStream_t stream) {
   const int lds_b = STAGES * 4 * 32 * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_q_kernel<STAGES>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
+  const void* k_atomic = HSHAPE ? (const void*)gemm_tn_h_kernel<STAGES, false> : (const void*)gemm_tn_q_kernel<STAGES, false>;
+  const void* k_slab = HSHAPE ? (const void*)gemm_tn_h_kernel<STAGES, true> : (const void*)gemm_tn_q_kernel<STAGES, true>;
+  for (const void* fn : {k_atomic, k_slab}) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+  }
+  g.slab = nullptr;
+  const size_t slab_bytes = (size_t)g.base[g.count] * 65536 * sizeof(float);
+  if (mvptr_knobs().tn_slab != 0 && g.splits >= 2 && slab_bytes <= TN_SLAB_MAX_BYTES)
+    g.slab = tn_slab_workspace(stream, slab_bytes);
+  void* kargs[] = {(void*)&g};
+  hipError_t le = hipLaunchKernel(g.slab == nullptr ? k_atomic : k_slab, dim3(g.base[g.count]), dim3(256), kargs, lds_b, stream);
+  if (le != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: launch: %s", hipGetErrorString(le));
   MVPTR_CHECK_LAUNCH("gemm_tn");
+  if (g.slab != nullptr) {
+    hipLaunchKernelGGL(tn_reduce_kernel<HSHAPE>, dim3((g.base[g.count] / g.splits) * 64), dim3(256), 0, stream, g);
+    MVPTR_CHECK_LAUNCH("gemm_tn reduce");
+  }
   return MVPTR_OK;
 }
 
@@ -612,7 +997,7 @@ struct TnPlan {
 // Estimated time of one configuration for `tiles` output tiles of one launch (all problems of a
 // group share M, so they share the split count): whole rounds of workgroups x steps per split,
 // plus the f32 atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
-TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false) {
+TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false, bool slab = false) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
   // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1; "Q": round 2)
   const double t64 = quad ? 1.5 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
@@ -621,7 +1006,11 @@ TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad 
   for (int sp = 1; sp <= 64 && sp <= max_splits; ++sp) {
     const double rounds = (double)((tiles * sp + slots - 1) / slots);
     const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
-    const double cost = rounds * steps * t64 + (double)sp * (double)out_elems * 4.0 / 1.3e6 * 0.7;
+    const double out_b = (double)out_elems * 4.0;
+    // write-out: f32 atomics (~1.3 TB/s chip-wide, partly overlapped), or plain slab stores
+    // (~6.5 TB/s) + the reduce kernel's reads of every slab (mostly L2 / MALL hits) + its launch
+    const double wr = (slab && sp >= 2) ? sp * out_b / 6.5e6 + (sp + 2) * out_b / 5.0e6 + 4.0 : sp * out_b / 1.3e6 * 0.7;
+    const double cost = rounds * steps * t64 + wr;
     if (cost < best.cost) {
       best.cost = cost;
       best.splits = sp;
@@ -654,14 +1043,14 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
       tiles += ((probs[i].N + TN_ - 1) / TN_) * ((probs[i].K + cfg_ks[c] * 128 - 1) / (cfg_ks[c] * 128));
       out_elems += (int64_t)probs[i].N * probs[i].K;
     }
-    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4);
+    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4, c == 4 && mvptr_knobs().tn_slab != 0);
   }
   // "Q" (256x256 tile, four waves of 128x128) wins from ~6 k token rows up (tools/sweep_tn.py,
   // tools/sweep_tn_group.py: 1.0-1.15 PF/s against 0.7-0.8 at M >= 19 k, +8 % at 11 k, -7 % at 3 k)
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
   if (M >= 6000) pick = 4;
   const char* env = mvptr_knobs().gemm_tn;
-  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q') ? 4 : 0;
+  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q' || env[0] == 'h' || env[0] == 'H') ? 4 : 0;
   TnPlan pl = plans[pick];
   if (mvptr_knobs().tn_splits > 0) pl.splits = min(mvptr_knobs().tn_splits, (M + 255) / 256);
   int rps = (M + pl.splits - 1) / pl.splits;
@@ -676,6 +1065,8 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
   const int splits = (M + rps - 1) / rps;
   GemmTnGroup g;
   g.count = count;
+  g.slab = nullptr;
+  g.splits = splits;
   g.base[0] = 0;
   for (int i = 0; i < count; ++i) {
     GemmTnArgs& a = g.prob[i];
@@ -703,7 +1094,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
-  if (pick == 4) return (mvptr_knobs().nt_exp & 64) ? launch_tn_q<5>(g, stream) : launch_tn_q<4>(g, stream);  // bit 6: 5-stage ring (160 KiB), A/B knob
+  if (pick == 4) return (env[0] == 'h' || env[0] == 'H') ? launch_tn_q<4, true>(g, stream) : launch_tn_q<4, false>(g, stream);
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
   if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);

@@ -284,6 +284,43 @@ def test_gemm_tn_multi(dev):
     hip.set_knob("MVPTR_GEMM_TN", "")
 
 
+def test_gemm_tn_slab_reduce(dev):
+    """'Q' write-out through per-split slabs + the reduce kernel: accumulates onto what dW holds, equals
+    the atomic write-out up to summation order, and is bitwise reproducible (fixed split order)."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(41)
+    M = 6400
+    shapes = [(2304, 768), (1000, 136), (768, 3072)]      # whole tiles, ragged edges, wide K
+    probs = []
+    for N, K in shapes:
+        probs.append((_bf(torch.randn(M, N, generator=g)).to(dev), _bf(torch.randn(M, K, generator=g)).to(dev), N, K))
+
+    def run(slab):
+        hip.set_knob("MVPTR_TN_SLAB", slab)
+        outs = []
+        try:
+            dws = [torch.full((N, K), 0.5, device=dev) for _, _, N, K in probs]
+            css = [torch.zeros(N, device=dev) for _, _, N, K in probs]
+            hip.gemm_tn_multi([(dy, x, dw, cs) for (dy, x, N, K), dw, cs in zip(probs, dws, css)])
+            outs = dws + css
+        finally:
+            hip.set_knob("MVPTR_TN_SLAB", "1")
+        return outs
+
+    hip.set_knob("MVPTR_GEMM_TN", "q")
+    try:
+        a1, a2, b = run("1"), run("1"), run("0")
+    finally:
+        hip.set_knob("MVPTR_GEMM_TN", "")
+    for (dy, x, N, K), s1, s2, at in zip(probs, a1[:3], a2[:3], b[:3]):
+        ref = 0.5 + dy.float().t() @ x.float()
+        assert torch.equal(s1, s2)
+        assert _rel(s1, ref) < 1e-4 and _rel(at, ref) < 1e-4
+        assert (s1 - at).abs().max() < 1e-3 * ref.abs().max()
+    for (dy, x, N, K), c1 in zip(probs, a1[3:]):
+        assert _rel(c1, dy.float().sum(0)) < 1e-4
+
+
 def test_gemm_tn_layout_exact(dev):
     from mvp_pytorch_amd import hip
     M, N, K = 64, 128, 128

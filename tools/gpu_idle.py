@@ -26,8 +26,17 @@ for s, e, _ in seg:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
 span = t1 - t0
-gaps = sorted(((seg[i + 1][0] - max(e for _, e, _ in seg[max(0, i - 8):i + 1])) for i in range(len(seg) - 1)), reverse=True)
+named = sorted(((seg[i + 1][0] - max(e for _, e, _ in seg[max(0, i - 8):i + 1]), seg[i][2][:60], seg[i + 1][2][:60])
+                for i in range(len(seg) - 1)), reverse=True)
+gaps = [g for g, _, _ in named]
 print("5 steps: span %.2f ms (%.2f ms/step), GPU busy %.2f ms = %.1f %%, idle %.2f ms/step, kernels/step %d, sum of kernel time %.2f ms/step"
       % (span / 1e6, span / 5e6, busy / 1e6, 100.0 * busy / span, (span - busy) / 5e6, len(seg) // 5,
          sum(e - s for s, e, _ in seg) / 5e6))
 print("largest gaps (us):", [round(g / 1e3, 1) for g in gaps[:12]])
+for g, a, b in named[:14]:
+    print("  %7.1f us  after %-60s before %s" % (g / 1e3, a, b))
+# context of the largest gap: the launches either side of it with their offsets from the gap's start
+big = max(range(len(seg) - 1), key=lambda i: seg[i + 1][0] - max(e for _, e, _ in seg[max(0, i - 8):i + 1]))
+ref = seg[big][1]
+for s, e, name in seg[max(0, big - 10):big + 14]:
+    print("  start %+9.1f us  dur %7.1f us  %s" % ((s - ref) / 1e3, (e - s) / 1e3, name[:110]))

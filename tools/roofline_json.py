@@ -28,16 +28,21 @@ def mix(Ms):
 
 
 res = {"_what": "gemm_tn_q_kernel<4> (grouped weight gradients, 36 launches per step), mean over the step's launch mix; "
-                "duration = rocprofv3 --kernel-trace --stats AverageNs of tools/prof_dominant.py; FLOPs = 2MNK summed over the "
+                "duration = rocprofv3 --kernel-trace --stats AverageNs of tools/prof_dominant.py, gemm_tn_q_kernel + the tn_reduce_kernel "
+                "that sums its per-split slabs (one launch = both); FLOPs = 2MNK summed over the "
                 "problems of a launch; algorithmic bytes = operands read once + f32 outputs accumulated once; peak = 2500 TFLOP/s "
                 "dense bf16 MFMA (MI355X_MICROARCH.md)",
        "peak_tflops": PEAK}
 rows_packed = tr.get("row_packed_batch", {}).get("rows_per_launch_group", [10917, 11143, 37748])
 for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
     us, calls = avg_us(path, "gemm_tn_q_kernel")
+    us_red, calls_red = avg_us(path, "tn_reduce_kernel")   # second kernel of the same launch (slab write-out)
+    if us and us_red:
+        us += us_red * calls_red / calls
     flop, alg = mix(Ms)
     t = tr.get(key, {}).get("gemm_tn_q_kernel", {})
-    res[key] = {"rows_per_launch_group": Ms, "avg_launch_us": us, "launches_profiled": calls, "flop_per_launch": flop,
+    res[key] = {"rows_per_launch_group": Ms, "avg_launch_us": us, "of_which_reduce_kernel_us": (us_red * calls_red / calls) if us_red else 0.0,
+                "launches_profiled": calls, "flop_per_launch": flop,
                 "achieved_tflops": flop / us / 1e6 if us else None, "frac_of_peak": flop / us / 1e6 / PEAK if us else None,
                 "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
                 "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}

@@ -47,6 +47,11 @@ for key, fd, wd in (("row_packed_batch", pf, pw), ("all_slots_valid", ff, fw)):
             continue
         fr = sum(f) / len(f) * 1024.0
         wr = sum(w) / len(w) * 1024.0
+        if frag == "gemm_tn_q_kernel":     # the reduce kernel over the per-split slabs belongs to the same launch
+            f2, w2 = pick(fa, "tn_reduce_kernel"), pick(wa, "tn_reduce_kernel")
+            if f2 and w2:
+                fr += sum(f2) / len(f) * 1024.0
+                wr += sum(w2) / len(w) * 1024.0
         ent[name] = {"fetch_size_raw_bytes": fr, "fetch_bytes_calibrated": fr / f_lds if f_lds > 0 else None,
                      "write_size_bytes": wr, "bytes_per_launch": round(fr / f_lds + wr) if f_lds > 0 else None,
                      "launches": len(f)}
