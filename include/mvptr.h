@@ -376,6 +376,12 @@ int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, float* sink
  * (8 x 128 B at the output row stride = the GEMM epilogues' shape); tools/store_probe.py. */
 int mvptr_diag_store_probe(void* dst, int64_t dst_bytes, int blocks, int64_t bytes_per_wave, int rows_per_instr,
                            int64_t stride, void* stream);
+/* Measurement helper: operand-fill rate.  `blocks` 256-thread workgroups each stream their wg_bytes region
+ * (all the same region when shared != 0) `reps` times in 32-KiB stages, three in flight — the GEMM
+ * kernels' staging pattern alone.  mode 0: buffer_load ... lds, mode 1: buffer_load to registers;
+ * the working-set size decides the level served from (L2 / Infinity Cache / HBM); tools/fill_probe.py. */
+int mvptr_diag_fill_probe(const void* src, int64_t src_bytes, int blocks, int64_t wg_bytes, int reps, int shared, int mode,
+                          float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,69 @@ __global__ __launch_bounds__(512) void store_probe_kernel(char* dst, int64_t byt
     *reinterpret_cast<u32x4*>(base + (i * rows_per_instr + r) * stride + c * 16) = v;
 }
 
+
+// Operand-fill probe: every workgroup (256 threads, one per CU when the grid is the CU count) streams
+// its `wg_bytes` region `reps` times in 32-KiB stages of 8 x 1 KiB per wave, three stages in flight
+// (the GEMM kernels' staging pattern without their MFMAs, LDS reads and barriers).  mode 0: LDS-DMA
+// (buffer_load_dwordx4 ... lds); mode 1: buffer_load_dwordx4 to registers.  shared != 0: all
+// workgroups read the same region.  The working set (wg_bytes x grid, or wg_bytes when shared)
+// decides whether the bytes come from L2, the Infinity Cache or HBM.
+__global__ __launch_bounds__(256, 1) void fill_probe_kernel(const char* src, int64_t wg_bytes, int reps, int shared, int mode, float* sink) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* base = src + (shared ? (int64_t)0 : (int64_t)blockIdx.x * wg_bytes);
+  const u32x4 rs = make_rsrc_words(base, (uint32_t)wg_bytes);
+  const uint32_t lds0 = lds_addr(dlds) + (uint32_t)wave * 1024u;
+  const int nst = (int)(wg_bytes >> 15);
+  const int total = nst * reps;
+  const uint32_t lane_off = (uint32_t)(wave * 1024 + lane * 16);
+  if (mode == 0) {
+    auto issue = [&](int s) {
+      const uint32_t so = (s < total) ? (uint32_t)(s % nst) << 15 : MVPTR_OOB;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t vo = (so == MVPTR_OOB) ? MVPTR_OOB : so + (uint32_t)i * 4096u + lane_off;
+        lds_dma16(rs, vo, lds0 + (uint32_t)((s & 3) * 32768 + i * 4096));
+      }
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+    for (int s = 0; s < total; ++s) {
+      issue(s + 3);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (reps < 0) *sink = *reinterpret_cast<const float*>(dlds + lane * 4);
+  } else {
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(base, (uint32_t)wg_bytes);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    u32x4 r[3][8];
+    auto issue = [&](int s, u32x4(&d)[8]) {
+      const uint32_t so = (s < total) ? (uint32_t)(s % nst) << 15 : MVPTR_OOB;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t vo = (so == MVPTR_OOB) ? MVPTR_OOB : so + (uint32_t)i * 4096u + lane_off;
+        d[i] = __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, 0, 0);
+      }
+    };
+    auto use = [&](u32x4(&d)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i & 3] += __builtin_bit_cast(float, d[i][i & 3]);
+    };
+    issue(0, r[0]);
+    issue(1, r[1]);
+    for (int s = 0; s < total; s += 3) {
+      issue(s + 2, r[2]);
+      use(r[0]);
+      issue(s + 3, r[0]);
+      use(r[1]);
+      issue(s + 4, r[1]);
+      use(r[2]);
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) *sink = acc[0];
+  }
+}
 }  // namespace
 
 extern "C" int mvptr_diag_store_probe(void* dst, int64_t dst_bytes, int blocks, int64_t bytes_per_wave, int rows_per_instr,
@@ -73,5 +136,19 @@ extern "C" int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, 
   if (((uintptr_t)src & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "diag_stream_read: src must be 16-byte aligned");
   hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 4096, (hipStream_t)stream, (const char*)src, bytes, mode, sink);
   MVPTR_CHECK_LAUNCH("diag_stream_read");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_diag_fill_probe(const void* src, int64_t src_bytes, int blocks, int64_t wg_bytes, int reps, int shared, int mode,
+                                     float* sink, void* stream) {
+  if (!src || !sink || blocks <= 0 || reps <= 0 || wg_bytes < 32768 || (wg_bytes & 32767) || wg_bytes >= ((int64_t)1 << 31))
+    MVPTR_FAIL(MVPTR_BAD_ARG, "diag_fill_probe: wg_bytes must be a multiple of 32 KiB below 2 GiB, blocks and reps > 0");
+  if ((shared ? wg_bytes : wg_bytes * blocks) > src_bytes) MVPTR_FAIL(MVPTR_BAD_ARG, "diag_fill_probe: source too small");
+  if (((uintptr_t)src & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "diag_fill_probe: src must be 16-byte aligned");
+  hipError_t e = hipFuncSetAttribute((const void*)fill_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "diag_fill_probe: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(fill_probe_kernel, dim3(blocks), dim3(256), 131072, (hipStream_t)stream, (const char*)src, wg_bytes, reps, shared,
+                     mode, sink);
+  MVPTR_CHECK_LAUNCH("diag_fill_probe");
   return MVPTR_OK;
 }

@@ -593,20 +593,23 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
 }
 
 
-// "H" configuration: the "Q" tile (256 x 256 per 256-thread workgroup, four waves of 128 x 128, 32
-// token rows per stage, STAGES-deep LDS-DMA ring) on v_mfma_f32_16x16x32_bf16: 8 x 8 blocks of
-// 16 x 16 per wave, one MFMA per block and 32-row stage.  LDS bytes, LDS instructions and cycles per
-// FLOP equal "Q"'s; what differs is that a 16x16x32 MFMA reads and writes a quarter of the
-// accumulator values of a 32x32x16 per instruction (half per FLOP), and the chip holds a higher
-// clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7).  The fragments of stage
-// st+1 are read during the MFMAs of stage st (two fragment sets, 128 registers), so a stage's
-// buffer is free — and refilled with stage st+STAGES — from the barrier at the START of its MFMAs.
+// "O" configuration (MVPTR_GEMM_TN=o): the "Q" tile (256 x 256 per workgroup, 32 token rows
+// per stage, STAGES-deep LDS-DMA ring) with EIGHT waves (two per SIMD) as 2(n) x 4(k), each 128 x 64 =
+// 8 x 4 blocks of v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  In-loop stamps of the
+// four-wave layouts (tools/clock_tn.py) read ~1 670 cycles per stage against the 1 024 the MFMAs
+// need: a lone wave per SIMD pays for each of its eight LDS-DMA issues (~80 cycles) with an idle
+// matrix pipe; with a partner wave on the SIMD the other's MFMAs run meanwhile (1 528 cycles here).
+// The chip gives most of that back as clock (1.99 -> 1.86 GHz in the loop, DVFS give-back item 3 of
+// MI355X_MICROARCH.md): "Q", a 16x16x32 four-wave build and this one land within 2-5 % of each
+// other in wall time — the loop is bounded by the power the MFMAs + operand traffic draw, not by
+// its issue schedule.  Fragment reads: one set of eight A fragments refreshed in place behind its
+// row, B fragments 0-1 double-buffered, 2-3 refreshed after the last row.
 template <int STAGES, bool SLAB>
-__global__ __launch_bounds__(256, 1) void gemm_tn_h_kernel(GemmTnGroup grp) {
+__global__ __launch_bounds__(512, 1) void gemm_tn_o_kernel(GemmTnGroup grp) {
   constexpr int TM_ = 32;
   constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
   constexpr int STAGE_B = 4 * SUB_B;   // A: 2 sub-tiles (256 n), B: 2 sub-tiles (256 k)
-  constexpr int NI = 4, LPS = 8;
+  constexpr int LPS = 4;               // LDS-DMA pieces per wave and stage: 2 for A, 2 for B
   constexpr int TKW = 256;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -647,77 +650,70 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_h_kernel(GemmTnGroup grp) {
       p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
   const uint32_t lds0 = lds_addr(lds);
 
-  uint32_t offA[NI], offB[NI];
+  // staging: wave w fills the 4-row group w of each of the four 32 x 128 sub-tiles (A0 A1 B0 B1)
+  uint32_t offA[2], offB[2];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = i * 4 + wave;
-    const int row = (j & 7) * 4 + (lane >> 4);
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 4 + (lane >> 4);
     const int ch = (lane & 15) ^ swz256(row);
-    const int col = (j >> 3) * 128 + ch * 8;
+    const int col = i * 128 + ch * 8;
     offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
     offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
   }
   const uint32_t stepA = (uint32_t)(TM_ * p.lda * 2), stepB = (uint32_t)(TM_ * p.ldb * 2);
-  auto stage_piece = [&](int buf, int st, int i) {
-    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
-    if (i < NI) {
-      const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)st * stepA;
-      lds_dma16(rsA, va, la + i * 4096);
-    } else {
-      const int j = i - NI;
-      const uint32_t vb = (offB[j] == MVPTR_OOB) ? MVPTR_OOB : offB[j] + (uint32_t)st * stepB;
-      lds_dma16(rsB, vb, la + 2 * SUB_B + j * 4096);
-    }
-  };
-  auto stage = [&](int buf, int st) {
-#pragma unroll
-    for (int i = 0; i < 2 * NI; ++i) stage_piece(buf, st, i);
+  auto stage_piece = [&](int buf, int st, int i) {   // i: 0,1 = A sub-tiles, 2,3 = B sub-tiles
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 4
+    return;
+#endif
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + i * SUB_B + wave * 1024);
+    // a lane whose column lies outside the tile holds MVPTR_OOB (2^31): adding a stage offset (the
+    // split's byte span is below 2^31) keeps it past the descriptor's range, no select needed
+    if (i < 2) lds_dma16(rsA, offA[i] + (uint32_t)st * stepA, la);
+    else lds_dma16(rsB, offB[i - 2] + (uint32_t)st * stepB, la);
   };
 
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave >> 2, wk = wave & 3;
   const int g = lane >> 4, i16 = lane & 15;
   const int q = i16 >> 2, pp = i16 & 3;
-  // fragment b = 16 columns x 32 token rows: lane (g, i16) holds column i16, rows 8 g .. 8 g + 7 =
-  // two transposed 8-byte reads (rows 8g + q and 8g + 4 + q of the 4 x 16 block a lane group loads).
-  // Block b's offsets are block 0's with b XORed into chunk bits 1-3 (the swizzle is an XOR too).
-  uint32_t ta0[2], tb0[2];
-#pragma unroll
-  for (int hl = 0; hl < 2; ++hl) {
-    const int row = 8 * g + 4 * hl + q;
-    const uint32_t o = row * 256 + ((((pp >> 1)) ^ swz256(row)) << 4) + 8 * (pp & 1);
-    ta0[hl] = (uint32_t)wn * SUB_B + o;
-    tb0[hl] = (uint32_t)(2 + wk) * SUB_B + o;
+  // offsets of the low read (rows 8g + q) of block 0; block b XORs b into chunk bits 1-3, and the high
+  // read (rows 8g + 4 + q: 1 KiB further, swizzle bit 0 set) is (low ^ 16) + 1024: every fragment
+  // address is one v_xad_u32 from these two registers
+  uint32_t ta0, tb0;
+  {
+    const int row = 8 * g + q;
+    const int sw = swz256(row);
+    ta0 = (uint32_t)wn * SUB_B + row * 256 + (((pp >> 1) ^ sw) << 4) + 8 * (pp & 1);
+    tb0 = (uint32_t)(2 + (wk >> 1)) * SUB_B + row * 256 + ((((wk & 1) * 8 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
   }
 
-  f32x4 acc[8][8];
+  f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
   float bsum[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
-  bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
-  auto frag = [&](const char* base, const uint32_t(&t0)[2], int b) {
-    return tr_frag(base, t0[0] ^ (uint32_t)(b << 5), t0[1] ^ (uint32_t)(b << 5));
+  // one A fragment set, refreshed in place (fragment j of the next stage is requested right after
+  // row j, its only user, has been issued).  Every row uses all four B fragments: 0-1 have two sets
+  // (the next stage's arrive during rows 0-1), 2-3 are refreshed in place after the last row — the
+  // next stage's first row starts on 0-1 while they land.
+  bf16x8 fa[8], fbl0[2], fbl1[2], fbh[2];
+  auto frag = [&](const char* base, uint32_t t0, int b) {
+    return tr_frag(base, t0 ^ (uint32_t)(b << 5), (t0 ^ (uint32_t)((b << 5) | 16)) + 1024u);
   };
-  // piece j of a stage's 16 fragments: B 0-1, 2-3, 4-5, 6-7, then A 0-1 ... 6-7 (row 0 of the next
-  // stage needs every B fragment and A fragment 0)
-  auto read_piece = [&](const char* base, int j, bf16x8(&fa)[8], bf16x8(&fb)[8]) {
-    if (j < 4) {
-      fb[2 * j] = frag(base, tb0, 2 * j);
-      fb[2 * j + 1] = frag(base, tb0, 2 * j + 1);
-    } else {
-      fa[2 * j - 8] = frag(base, ta0, 2 * j - 8);
-      fa[2 * j - 7] = frag(base, ta0, 2 * j - 7);
-    }
-  };
-  auto mma_row = [&](int nb, const bf16x8(&fa)[8], const bf16x8(&fb)[8], auto bias_tag) {
+  auto mma_row = [&](int nb, const bf16x8(&fbl)[2], auto bias_tag) {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-      acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nb], fb[kb], acc[nb][kb], 0, 0, 0);
+    for (int kb = 0; kb < 4; ++kb) {
+      const bf16x8& b = (kb < 2) ? fbl[kb] : fbh[kb - 2];
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 2
+      asm volatile("" ::"v"(fa[nb]), "v"(b));
+#else
+      acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nb], b, acc[nb][kb], 0, 0, 0);
+#endif
+    }
     if constexpr (decltype(bias_tag)::value) {
       const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
 #pragma unroll
@@ -728,75 +724,80 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_h_kernel(GemmTnGroup grp) {
     }
   };
 
+  // Uniform pipeline: every stage is issued, landed-checked and read the same way whether it exists
+  // or not.  A stage past the split's rows lies beyond the descriptors' ranges, so its LDS-DMA
+  // pieces fill the buffer with zeros without touching memory: the vmcnt counts are compile-time
+  // constants, the loop body has no run-time branch (one inside the MFMA sequence makes hipcc
+  // spill), and an odd stage count is padded with one all-zero stage.  At a stage's start: this
+  // wave's fragments have landed (lgkmcnt(0)), stage st+1 has landed (counted vmcnt), barrier ->
+  // every wave is done with the stage's buffer, which is refilled with stage st+STAGES.
   const int nsteps = (rows + TM_ - 1) / TM_;
 #pragma unroll
   for (int i = 0; i < STAGES; ++i)
-    if (i < nsteps) stage(i, i);
-  {
-    const int younger = min(STAGES, nsteps) - 1;
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(i, i, j);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * LPS) : "memory");
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    fbl0[j] = frag(lds, tb0, j);
+    fbh[j] = frag(lds, tb0, 2 + j);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) read_piece(lds, j, fa0, fb0);
+  for (int j = 0; j < 8; ++j) fa[j] = frag(lds, ta0, j);
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl_c0 = __builtin_amdgcn_s_memtime(), tl_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   auto main_loop = [&](auto bias_tag) {
     int buf = 0;
-    // one stage = 8 rows of 8 MFMAs.  At its start: this wave's fragments of the stage have landed
-    // (lgkmcnt(0)), stage st+1 has landed (counted vmcnt), barrier -> every wave is done with the
-    // stage's buffer.  Each row then carries one LDS-DMA piece of stage st+STAGES (into that buffer)
-    // and two fragments of stage st+1 (into the other fragment set).
-    auto step = [&](int st, auto steady_tag, const bf16x8(&fa)[8], const bf16x8(&fb)[8], bf16x8(&na)[8], bf16x8(&nb_)[8]) {
-      constexpr bool STEADY = decltype(steady_tag)::value;
-      const bool more = STEADY || st + 1 < nsteps;
+    auto step = [&](int st, const bf16x8(&fbl)[2], bf16x8(&nbl)[2]) {
       const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
-      if (more) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if constexpr (STEADY) {
-          asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
-        } else {
-          const int younger = min(STAGES - 2, nsteps - 2 - st);
-          if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
-          else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 6
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPS) : "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
+#endif
       const char* nxt = lds + nbuf * STAGE_B;
+      // opaque per stage: hipcc would otherwise hoist the 24 per-fragment offsets (base ^ block) out of
+      // the loop and spill them; computed in place each is one v_xad_u32 beside the MFMAs
+      asm volatile("" : "+v"(ta0), "+v"(tb0));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if constexpr (STEADY) stage_piece(buf, st + STAGES, j);
-        if (more) read_piece(nxt, j, na, nb_);
-        mma_row(j, fa, fb, bias_tag);
+        if ((j & 1) == 0) stage_piece(buf, st + STAGES, j >> 1);
+        if (j < 2) nbl[j] = frag(nxt, tb0, j);
+        mma_row(j, fbl, bias_tag);
+        fa[j] = frag(nxt, ta0, j);
+        if (j == 7) {
+          fbh[0] = frag(nxt, tb0, 2);
+          fbh[1] = frag(nxt, tb0, 3);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       buf = nbuf;
     };
-    const std::true_type T{};
-    const std::false_type F{};
-    int st = 0;
-    for (; st + STAGES + 1 < nsteps; st += 2) {
-      step(st, T, fa0, fb0, fa1, fb1);
-      step(st + 1, T, fa1, fb1, fa0, fb0);
-    }
-    if (st + STAGES < nsteps) {      // one more stage has a successor STAGES ahead: odd parity from here
-      step(st, T, fa0, fb0, fa1, fb1);
-      ++st;
-      for (; st < nsteps; st += 2) {
-        step(st, F, fa1, fb1, fa0, fb0);
-        if (st + 1 < nsteps) step(st + 1, F, fa0, fb0, fa1, fb1);
-      }
-    } else {
-      for (; st < nsteps; st += 2) {
-        step(st, F, fa0, fb0, fa1, fb1);
-        if (st + 1 < nsteps) step(st + 1, F, fa1, fb1, fa0, fb0);
-      }
+    for (int st = 0; st < nsteps; st += 2) {
+      step(st, fbl0, fbl1);
+      step(st + 1, fbl1, fbl0);
     }
   };
   if (do_bias) main_loop(std::true_type{});
   else main_loop(std::false_type{});
+#ifdef MVPTR_TIMELINE_BUILD
+  {
+    const unsigned long long tl_c1 = __builtin_amdgcn_s_memtime(), tl_r1 = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps != nullptr && tid == 0) {
+      unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+      o[0] = tl_r0;
+      o[1] = tl_r1;
+      o[2] = tl_c0;
+      o[3] = tl_c1;
+      o[4] = (unsigned long long)nsteps;
+    }
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // write-out.  Accumulator block (nb, kb), register r of lane (g, i16): dW[n0 + wn*128 + nb*16 + 4g + r][k0 + wk*128 + kb*16 + i16]
+  // write-out.  Block (nb, kb), register r of lane (g, i16): dW[n0 + wn*128 + nb*16 + 4g + r][k0 + wk*64 + kb*16 + i16]
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int ge = lane_e >> 4, ie = lane_e & 15;
@@ -810,45 +811,33 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_h_kernel(GemmTnGroup grp) {
     }
   }
   if constexpr (SLAB) {
-    // float index (((wave*8 + nb)*8 + kb)*64 + lane)*4 + r: 1 KiB contiguous per wave instruction
-    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 16384 + lane_e * 4;
+    // float index (((wave*8 + nb)*4 + kb)*64 + lane)*4 + r
+    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 8192 + lane_e * 4;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-      for (int kb = 0; kb < 8; ++kb) *reinterpret_cast<f32x4*>(sl + (nb * 8 + kb) * 256) = acc[nb][kb];
+      for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(sl + (nb * 4 + kb) * 256) = acc[nb][kb];
   } else {
-    const int nw = n0 + wn * 128 + 4 * ge, kw = k0 + wk * 128 + ie;
-    const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
+    const int nw = n0 + wn * 128 + 4 * ge, kw = k0 + wk * 64 + ie;
     float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
-    if (full) {
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb)
+    for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* rowp = wbase + (int64_t)(nb * 16 + r) * p.ldw;
+      for (int r = 0; r < 4; ++r) {
+        const int nn = nb * 16 + r;
+        float* rowp = wbase + (int64_t)nn * p.ldw;
 #pragma unroll
-          for (int kb = 0; kb < 8; ++kb) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
-        }
-    } else {
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nn = nb * 16 + r;
-          float* rowp = wbase + (int64_t)nn * p.ldw;
-#pragma unroll
-          for (int kb = 0; kb < 8; ++kb)
-            if (nw + nn < p.N && kw + kb * 16 < p.K) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
-        }
-    }
+        for (int kb = 0; kb < 4; ++kb)
+          if (nw + nn < p.N && kw + kb * 16 < p.K) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
+      }
   }
 }
 
-// Sum of the M-splits' slabs of gemm_tn_q_kernel / gemm_tn_h_kernel into dW (+=), splits in ascending order: the
+// Sum of the M-splits' slabs of gemm_tn_q_kernel / gemm_tn_o_kernel into dW (+=), splits in ascending order: the
 // result does not depend on the order in which workgroups finished (bitwise reproducible, unlike
 // the atomic write-out).  One thread per 16-byte slab position = four rows n..n+3 of one column k;
 // a wave reads 1 KiB contiguous per split and updates 2 x 128-byte row segments per row.
-template <bool HLAYOUT>
+template <int LAYOUT>   // 0: "Q", 2: "O"
 __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
   const int splits = grp.splits;
   const int tile_lin = blockIdx.x >> 6;
@@ -871,7 +860,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
     tk = t - tn * p.tiles_k;
   }
   const int e4 = (blockIdx.x & 63) * 256 + threadIdx.x;   // 16-byte position inside the tile's slab
-  const int lane = e4 & 63, wave = e4 >> 12;
+  const int lane = e4 & 63;
   const f32x4* src = reinterpret_cast<const f32x4*>(grp.slab) + ((int64_t)(pbase + t) * 16384 + e4);
   const int64_t sstride = (int64_t)nt * 16384;
   // rows_per_split covers M with `active` splits (the planner's count may leave trailing ones empty)
@@ -888,12 +877,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
   }
   for (; sidx < active; ++sidx) sum += src[(int64_t)sidx * sstride];
   int n, k;
-  if constexpr (HLAYOUT) {   // gemm_tn_h_kernel: e4 = ((wave*8 + nb)*8 + kb)*64 + lane, rows 4 (lane>>4) + j, column lane & 15
-    const int kb = (e4 >> 6) & 7, nb = (e4 >> 9) & 7;
-    n = tn * TN_ + (wave >> 1) * 128 + nb * 16 + 4 * (lane >> 4);
-    k = tk * 256 + (wave & 1) * 128 + kb * 16 + (lane & 15);
+  if constexpr (LAYOUT == 2) {   // gemm_tn_o_kernel: e4 = ((wave*8 + nb)*4 + kb)*64 + lane, eight waves 2(n) x 4(k)
+    const int kb = (e4 >> 6) & 3, nb = (e4 >> 8) & 7, wave = e4 >> 11;
+    n = tn * TN_ + (wave >> 2) * 128 + nb * 16 + 4 * (lane >> 4);
+    k = tk * 256 + (wave & 3) * 64 + kb * 16 + (lane & 15);
   } else {                   // gemm_tn_q_kernel: e4 = (((wave*4 + nb)*4 + kb)*4 + i)*64 + lane
-    const int i = (e4 >> 6) & 3, kb = (e4 >> 8) & 3, nb = (e4 >> 10) & 3;
+    const int i = (e4 >> 6) & 3, kb = (e4 >> 8) & 3, nb = (e4 >> 10) & 3, wave = e4 >> 12;
     n = tn * TN_ + (wave >> 1) * 128 + nb * 32 + 8 * i + 4 * (lane >> 5);
     k = tk * 256 + (wave & 1) * 128 + kb * 32 + (lane & 31);
   }
@@ -965,11 +954,11 @@ float* tn_slab_workspace(hipStream_t stream, size_t bytes) {
   return slot.first;
 }
 
-template <int STAGES, bool HSHAPE>
+template <int STAGES, int LAYOUT>
 int launch_tn_q(GemmTnGroup& g, hipStream_t stream) {
   const int lds_b = STAGES * 4 * 32 * 256;
-  const void* k_atomic = HSHAPE ? (const void*)gemm_tn_h_kernel<STAGES, false> : (const void*)gemm_tn_q_kernel<STAGES, false>;
-  const void* k_slab = HSHAPE ? (const void*)gemm_tn_h_kernel<STAGES, true> : (const void*)gemm_tn_q_kernel<STAGES, true>;
+  const void* k_atomic = LAYOUT == 2 ? (const void*)gemm_tn_o_kernel<STAGES, false> : (const void*)gemm_tn_q_kernel<STAGES, false>;
+  const void* k_slab = LAYOUT == 2 ? (const void*)gemm_tn_o_kernel<STAGES, true> : (const void*)gemm_tn_q_kernel<STAGES, true>;
   for (const void* fn : {k_atomic, k_slab}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
     if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
@@ -979,11 +968,11 @@ int launch_tn_q(GemmTnGroup& g, hipStream_t stream) {
   if (mvptr_knobs().tn_slab != 0 && g.splits >= 2 && slab_bytes <= TN_SLAB_MAX_BYTES)
     g.slab = tn_slab_workspace(stream, slab_bytes);
   void* kargs[] = {(void*)&g};
-  hipError_t le = hipLaunchKernel(g.slab == nullptr ? k_atomic : k_slab, dim3(g.base[g.count]), dim3(256), kargs, lds_b, stream);
+  hipError_t le = hipLaunchKernel(g.slab == nullptr ? k_atomic : k_slab, dim3(g.base[g.count]), dim3(LAYOUT == 2 ? 512 : 256), kargs, lds_b, stream);
   if (le != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: launch: %s", hipGetErrorString(le));
   MVPTR_CHECK_LAUNCH("gemm_tn");
   if (g.slab != nullptr) {
-    hipLaunchKernelGGL(tn_reduce_kernel<HSHAPE>, dim3((g.base[g.count] / g.splits) * 64), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(tn_reduce_kernel<LAYOUT>, dim3((g.base[g.count] / g.splits) * 64), dim3(256), 0, stream, g);
     MVPTR_CHECK_LAUNCH("gemm_tn reduce");
   }
   return MVPTR_OK;
@@ -1050,9 +1039,13 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
   if (M >= 6000) pick = 4;
   const char* env = mvptr_knobs().gemm_tn;
-  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q' || env[0] == 'h' || env[0] == 'H') ? 4 : 0;
+  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q' || env[0] == 'o' || env[0] == 'O') ? 4 : 0;
   TnPlan pl = plans[pick];
   if (mvptr_knobs().tn_splits > 0) pl.splits = min(mvptr_knobs().tn_splits, (M + 255) / 256);
+  // 256 x 256 tiles: "Q" (four waves, 32x32x16) unless MVPTR_GEMM_TN=o asks for "O" (eight waves, 16x16x32;
+  // within 2-5 % of "Q" on isolated launches, no difference on the training step: see its header)
+  const bool oshape = (pick == 4) && (env[0] == 'o' || env[0] == 'O');
+  if (oshape) pl.tm = 64;       // gemm_tn_o_kernel runs its stages in pairs
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
   // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)
@@ -1094,7 +1087,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
-  if (pick == 4) return (env[0] == 'h' || env[0] == 'H') ? launch_tn_q<4, true>(g, stream) : launch_tn_q<4, false>(g, stream);
+  if (pick == 4) return oshape ? launch_tn_q<4, 2>(g, stream) : launch_tn_q<4, 0>(g, stream);
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
   if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);

@@ -680,7 +680,7 @@ bool knob_assign(const char* name, const char* value) {
 bool knobs_from_env() {
   memset(&g_knobs, 0, sizeof(g_knobs));
   g_knobs.tn_group = 1;
-  g_knobs.tn_slab = 1;
+  g_knobs.tn_slab = 0;
   g_knobs.delay[1] = 256;
   g_knobs.delay[2] = 512;
   static const char* names[] = {"MVPTR_GEMM_CFG", "MVPTR_GEMM_TN", "MVPTR_NT_EXP", "MVPTR_TN_GROUP",

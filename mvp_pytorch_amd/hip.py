@@ -26,7 +26,7 @@ SYMBOLS = [
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
-    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe",
+    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe",
 ]
 
 
@@ -103,6 +103,7 @@ def load():
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
     lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
     lib.mvptr_diag_store_probe.argtypes = [P, I64, I, I64, I, I64, P]
+    lib.mvptr_diag_fill_probe.argtypes = [P, I64, I, I64, I, I, I, P, P]
     lib.mvptr_decoder_ce_fwd.argtypes = [P, I64, P, I64, P, P, I, I, I, P, P, P, P, P]
     lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
@@ -340,6 +341,12 @@ def diag_store_probe(buf, blocks, bytes_per_wave, rows_per_instr, stride):
     """Measurement helper: store-rate probe (see mvptr.h)."""
     _check(load().mvptr_diag_store_probe(_p(buf), buf.numel() * buf.element_size(), blocks, bytes_per_wave, rows_per_instr,
                                          stride, _stream()))
+
+
+def diag_fill_probe(buf, blocks, wg_bytes, reps, shared, mode, sink):
+    """Measurement helper: operand-fill probe (see mvptr.h)."""
+    _check(load().mvptr_diag_fill_probe(_p(buf), buf.numel() * buf.element_size(), blocks, wg_bytes, reps, int(shared), mode,
+                                        _p(sink), _stream()))
 
 
 def diag_stream_read(buf, mode, sink):

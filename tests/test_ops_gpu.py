@@ -229,7 +229,7 @@ def test_gemm_tn(dev, M, N, K):
     dy[:, :N] = _bf(torch.randn(M, N, generator=g))
     dy = dy.to(dev)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    for cfg in ("32", "64", "k2", "K", "q", None):  # every tile configuration + the planner's own choice
+    for cfg in ("32", "64", "k2", "K", "q", "o", None):  # every tile configuration + the planner's own choice
         if cfg is None:
             hip.set_knob("MVPTR_GEMM_TN", "")
         else:
@@ -267,7 +267,7 @@ def test_gemm_tn_multi(dev):
     dw5 = torch.zeros(104, 72, device=dev)
     probs.append((dy5, x5, dw5, None))
     refs.append(dy5.float().t() @ x5.float())
-    for cfg in ("32", "K", "q", None):
+    for cfg in ("32", "K", "q", "o", None):
         if cfg is None:
             hip.set_knob("MVPTR_GEMM_TN", "")
         else:
@@ -304,21 +304,22 @@ def test_gemm_tn_slab_reduce(dev):
             hip.gemm_tn_multi([(dy, x, dw, cs) for (dy, x, N, K), dw, cs in zip(probs, dws, css)])
             outs = dws + css
         finally:
-            hip.set_knob("MVPTR_TN_SLAB", "1")
+            hip.set_knob("MVPTR_TN_SLAB", "0")
         return outs
 
-    hip.set_knob("MVPTR_GEMM_TN", "q")
-    try:
-        a1, a2, b = run("1"), run("1"), run("0")
-    finally:
-        hip.set_knob("MVPTR_GEMM_TN", "")
-    for (dy, x, N, K), s1, s2, at in zip(probs, a1[:3], a2[:3], b[:3]):
-        ref = 0.5 + dy.float().t() @ x.float()
-        assert torch.equal(s1, s2)
-        assert _rel(s1, ref) < 1e-4 and _rel(at, ref) < 1e-4
-        assert (s1 - at).abs().max() < 1e-3 * ref.abs().max()
-    for (dy, x, N, K), c1 in zip(probs, a1[3:]):
-        assert _rel(c1, dy.float().sum(0)) < 1e-4
+    for cfg in ("q", "o"):
+        hip.set_knob("MVPTR_GEMM_TN", cfg)
+        try:
+            a1, a2, b = run("1"), run("1"), run("0")
+        finally:
+            hip.set_knob("MVPTR_GEMM_TN", "")
+        for (dy, x, N, K), s1, s2, at in zip(probs, a1[:3], a2[:3], b[:3]):
+            ref = 0.5 + dy.float().t() @ x.float()
+            assert torch.equal(s1, s2)
+            assert _rel(s1, ref) < 1e-4 and _rel(at, ref) < 1e-4
+            assert (s1 - at).abs().max() < 1e-3 * ref.abs().max()
+        for (dy, x, N, K), c1 in zip(probs, a1[3:]):
+            assert _rel(c1, dy.float().sum(0)) < 1e-4
 
 
 def test_gemm_tn_layout_exact(dev):

@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvp_pytorch_amd import hip  # noqa: E402
 
+if os.environ.get("MVPTR_TOOL_LIB"):     # ablation build (make -C mvp_pytorch_amd/csrc libmvptr_hip_exp4.so ...): speed only
+    hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), os.environ["MVPTR_TOOL_LIB"])
 dev = torch.device("cuda:0")
 CFGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto", "32", "q"]
 SPLITS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
