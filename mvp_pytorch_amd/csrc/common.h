@@ -46,6 +46,7 @@ struct MvptrKnobs {
   int tn_group;        // MVPTR_TN_GROUP   0: one launch per weight-gradient problem
   int ln_grid;         // MVPTR_LN_GRID    partial rows of the LayerNorm backward pass (0 = default)
   int tn_splits;       // MVPTR_TN_SPLITS  force the M-split count of the weight-gradient launches (0 = planner)
+  int nt_group[2];     // MVPTR_NT_GROUP   "gm[,gn]": tile order of gemm_nt (row tiles per group, column tiles per chunk; 0 = default)
   int tn_slab;         // MVPTR_TN_SLAB    1: per-split f32 slabs + reduce kernel (fixed summation order) instead of f32 atomics
   int delay[3];        // MVPTR_GEMM_DELAY "cycles[,lo,hi]"
   unsigned long long stamps;  // MVPTR_GEMM_STAMPS (diagnostic builds)

@@ -70,6 +70,7 @@ struct GemmNtArgs {
   float* vec_out;
   DropDev drop;
   int tiles_m, tiles_n;
+  int group_m, group_n;  // tile order: column tiles in chunks of group_n, inside a chunk group_m row tiles x the chunk's columns, row tile fastest
   int vec_out_ok;   // 16-byte stores allowed on out0/out1
   int vec_aux_ok;   // 16-byte loads allowed on aux
   int vec_bias_ok;  // 16-byte loads allowed on bias
@@ -368,14 +369,21 @@ void gemm_nt_kernel(GemmNtArgs p) {
     while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(16);
   }
   const int t = xcd_remap(blockIdx.x, nwg);
-  // grouped order: GROUP_M row-tiles x all column tiles, row-tile fastest
-  const int gsz = GROUP_M * p.tiles_n;
-  const int grp = t / gsz;
-  const int first_m = grp * GROUP_M;
-  const int gm = min(GROUP_M, p.tiles_m - first_m);
-  const int in_g = t - grp * gsz;
+  // order of the logical tiles (an XCD owns a contiguous run of them): column tiles in chunks of
+  // group_n; inside a chunk, groups of group_m row tiles x the chunk's columns, row tile fastest.
+  // A chunk narrower than the matrix keeps that part of B in the XCD's L2 while its rows stream by.
+  const int chunk_full = p.tiles_m * p.group_n;
+  const int chunk = t / chunk_full;
+  const int cn0 = chunk * p.group_n;
+  const int cn = min(p.group_n, p.tiles_n - cn0);
+  const int tc = t - chunk * chunk_full;
+  const int gsz = p.group_m * cn;
+  const int grp = tc / gsz;
+  const int first_m = grp * p.group_m;
+  const int gm = min(p.group_m, p.tiles_m - first_m);
+  const int in_g = tc - grp * gsz;
   const int tm = first_m + in_g % gm;
-  const int tn = in_g / gm;
+  const int tn = cn0 + in_g / gm;
   const int m0 = tm * BM, n0 = tn * BN;
   const int rows_a = min(BM, p.M - m0);
   const int rows_b = min(BN, p.N - n0);
@@ -1818,6 +1826,18 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
+  // Tile order (tools/sweep_nt_group.py, profiles/r02_experiments.txt): wide outputs are swept in
+  // chunks of 4 column tiles (3 for the GELU-backward epilogue, which also reads an M x N operand),
+  // groups of 4 row tiles (6 for the two-output GELU epilogue) inside a chunk.  Against whole-width
+  // groups: FFN1 forward 283 -> 228 us at M = 37 748 (-19 %), -6...-12 % at the other row counts,
+  // Q/K/V projection -13 % at M = 64 000, the rest within 2 %.  MVPTR_NT_GROUP=gm,gn overrides.
+  constexpr bool kEncoderEpi = (EPI <= MVPTR_EPI_GELU_BWD);     // bias / gelu / residual / gelu-backward: the measured shapes
+  const bool chunked = kEncoderEpi && C::BN == 256 && a.tiles_n > 4;
+  a.group_m = (EPI == MVPTR_EPI_BIAS_GELU && chunked) ? 6 : GROUP_M;
+  a.group_n = chunked ? ((EPI == MVPTR_EPI_GELU_BWD) ? 3 : 4) : a.tiles_n;
+  if (mvptr_knobs().nt_group[0] > 0) a.group_m = mvptr_knobs().nt_group[0];
+  if (mvptr_knobs().nt_group[1] > 0) a.group_n = min(mvptr_knobs().nt_group[1], a.tiles_n);
+  if (mvptr_knobs().nt_group[0] > 0 && mvptr_knobs().nt_group[1] <= 0) a.group_n = a.tiles_n;   // "gm" or "gm,0": whole width
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, SCHED>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;

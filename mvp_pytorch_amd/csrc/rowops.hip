@@ -670,6 +670,10 @@ bool knob_assign(const char* name, const char* value) {
   else if (!strcmp(name, "MVPTR_LN_GRID")) g_knobs.ln_grid = atoi(v);
   else if (!strcmp(name, "MVPTR_TN_SPLITS")) g_knobs.tn_splits = atoi(v);
   else if (!strcmp(name, "MVPTR_TN_SLAB")) g_knobs.tn_slab = atoi(v);
+  else if (!strcmp(name, "MVPTR_NT_GROUP")) {
+    g_knobs.nt_group[0] = g_knobs.nt_group[1] = 0;
+    sscanf(v, "%d,%d", &g_knobs.nt_group[0], &g_knobs.nt_group[1]);
+  }
   else if (!strcmp(name, "MVPTR_GEMM_DELAY")) {
     g_knobs.delay[0] = 0; g_knobs.delay[1] = 256; g_knobs.delay[2] = 512;
     sscanf(v, "%d,%d,%d", &g_knobs.delay[0], &g_knobs.delay[1], &g_knobs.delay[2]);
@@ -685,7 +689,7 @@ bool knobs_from_env() {
   g_knobs.delay[2] = 512;
   static const char* names[] = {"MVPTR_GEMM_CFG", "MVPTR_GEMM_TN", "MVPTR_NT_EXP", "MVPTR_TN_GROUP",
                                 "MVPTR_LN_GRID", "MVPTR_GEMM_DELAY", "MVPTR_GEMM_STAMPS", "MVPTR_TN_SPLITS",
-                                "MVPTR_TN_SLAB"};
+                                "MVPTR_TN_SLAB", "MVPTR_NT_GROUP"};
   for (const char* n : names) {
     const char* v = getenv(n);
     if (v != nullptr && v[0] != 0) {
