@@ -4,3 +4,4 @@ Host side mirrors the reference's `oscar.modeling.*` class surface (see mvp_pyto
 the encoder itself is hand-written HIP in csrc/ behind the C ABI of include/mvptr.h.
 """
 __version__ = "0.1.0"
+

@@ -15,7 +15,7 @@ Functions
                                                                 modeling_vlbert.py:1228-1249
 """
 import ctypes
-
+import os
 import threading
 
 import torch
@@ -301,6 +301,36 @@ def side_stream(device):
         if key not in SIDE_STREAMS:
             SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
         return SIDE_STREAMS[key]
+
+
+class small_f32_blas:
+    """Scope in which torch's matrix products go to rocBLAS.  hipBLASLt, torch's default BLAS on this ROCm
+    build, serves the step's [256, 768] x [768, 256] f32 global projections and the 256 x 256
+    similarity matrix with ONE 256 x 256 tile = one workgroup (173 us and 63 us; rocBLAS: 7 and 8 us,
+    tools/small_mm.py).  The switch is process-wide in torch, so the scope is reference-counted under
+    the module lock: the previous setting comes back when the last concurrent user (nn.DataParallel
+    replicas run their forward passes in threads) leaves.  MVPTR_KEEP_BLAS=1 disables it."""
+    _depth = 0
+    _saved = None
+
+    def __enter__(self):
+        if os.environ.get("MVPTR_KEEP_BLAS") == "1" or not getattr(torch.version, "hip", None):
+            return self
+        with _state_lock:
+            if small_f32_blas._depth == 0:
+                small_f32_blas._saved = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library("cublas")      # = rocBLAS on ROCm
+            small_f32_blas._depth += 1
+        self._entered = True
+        return self
+
+    def __exit__(self, *exc):
+        if getattr(self, "_entered", False):
+            with _state_lock:
+                small_f32_blas._depth -= 1
+                if small_f32_blas._depth == 0:
+                    torch.backends.cuda.preferred_blas_library(small_f32_blas._saved)
+        return False
 
 
 class AsyncCounts:

@@ -55,15 +55,19 @@ def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
 
 
 def _streams_allowed(setting):
-    """Two-stream execution of the uni-modal stacks is validated on one GPU (and, functionally, with
-    two gloo ranks sharing one: tests/test_dp_gpu.py); with gloo the bucketed gradient exchange
-    slows down badly beside a side stream (tools/dp_gloo_check.py), and there was no multi-GPU box
-    to measure the same thing under RCCL, so multi-rank jobs keep one stream unless the config says
-    parallel_stacks = "always"."""
+    """Two-stream execution of the uni-modal stacks: on one GPU always; in a multi-rank job under RCCL
+    (backend "nccl") too — the collectives run on RCCL's own stream whatever the compute streams do,
+    and mvp_pytorch_amd.dp.GradSync makes a bucket wait for every stream that produced one of its
+    gradients before it is handed over (exercised with two ranks in tests/test_dp_gpu.py).  With gloo
+    the bucketed exchange slows down badly beside a side stream (host-side copies that synchronise
+    the device, tools/dp_gloo_check.py), so gloo jobs keep one stream unless the config says
+    parallel_stacks = "always".  No multi-GPU box was available to time the RCCL case."""
     if setting == "always":
         return True
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return True
+    return dist.get_backend() == "nccl"
 
 
 def additive_mask(attention_mask):
@@ -285,8 +289,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
 
     def _globals(self, txt, vis):
         """vl:525-526 — f32 (feeds argmax: kept out of bf16)."""
-        gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
-        gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
+        with engine.small_f32_blas():
+            gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
+            gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
         return gt, gi
 
     def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
@@ -303,7 +308,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         only_vis = vis[:, cut:, :]
         only_vis_mask = mask_b[:, cut:]
         global_txt, global_img = self._globals(txt, vis)
-        sim_mat = global_txt @ global_img.t()
+        with engine.small_f32_blas():
+            sim_mat = global_txt @ global_img.t()
 
         hard_out = hard_pooled = hard_txt_full = hard_img_full = None
         if encode_hn:
@@ -398,7 +404,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
         with self._packed_stacks(self, packed):
             txt = self.txt_encoder(xa, mask_a)[0]
-        glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
+        with engine.small_f32_blas():
+            glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
         return dict(seq=txt, mask=mask_a, glob=glob)
 
     @torch.no_grad()
@@ -415,7 +422,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         with self._packed_stacks(self, packed):
             vis = self.vis_encoder(xb, mask_b)[0]
         cut = 1 if use_b else max_tag_length
-        glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
+        with engine.small_f32_blas():
+            glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
         return dict(seq=vis[:, cut:, :].contiguous(), mask=mask_b[:, cut:].contiguous(), glob=glob)
 
     @torch.no_grad()
@@ -850,7 +858,8 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
     def coarse_scores(self, text, image):
         """[n_text, n_image] cosine similarities of the global embeddings (forward_mod 'coarse' +
         the matrix product of run_retrieval.py:741-745)."""
-        return text["glob"] @ image["glob"].t()
+        with engine.small_f32_blas():
+            return text["glob"] @ image["glob"].t()
 
     @torch.no_grad()
     def rerank(self, text, image, txt_idx, img_idx, chunk=4096, packed=True):
