@@ -277,8 +277,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const LaneOffs lo_ = make_lane_offs(lane);
   __bf16* dq_base = p.dqkv + row0 * ldq + hd * 64;
 
-  // ---------------- pass A: waves own key blocks; key on lane, query in registers
-  for (int kb = wave; kb < nb; kb += 4) {
+  // 2 nb independent tasks dealt to the four waves: task t < nb is "pass A" for key block t, task
+  // t >= nb is "pass B" for query block t - nb.  One list instead of two loops keeps all four waves busy
+  // on the short sequences of this path: with nb = 1 or 2 (L <= 64) the two passes take one round of the
+  // waves instead of two, with nb = 5 three instead of four.
+  for (int task = wave; task < 2 * nb; task += 4) {
+  if (task < nb) {
+    // ---------------- pass A: the wave owns a key block; key on lane, query in registers
+    const int kb = task;
     const int key = 32 * kb + l31;
     const float mk = maskv[key];
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
@@ -352,10 +358,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
           *reinterpret_cast<bf16x4*>(dV + d) = c;
         }
     }
-  }
-
-  // ---------------- pass B: waves own query blocks; query on lane, key in registers
-  for (int qb = wave; qb < nb; qb += 4) {
+  } else {
+    // ---------------- pass B: the wave owns a query block; query on lane, key in registers
+    const int qb = task - nb;
     const int q = 32 * qb + l31;
     const float ls = lsev[q], dl = deltav[q];
     f32x16 dq[2] = {zero16(), zero16()};
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
           *reinterpret_cast<bf16x4*>(dQ + 32 * db + 8 * t4 + 4 * hh) = a;
         }
     }
+  }
   }
 }
 
