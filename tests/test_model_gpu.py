@@ -808,6 +808,83 @@ def test_configs1_shape_full_batch(dev):
     assert worst[0] < 3e-2
 
 
+def test_configs3_retrieval_scale(dev):
+    """BASELINE configs[3] at its size: 1 000 images x 5 captions (COCO-1k shape, README retrieval lengths
+    50 tok + 5 phrases / 30 tags / 50 regions), BERT-base, random init.  Two-stage engine: encode every caption
+    and image once, coarse ranks on the device, re-rank the top-8 images of every caption (40 000 pairs,
+    row-packed).  Size-independent properties: coarse ranks == an independent numpy argsort walk of the same
+    similarity matrix; on a sample of pairs the padded cached re-rank equals forward_mod='fine' bit for bit and the
+    row-packed one to bf16 rounding; second-stage ranks are well-formed; everything finite."""
+    from mvp_pytorch_amd import modeling, retrieval_eval
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    n_img, c, topk = 1000, 5, 8
+    dims = dict(B=n_img * c, T=50, P=5, G=30, R=50)
+    cfg = dict(gu.BASE_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, loss_type="ce", num_labels=2)
+    torch.manual_seed(3)
+    model = modeling.BiImageBertForRetrieval(modeling.make_config(cfg)).to(dev).eval()
+    b = synthetic_batch(dims, cfg, 31, device=dev)
+    n_cap = dims["B"]
+    img_rows = torch.arange(0, n_cap, c, device=dev)       # caption j describes image j // c; one copy of every image
+
+    def encode(packed):
+        text = {k: [] for k in ("seq", "mask", "glob")}
+        for s0 in range(0, n_cap, 1000):
+            sl = slice(s0, s0 + 1000)
+            t = model.encode_text(input_ids_a=b["input_ids_a"][sl], token_type_ids_a=b["segment_ids_a"][sl],
+                                  attention_mask_a=b["input_mask_a"][sl], packed=packed)
+            for k in text:
+                text[k].append(t[k])
+        text = {k: torch.cat(v) for k, v in text.items()}
+        image = model.encode_image(input_ids_b=b["input_ids_b"][img_rows], img_feats=b["img_feats"][img_rows],
+                                   token_type_ids_b=b["segment_ids_b"][img_rows], attention_mask_b=b["input_mask_b"][img_rows],
+                                   max_tag_length=dims["G"], packed=packed)
+        return text, image
+
+    text, image = encode(True)
+    sim_ti = model.coarse_scores(text, image)                # [n_cap, n_img]
+    assert sim_ti.shape == (n_cap, n_img) and bool(torch.isfinite(sim_ti).all())
+    sim = sim_ti.t().contiguous()                            # run_retrieval.py layout: [n_img, n_cap]
+    out = retrieval_eval.coarse_ranks(sim, c, 20, topk)
+    s_np = sim.cpu().numpy()
+    order_t2i = np.argsort(-s_np, axis=0, kind="stable")     # independent check: full argsort walk
+    pos = np.empty_like(order_t2i)
+    np.put_along_axis(pos, order_t2i, np.arange(n_img)[:, None], axis=0)
+    gt_img = np.arange(n_cap) // c
+    ties = (np.sort(s_np, axis=0)[1:] == np.sort(s_np, axis=0)[:-1]).any()
+    if not ties:
+        assert np.array_equal(out["t2i_ranks"].cpu().numpy(), pos[gt_img, np.arange(n_cap)])
+        assert np.array_equal(out["t2i_topk"].cpu().numpy(), order_t2i[:topk].T)
+    cand = out["t2i_topk"]                                   # [n_cap, topk] images to re-rank per caption
+    ti = torch.arange(n_cap, device=dev).repeat_interleave(topk)
+    ii = cand.reshape(-1)
+    scores = model.rerank(text, image, ti, ii, chunk=4096)   # row-packed (default)
+    assert scores.shape == (n_cap * topk, 2) and bool(torch.isfinite(scores.float()).all())
+    p_match = torch.softmax(scores.float(), -1)[:, 1].view(n_cap, topk)
+    gt_mask = cand == torch.from_numpy(gt_img).to(dev)[:, None]
+    rr = retrieval_eval.rerank_ranks(p_match, cand, gt_mask)
+    assert int(rr.min()) >= 0 and int(rr.max()) <= topk
+    assert bool((rr[~gt_mask.any(1)] == topk).all())
+    # a sample of pairs against the reference evaluation's per-pair forward pass
+    g = torch.Generator().manual_seed(9)
+    pick = torch.randperm(n_cap * topk, generator=g)[:384].to(dev)
+    t_s, i_s = ti[pick], ii[pick]
+    text_pad, image_pad = encode(False)
+    got_pad = model.rerank(text_pad, image_pad, t_s, i_s, chunk=384, packed=False)      # same batch as the per-pair pass below
+    got_ragged = model.rerank(text_pad, image_pad, t_s, i_s, chunk=100, packed=False)   # other batch sizes: torch's f32 heads may
+                                                                                         # pick other GEMM kernels (last-bit differences)
+    model.forward_mod = "fine"
+    r = img_rows[i_s]
+    with torch.no_grad():
+        ref = model(input_ids_a=b["input_ids_a"][t_s], token_type_ids_a=b["segment_ids_a"][t_s], attention_mask_a=b["input_mask_a"][t_s],
+                    input_ids_b=b["input_ids_b"][r], token_type_ids_b=b["segment_ids_b"][r], attention_mask_b=b["input_mask_b"][r],
+                    img_feats=b["img_feats"][r], max_tag_length=dims["G"])
+    assert torch.equal(got_pad, ref)
+    assert (got_ragged.float() - ref.float()).abs().max().item() < 1e-5
+    dp = (torch.softmax(scores[pick].float(), -1)[:, 1] - torch.softmax(ref.float(), -1)[:, 1]).abs().max().item()
+    print("configs[3]: %d pairs re-ranked; row-packed vs per-pair 'fine' max |delta p(match)| = %.2e" % (n_cap * topk, dp))
+    assert dp < 2e-2
+
+
 def test_configs4_vqa_shape_vs_oracle(dev):
     """BASELINE configs[4] shapes (run_vqa.py README: max_seq_length 128 + 5 phrases -> La = 133, 30 tag
     slots + 50 regions -> Lb = 80, no max_tag_length forwarded -> joint length 133 + 60 = 193; 3129-way
