@@ -59,3 +59,32 @@ for ev in evs:
 print("wall %.2f ms/step; GPU time between the host-side phase boundaries: forward %.2f, backward %.2f, optimizer %.2f ms "
       "(the fused AdamW kernels take 1.23 ms in the kernel summary: what exceeds that is the GPU waiting for the host)"
       % (wall, acc[0], acc[1], acc[2]))
+
+# GPU-side bubble at each awaited count (engine.AsyncCounts.get): an event queued just before the host blocks and
+# one queued the moment it returns; between them the GPU has nothing but what was queued earlier
+from mvp_pytorch_amd import engine  # noqa: E402
+orig_get = engine.AsyncCounts.get
+bubbles = []
+
+
+def timed_get(self):
+    a, c = E(), E()
+    a.record()
+    h0 = time.perf_counter()
+    out = orig_get(self)
+    h1 = time.perf_counter()
+    c.record()
+    bubbles.append((a, c, (h1 - h0) * 1e3))
+    return out
+
+
+engine.AsyncCounts.get = timed_get
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+engine.AsyncCounts.get = orig_get
+per_step = len(bubbles) // 5
+for k in range(per_step):
+    g = sum(bubbles[i * per_step + k][0].elapsed_time(bubbles[i * per_step + k][1]) for i in range(5)) / 5
+    h = sum(bubbles[i * per_step + k][2] for i in range(5)) / 5
+    print("awaited count %d of a step: host blocked %.3f ms; GPU between 'queued before the wait' and 'host returned' %.3f ms" % (k, h, g))
