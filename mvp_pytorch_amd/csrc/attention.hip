@@ -30,6 +30,7 @@ struct AttnArgs {
   const int* seq_start;     // packed mode: first row of sequence b in the row-packed buffers
   const int* seq_len;       //              its length (<= L); NULL => dense [B, L] layout
   DropDev drop;
+  unsigned long long* stamps;  // -DMVPTR_TIMELINE_BUILD only (MVPTR_GEMM_STAMPS): per-workgroup phase times
 };
 
 // swizzle of the 8 16-byte chunks of a 128-B tile row
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
   const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
   if (L <= 0) return;
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int64_t row0 = (p.seq_start != nullptr) ? (int64_t)p.seq_start[b] : (int64_t)b * LT;
   const int Lp = (L + 31) & ~31;
   const int64_t ldq = 3 * (int64_t)H;
@@ -276,6 +280,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int nb = Lp >> 5;
   const LaneOffs lo_ = make_lane_offs(lane);
   __bf16* dq_base = p.dqkv + row0 * ldq + hd * 64;
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // 2 nb independent tasks dealt to the four waves: task t < nb is "pass A" for key block t, task
   // t >= nb is "pass B" for query block t - nb.  One list instead of two loops keeps all four waves busy
@@ -409,6 +416,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
     }
   }
   }
+#ifdef MVPTR_TIMELINE_BUILD
+  {
+    // diagnostic build: 100-MHz ticks at entry / after the staging barrier / when this wave is done (wave 0 and
+    // the slowest wave by atomicMax) -> prologue and task-loop times per workgroup; a buffer of its own
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps != nullptr && lane == 0) {
+      unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+      if (wave == 0) {
+        o[0] = tl0;
+        o[1] = tl1;
+        o[3] = (unsigned long long)L;
+      }
+      atomicMax(o + 2, tl2);
+    }
+  }
+#endif
 }
 
 int check_common(const char* who, const void* qkv, int B, int L, int heads) {
@@ -479,6 +503,10 @@ extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add
   a.seq_start = seq_start;
   a.seq_len = seq_len;
   a.drop = make_dropdev(drop);
+  a.stamps = nullptr;
+#ifdef MVPTR_TIMELINE_BUILD
+  a.stamps = (unsigned long long*)mvptr_knobs().stamps;
+#endif
   const size_t lds = (size_t)a.Lp * 128 * 4 + (size_t)a.Lp * 12;
   hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_bwd: set LDS size: %s", hipGetErrorString(e));
