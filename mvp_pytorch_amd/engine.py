@@ -346,10 +346,12 @@ class AsyncCounts:
         if not t.is_cuda:
             self._host, self._event = t, None
             return
-        key = (t.device.index, t.numel(), threading.get_ident())
+        # one small ring of pinned buffers per (device, count): a device is driven by one thread at a time (its
+        # nn.DataParallel replica), and those threads are new ones in every forward pass, so the thread is not part of the key
+        key = (t.device.index, t.numel())
         with _state_lock:
-            bufs = AsyncCounts._pins.setdefault(key, [torch.empty(t.numel(), dtype=torch.int64).pin_memory() for _ in range(4)])
-            bufs.append(bufs.pop(0))       # rotate: a buffer is reused four requests later at the earliest
+            bufs = AsyncCounts._pins.setdefault(key, [torch.empty(t.numel(), dtype=torch.int64).pin_memory() for _ in range(8)])
+            bufs.append(bufs.pop(0))       # rotate: a buffer is reused eight requests later at the earliest
             self._host = bufs[-1]
         self._host.copy_(t, non_blocking=True)
         self._event = torch.cuda.Event()
