@@ -368,7 +368,8 @@ void gemm_nt_kernel(GemmNtArgs p) {
     const long long t0 = __builtin_readcyclecounter();
     while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(16);
   }
-  const int t = xcd_remap(blockIdx.x, nwg);
+  // MVPTR_NT_EXP bit 14 (A/B knob): no XCD remap — consecutive logical tiles go to consecutive XCDs
+  const int t = (p.exp_flags & 16384) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
   // order of the logical tiles (an XCD owns a contiguous run of them): column tiles in chunks of
   // group_n; inside a chunk, groups of group_m row tiles x the chunk's columns, row tile fastest.
   // A chunk narrower than the matrix keeps that part of B in the XCD's L2 while its rows stream by.

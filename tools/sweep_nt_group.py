@@ -41,6 +41,10 @@ for name, N, K, epi in SHAPES:
     vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
     line = "M=%d %-12s N=%4d K=%4d" % (M, name, N, K)
     for o in ORDERS:
+        exp = "0"
+        if o.endswith("x"):          # "gm,gnx": without the XCD remap (MVPTR_NT_EXP bit 14)
+            o, exp = o[:-1], "16384"
+        hip.set_knob("MVPTR_NT_EXP", exp)
         hip.set_knob("MVPTR_NT_GROUP", o)
         fn = lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec)  # noqa: E731
         if PMC:
@@ -48,6 +52,7 @@ for name, N, K, epi in SHAPES:
             torch.cuda.synchronize()
             continue
         us = min(timeit(fn) for _ in range(3))
-        line += "  [%s] %6.1f us %4.0f TF" % (o, us, 2.0 * M * N * K / us / 1e6)
+        line += "  [%s%s] %6.1f us %4.0f TF" % (o, "x" if exp != "0" else "", us, 2.0 * M * N * K / us / 1e6)
     print(line, flush=True)
 hip.set_knob("MVPTR_NT_GROUP", "0,0")
+hip.set_knob("MVPTR_NT_EXP", "0")
