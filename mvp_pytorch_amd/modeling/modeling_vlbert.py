@@ -12,6 +12,7 @@ tuples, state_dict keys and config attributes follow the reference; encoder acti
 bf16 tensors, pooled outputs / logits / losses are f32.
 """
 import copy
+import os
 import logging
 import math
 import random
@@ -298,7 +299,11 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                 use_b=False, position_ids_a=None, input_ids_b=None, token_type_ids_b=None,
                 attention_mask_b=None, phrase_layer=None, position_ids_b=None, head_mask=None,
                 img_feats=None, encoder_history_states=None, encode_hn=False, hn_mod="hard", logit=None,
-                pack_hints=None):
+                pack_hints=None, beside=None):
+        """beside: optional callable(txt, vis, sim_mat) with work that only needs the uni-modal outputs (the visual
+        MLM head and the contrastive loss of the pre-training model).  It is queued on the side stream before the
+        joint stack, so its small kernels — and, in the backward pass, their gradients — run beside the joint
+        stack's GEMMs instead of after them; the caller waits for engine.side_stream before using its results."""
         if head_mask is not None or encoder_history_states or phrase_layer is not None:
             raise NotImplementedError("head_mask / encoder_history_states / phrase_layer are outside the accelerated path")
         txt, vis, mask_a, mask_b = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
@@ -334,6 +339,17 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             both_mask = torch.cat([joint_mask, hard_mask], 0)
             lens = (both_mask == 0).sum(1)
             cnt = engine.AsyncCounts([lens.sum(), lens.max()])
+        if beside is not None:
+            if txt.is_cuda and self.parallel_stacks and _streams_allowed(self.parallel_stacks):
+                main = torch.cuda.current_stream(txt.device)
+                side = engine.side_stream(txt.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    beside(txt, vis, sim_mat)
+                for t in (txt, vis, sim_mat):
+                    t.record_stream(side)      # produced on the main stream, read on the side stream
+            else:
+                beside(txt, vis, sim_mat)
         if encode_hn:
             hard_seqs = torch.cat([txt.index_select(0, hard_txt_full), only_vis.index_select(0, hard_img_full)], 1)
         joint = torch.cat([txt, only_vis], dim=1)
@@ -683,6 +699,10 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         # WRA random draws on the device (no host round trip); False = host draws in the reference's
         # order, which the parity tests replay from the golden fixtures
         self.wra_on_device = True
+        # Heads on the second stream (2, default): the visual-MLM and contrastive heads only need the uni-modal outputs and
+        # are queued beside the joint stack; ITM / QA / WRA (chains of small kernels) run beside the text MLM head's
+        # vocabulary GEMMs.  MVPTR_HEADS_BESIDE (A/B knob): 1 = only the first pair, 0 = everything on one stream.
+        self.heads_beside = int(os.environ.get("MVPTR_HEADS_BESIDE", "2") or 2)
         self.apply(self.init_weights)
         self.tie_weights()
 
@@ -708,41 +728,54 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
             keep_a, keep_b = (masked_lm_labels_a > -1).reshape(-1), (masked_lm_labels_b > -1).reshape(-1)
             la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
             pack_hints = engine.AsyncCounts([keep_a.sum(), keep_b.sum(), la.sum(), la.max(), lb.sum(), lb.max()])
+        ce_loss = CrossEntropyLoss(ignore_index=-1)
+        early = {}
+
+        def uni_heads(txt_out, vis_out, sim_mat):
+            """The two losses that only need the uni-modal outputs: masked-concept / visual MLM and the contrastive
+            loss.  Run from inside the backbone, beside the joint stack (BiBertImgModel.forward, `beside`)."""
+            ib = None
+            if pack_hints is not None:
+                ib = torch.nonzero_static(keep_b, size=pack_hints.get()[1]).view(-1)      # counts landed in the backbone
+            vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b, ib)
+            early["vis_mlm"], _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels, want_scores=False)
+            logits = sim_mat * self.logit_scale.exp()
+            pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
+            early["retrieval"] = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
+
         outputs, single, hard_indexes = self.bert(
             input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
             attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats, input_ids_b=input_ids_b,
             position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b, attention_mask_b=attention_mask_b,
-            max_tag_length=max_tag_length, encode_hn=True, pack_hints=pack_hints)
+            max_tag_length=max_tag_length, encode_hn=True, pack_hints=pack_hints,
+            beside=uni_heads if self.heads_beside >= 1 else None)
         txt_out, vis_out, sim_mat = single
-        ce_loss = CrossEntropyLoss(ignore_index=-1)
         if pack_hints is not None:
-            c = pack_hints.get()      # landed long ago (awaited in the backbone)
-            idx_a = torch.nonzero_static(keep_a, size=c[0]).view(-1)
-            idx_b = torch.nonzero_static(keep_b, size=c[1]).view(-1)
-
-        vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b, idx_b)
-        vis_mlm_loss, _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels, want_scores=False)
-
-        logits = sim_mat * self.logit_scale.exp()
-        pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
-        retrieval_loss = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
+            idx_a = torch.nonzero_static(keep_a, size=pack_hints.get()[0]).view(-1)      # landed long ago (awaited in the backbone)
+        if not early:
+            uni_heads(txt_out, vis_out, sim_mat)
+        elif sim_mat.is_cuda:
+            main = torch.cuda.current_stream(sim_mat.device)
+            main.wait_stream(engine.side_stream(sim_mat.device))
+            for t in early.values():
+                t.record_stream(main)
+        vis_mlm_loss, retrieval_loss = early["vis_mlm"], early["retrieval"]
 
         sequence_output, pooled_output, hard_sequence_output, hard_pooled_output = outputs
-        rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a, idx_a)
-        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels, want_scores=False)
-        seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
-        n = pooled_output.shape[0]
-        dev = seq_relationship_score.device      # built on the device: a pageable host->device copy is a sync
-        next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
-        next_sentence_loss = ce_loss(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
+        late = {}
 
-        total_loss = vis_mlm_loss + retrieval_loss + masked_lm_loss + next_sentence_loss
-        outs = (vis_mlm_loss, retrieval_loss, masked_lm_loss, next_sentence_loss)
-        if qa_ans is not None:
-            qa_loss = ce_loss(self.qa_head(pooled_output), qa_ans)
-            total_loss = total_loss + qa_loss
-            outs = outs + (qa_loss,)
-        if phrase_index is not None:
+        def small_heads():
+            """ITM, QA and word-region alignment: chains of small kernels on the joint output; run beside the text MLM
+            head's vocabulary GEMMs (second stream) when streams are in use."""
+            seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
+            n = pooled_output.shape[0]
+            dev = seq_relationship_score.device      # built on the device: a pageable host->device copy is a sync
+            next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
+            late["itm"] = ce_loss(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
+            if qa_ans is not None:
+                late["qa"] = ce_loss(self.qa_head(pooled_output), qa_ans)
+            if phrase_index is None:
+                return
             if phrase_mod == "hard":
                 hard_txt_index, hard_img_index = hard_indexes
                 hard_phrase_index = phrase_index.index_select(0, hard_txt_index)
@@ -764,9 +797,37 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 raise NotImplementedError
             hinge = torch.clamp(neg_sims + 0.2 - pos_sims, min=0)
             # mean over the samples that have phrases (vl:1298-1300) without a data-dependent shape
-            wra_loss = torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype)
-            total_loss = total_loss + wra_loss
-            return (total_loss,) + outs + (wra_loss,)
+            late["wra"] = torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype)
+
+        bb = self.bert
+        use_side = (self.heads_beside >= 2 and sequence_output.is_cuda and bool(bb.parallel_stacks) and _streams_allowed(bb.parallel_stacks))
+        if use_side:
+            main = torch.cuda.current_stream(sequence_output.device)
+            side = engine.side_stream(sequence_output.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                small_heads()
+            for t in (sequence_output, pooled_output, hard_pooled_output, hard_sequence_output):
+                if t is not None:
+                    t.record_stream(side)
+        else:
+            small_heads()
+        rows, labels = _masked_rows(sequence_output[:, :input_ids_a.shape[1], :], masked_lm_labels_a, idx_a)
+        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(rows, labels, want_scores=False)
+        if use_side:
+            main.wait_stream(side)
+            for t in late.values():
+                t.record_stream(main)
+        next_sentence_loss = late["itm"]
+
+        total_loss = vis_mlm_loss + retrieval_loss + masked_lm_loss + next_sentence_loss
+        outs = (vis_mlm_loss, retrieval_loss, masked_lm_loss, next_sentence_loss)
+        if qa_ans is not None:
+            total_loss = total_loss + late["qa"]
+            outs = outs + (late["qa"],)
+        if phrase_index is not None:
+            total_loss = total_loss + late["wra"]
+            return (total_loss,) + outs + (late["wra"],)
         return (total_loss,) + outs
 
 
