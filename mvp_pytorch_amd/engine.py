@@ -70,6 +70,7 @@ class WeightCache:
 
     def __init__(self):
         self._key = None
+        self._fresh_once = False  # set by a prefetch: the next stale() of the same parameters answers "fresh" once
         self.t = {}
         self._dev = None        # device this object serves (set at first use)
         self._children = {}     # other devices' caches (replicas of the owning module under DataParallel)
@@ -96,6 +97,12 @@ class WeightCache:
         if force is None:
             force = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._fresh_once:
+            # the copies were rebuilt earlier in THIS forward pass (EncoderPacks.prefetch, on the side stream beside the
+            # embedding kernels): do not rebuild them again
+            self._fresh_once = False
+            if key == self._key:
+                return False
         if force or key != self._key:
             self._key = key
             return True
@@ -259,6 +266,14 @@ class EncoderPacks:
             pk.cache._key = None
         plan.build()
         self.plan = plan
+
+    def prefetch(self, params):
+        """Rebuild the bf16 copies now, on the current stream; the stack's own refresh in the same forward pass
+        then finds them fresh.  Only for the one-launch path (contiguous f32 parameters)."""
+        if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            with torch.no_grad():      # as inside EncoderFn.forward: rebuild only if a version counter moved (optimizer step)
+                self.refresh(params)
+            self.cache._fresh_once = True
 
     def refresh(self, params):
         """-> list of LayerWeights, one per layer."""

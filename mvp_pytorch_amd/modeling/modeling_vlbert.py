@@ -148,6 +148,14 @@ class CaptionBertEncoder(nn.Module):
         return (y.view(B, L, H),)
 
 
+def _prefetch_weights(self, device):
+    """bf16 working copies of this stack rebuilt now, on the current stream (see engine.EncoderPacks.prefetch)."""
+    self._packs.for_device(device).group.prefetch(self._flat_params())
+
+
+CaptionBertEncoder.prefetch_weights = _prefetch_weights
+
+
 def _check_img_type(config):
     if getattr(config, "img_feature_type", "faster_r-cnn") in ("dis_code", "dis_code_t", "dis_code_scale"):
         raise NotImplementedError("discrete-code image features are outside the accelerated path")
@@ -234,9 +242,22 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             token_type_ids_b = torch.zeros_like(input_ids_b)
         mask_a = additive_mask(attention_mask_a)
         mask_b = additive_mask(attention_mask_b)
+        two_streams = bool(self.parallel_stacks) and input_ids_a.is_cuda and _streams_allowed(self.parallel_stacks)
+        prefetch = two_streams and self.training and torch.is_grad_enabled() and os.environ.get("MVPTR_NO_PREFETCH") != "1"
+        if prefetch:
+            # training rebuilds the bf16 weight copies of every stack each forward pass (one ~0.1-ms launch per stack):
+            # all three go to the side stream now, beside the embedding kernels, instead of in front of each stack
+            main = torch.cuda.current_stream(input_ids_a.device)
+            side = engine.side_stream(input_ids_a.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for enc in (self.txt_encoder, self.vis_encoder, self.mul_encoder):
+                    enc.prefetch_weights(input_ids_a.device)
         share = {}   # one word-table gradient buffer for both lookups of this forward pass
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self, share)
         xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self, share)
+        if prefetch:
+            main.wait_stream(side)      # the copies are read by the stacks below
         hint_a = hint_b = None
         if pack_hints is not None:
             # fetched by the caller together with its other counts; an AsyncCounts is awaited only now,
@@ -251,7 +272,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
             c = torch.stack([la.sum(), la.max(), lb.sum(), lb.max()]).tolist()
             hint_a, hint_b = (int(c[0]), int(c[1])), (int(c[2]), int(c[3]))
-        if self.parallel_stacks and xa.is_cuda and _streams_allowed(self.parallel_stacks):
+        if two_streams:
             # The two uni-modal stacks are independent networks: the visual one runs on a second HIP
             # stream beside the text one.  At ~11 k rows per stack a 256x256-tile GEMM with N = 768
             # occupies half of the CUs, so the two stacks' kernels fill each other's idle CUs
