@@ -367,6 +367,17 @@ int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights
                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
                             int64_t ws_bytes, void* stream);
 
+/* Same, with the layer's two grouped weight-gradient launches issued on `wgrad_stream` (ordered behind the
+ * kernels that produce their operands by events; NULL = on `stream`).  The caller owns the other half of
+ * the contract: the operands the weight gradients read live in `ws` and `saved`, so `ws` must not be
+ * overwritten (next layer's call with the same `ws`) and `g` must not be read before `wgrad_stream` has
+ * caught up — mvp_pytorch_amd.engine.EncoderFn alternates two workspaces and joins the streams at the end
+ * of a stack's backward pass. */
+int mvptr_encoder_layer_bwd2(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                             const void* x, const float* mask_add, const void* saved,
+                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
+                             int64_t ws_bytes, void* stream, void* wgrad_stream);
+
 /* Measurement helper (never on the product path): reads `bytes` (a multiple of 4096) of `src` exactly
  * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,
  * so that rocprofv3's FETCH_SIZE can be calibrated against a known byte count (tools/calib_fetch.py). */

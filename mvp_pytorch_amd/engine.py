@@ -307,6 +307,28 @@ def _thresh(p):
 # Side streams used for independent sub-networks (text / visual stack); mvp_pytorch_amd.dp waits on
 # them before a gradient bucket is handed to RCCL.
 SIDE_STREAMS = {}
+# Weight gradients of an encoder stack on a stream of their own (EncoderFn.backward, mvptr_encoder_layer_bwd2): opt-in
+# (MVPTR_WGRAD_ASIDE=1, optionally only for stacks of at most MVPTR_WGRAD_ASIDE_MAX_ROWS rows).  Measured on the
+# training step: -0.3 ms on one box and nothing on another for the variable-length batch, +0.4 ms (worse) with all
+# slots valid — the weight-gradient kernel owns a CU's whole register file and LDS, so "beside" means fewer CUs for
+# the data-gradient chain, which only pays where that chain leaves CUs idle (profiles/r02_experiments.txt).
+WGRAD_ASIDE = os.environ.get("MVPTR_WGRAD_ASIDE", "0") == "1"
+WGRAD_ASIDE_MAX_ROWS = int(os.environ.get("MVPTR_WGRAD_ASIDE_MAX_ROWS", "1000000"))
+
+
+WGRAD_STREAMS = {}
+
+
+def wgrad_stream(device, parent):
+    """The stream on which a stack's weight-gradient GEMMs run beside the rest of its backward pass: one per
+    (device, stream the backward pass itself runs on) — the text and visual stacks run their backward passes on
+    two streams at once."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), parent.cuda_stream)
+    with _state_lock:
+        if key not in WGRAD_STREAMS:
+            WGRAD_STREAMS[key] = torch.cuda.Stream(device=key[0])
+        return WGRAD_STREAMS[key]
 
 
 def side_stream(device):
@@ -458,14 +480,27 @@ class EncoderFn(torch.autograd.Function):
         n = len(meta.packs)
         dev = dy.device
         H, I = meta.H, meta.I
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        main = torch.cuda.current_stream()
+        stream = ctypes.c_void_p(main.cuda_stream)
         ws_bytes = lib.mvptr_layer_workspace_bytes(ctypes.byref(ctx.descs[0]))
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        # Weight gradients beside the data-gradient chain: a layer's two grouped weight-gradient launches only feed the
+        # optimizer, so they go to a stream of their own (mvptr_encoder_layer_bwd2 orders them behind the kernels
+        # that produce their operands) and run beside the next kernels of the chain — LayerNorm / attention backward,
+        # which leave the matrix pipes idle, and the partly filled last rounds of the N = 768 data-gradient GEMMs.
+        # Their operands live in the workspace and the stash: two workspaces alternate, and a layer waits for the
+        # weight gradients of the layer two before it (same workspace); the streams join at the end.
+        aside = WGRAD_ASIDE and n > 1 and dy.shape[0] <= WGRAD_ASIDE_MAX_ROWS
+        aux = wgrad_stream(dev, main) if aside else None
+        wss = [torch.empty(ws_bytes, device=dev, dtype=torch.uint8) for _ in range(2 if aside else 1)]
+        done = []
         sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
         total = sum(sizes)
         grads = [None] * (16 * n)
         d_cur = dy.contiguous()
-        for li in reversed(range(n)):
+        for k, li in enumerate(reversed(range(n))):
+            ws = wss[k % len(wss)]
+            if aside and k >= 2:
+                main.wait_event(done[k - 2])
             flat = torch.zeros(total, device=dev, dtype=torch.float32)
             parts, o = [], 0
             for s in sizes:
@@ -475,9 +510,16 @@ class EncoderFn(torch.autograd.Function):
             (g.w_qkv, g.b_qkv, g.w_o, g.b_o, g.ln1_g, g.ln1_b, g.w_i, g.b_i, g.w_out, g.b_out, g.ln2_g,
              g.ln2_b) = [p.data_ptr() for p in parts]
             dx = torch.empty_like(d_cur)
-            hip._check(lib.mvptr_encoder_layer_bwd(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
-                                                   hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
-                                                   hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream))
+            hip._check(lib.mvptr_encoder_layer_bwd2(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
+                                                    hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
+                                                    hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream,
+                                                    ctypes.c_void_p(aux.cuda_stream) if aside else None))
+            if aside:
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                done.append(ev)
+                for t in (flat, ws, ctx.xs[li], ctx.stashes[li]):
+                    t.record_stream(aux)
             wq = parts[0].view(3, H, H)
             bq = parts[1].view(3, H)
             gl = [wq[0], bq[0], wq[1], bq[1], wq[2], bq[2], parts[2].view(H, H), parts[3], parts[4], parts[5],
@@ -487,6 +529,8 @@ class EncoderFn(torch.autograd.Function):
                 if p.requires_grad:
                     grads[16 * li + j] = gl[j].to(p.dtype)
             d_cur = dx
+        if aside:
+            main.wait_stream(aux)      # the gradients handed back below are complete on this stream
         ctx.stashes = ctx.xs = None
         return (d_cur, None, None) + tuple(grads)
 

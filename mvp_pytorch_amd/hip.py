@@ -26,7 +26,7 @@ SYMBOLS = [
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
-    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe",
+    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe", "mvptr_encoder_layer_bwd2",
 ]
 
 
@@ -108,6 +108,7 @@ def load():
     lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
+    lib.mvptr_encoder_layer_bwd2.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P, P]
     _lib = lib
     return lib
 
