@@ -28,6 +28,27 @@ from . import hip
 # below is therefore either guarded by this lock or kept per device (WeightCache.for_device,
 # PackList.for_device, side_stream).
 _state_lock = threading.Lock()
+_tls = threading.local()
+
+
+class GradAwareFunction(torch.autograd.Function):
+    """autograd.Function whose forward can see the CALLER's grad mode: PyTorch runs Function.forward with grad mode
+    off, and the weight caches decide "parameters are being trained -> rebuild the bf16 copies at every forward pass"
+    from it (WeightCache.stale)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev = getattr(_tls, "outer_grad", None)
+        _tls.outer_grad = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _tls.outer_grad = prev
+
+
+def _caller_grad_enabled():
+    g = getattr(_tls, "outer_grad", None)
+    return torch.is_grad_enabled() if g is None else g
 _seed_counter = [0x5DEECE66D]
 
 
@@ -95,7 +116,7 @@ class WeightCache:
 
     def stale(self, params, force=None):
         if force is None:
-            force = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            force = _caller_grad_enabled() and any(p.requires_grad for p in params)
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._fresh_once:
             # the copies were rebuilt earlier in THIS forward pass (EncoderPacks.prefetch, on the side stream beside the
@@ -271,8 +292,7 @@ class EncoderPacks:
         """Rebuild the bf16 copies now, on the current stream; the stack's own refresh in the same forward pass
         then finds them fresh.  Only for the one-launch path (contiguous f32 parameters)."""
         if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
-            with torch.no_grad():      # as inside EncoderFn.forward: rebuild only if a version counter moved (optimizer step)
-                self.refresh(params)
+            self.refresh(params)       # training: rebuilt unconditionally (WeightCache.stale)
             self.cache._fresh_once = True
 
     def refresh(self, params):
@@ -430,7 +450,7 @@ class UnpackRows(torch.autograd.Function):
         return g.index_select(0, ctx.idx), None, None
 
 
-class EncoderFn(torch.autograd.Function):
+class EncoderFn(GradAwareFunction):
     """n stacked encoder layers: x bf16 [B*L,H], additive mask f32 [B,L] -> bf16 [B*L,H]."""
 
     @staticmethod
@@ -536,7 +556,7 @@ class EncoderFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
-class InputEmbedFn(torch.autograd.Function):
+class InputEmbedFn(GradAwareFunction):
     """Token embeddings (+ region-feature embedding) -> concatenated bf16 [B, Lt+R, H].
 
     args: ids/type_ids/pos_ids int64 [B,Lt]; img_feats f32 [B,R,D] or None; meta dict with
@@ -635,7 +655,7 @@ class InputEmbedFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
-class LinearFn(torch.autograd.Function):
+class LinearFn(GradAwareFunction):
     """y = act(x W^T + b) on bf16 rows; act in {None, 'gelu'}; W f32 [N,K] master weight."""
 
     @staticmethod
@@ -710,7 +730,7 @@ class LayerNormFn(torch.autograd.Function):
         return dz.view(dy.shape), dg, db, None
 
 
-class DecoderCEFn(torch.autograd.Function):
+class DecoderCEFn(GradAwareFunction):
     """loss = mean_{labels>=0} CE(h W^T + b, labels); W f32 [V,H] (vocabulary decoder).
     Returns (loss, logits f32 [M,V] view) — logits are a non-differentiable side output.
 

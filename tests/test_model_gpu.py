@@ -725,10 +725,20 @@ def test_weight_cache_sees_data_updates(dev):
     model, _ = _build("BiImageBertForRetrieval", dict(cfg, loss_type="ce", num_labels=2), 3, dev, train=True)
     model.forward_mod = "fine"
     a = model(max_tag_length=20, **kw).detach().clone()
+    # only parameters that reach the output through bf16 working copies alone (joint stack): if the copies were not
+    # rebuilt the output could not move
+    for n, p in model.named_parameters():
+        if n.startswith("bert.mul_encoder.") and n.endswith("dense.weight"):
+            p.data.mul_(0.5)                   # invisible to the version counters
+    a2 = model(max_tag_length=20, **kw).detach().clone()
+    assert not torch.allclose(a, a2)           # training mode: copies refreshed unconditionally
+    for n, p in model.named_parameters():
+        if n.startswith("bert.mul_encoder.") and n.endswith("dense.weight"):
+            p.data.mul_(2.0)
     for p in model.parameters():
-        p.data.mul_(0.5)                       # invisible to the version counters
+        p.data.mul_(0.5)
     b = model(max_tag_length=20, **kw).detach().clone()
-    assert not torch.allclose(a, b)            # training mode: copies refreshed unconditionally
+    assert not torch.allclose(a, b)
     model.eval()
     with torch.no_grad():
         c = model(max_tag_length=20, **kw).clone()
