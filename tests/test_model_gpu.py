@@ -360,6 +360,45 @@ def test_unpadded_equals_padded_execution(dev):
     assert torch.equal(seq_u[vj], seq_p[vj])
 
 
+def test_stream_placement_does_not_change_results(dev):
+    """Where a kernel is queued is not allowed to change what it computes: heads on the second stream (default) against
+    everything on one stream, and the stacks' weight gradients on their own stream (MVPTR_WGRAD_ASIDE, opt-in) against the
+    layer's stream: same losses and the same gradients up to the order of bf16 / f32 sums (checked at 1e-5 of each tensor's
+    norm, far below the 2e-3 parity tolerance)."""
+    from mvp_pytorch_amd import engine
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    dims = dict(B=8, T=16, P=3, G=6, R=7)
+    b = {k: v.to(dev) for k, v in synthetic_batch(dims, cfg, 77).items()}
+
+    def run(heads, aside):
+        old = engine.WGRAD_ASIDE
+        engine.WGRAD_ASIDE = aside
+        try:
+            model, _ = _build("BiBertImgForPreTraining", cfg, 5, dev, train=True)
+            model.wra_on_device = True
+            model.heads_beside = heads
+            torch.manual_seed(321)
+            o = model(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+                      masked_lm_labels_a=b["lm_label_ids_a"], input_ids_b=b["input_ids_b"], img_feats=b["img_feats"],
+                      token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"],
+                      masked_lm_labels_b=b["lm_label_ids_b"], max_tag_length=dims["G"], phrase_index=b["phrase_index"],
+                      img_index=b["image_index"])
+            o[0].backward()
+            torch.cuda.synchronize()
+            return torch.stack([x.detach() for x in o]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            engine.WGRAD_ASIDE = old
+
+    ref_l, ref_g = run(0, False)
+    for heads, aside in ((2, False), (1, False), (0, True), (2, True)):
+        l, g = run(heads, aside)
+        assert torch.allclose(l, ref_l, rtol=1e-6, atol=0), (heads, aside, l.tolist(), ref_l.tolist())
+        assert g.keys() == ref_g.keys()
+        worst = max((_rel(g[n], ref_g[n]), n) for n in g if ref_g[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
+        assert worst[0] < 1e-5, (heads, aside, worst)
+
+
 def test_finetune_models_unpadded_two_streams_equal_padded_one_stream(dev):
     """VQA (encode_hn=False path) and retrieval-train wrappers in training mode: row-packed stacks +
     text/visual stacks on two streams (defaults) against padded, single-stream execution."""
