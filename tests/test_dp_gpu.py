@@ -75,3 +75,25 @@ def test_two_rank_training_step_keeps_replicas_identical(dev):
     assert ld == ls
     for k in pd_:
         assert np.array_equal(pd_[k], ps[k]), k     # rows outside the union are zero on both ranks: same sums
+
+
+def test_bench_launcher_two_ranks_on_one_gpu(dev):
+    """`python bench.py --gpus 2` as the driver starts it without a launcher: two rank processes, one JSON line from rank 0
+    with n_gpus = 2 and the whole-job rate.  The test box has one GPU, so both ranks are pinned to it and talk through gloo
+    (MVPTR_BENCH_DEVICE / MVPTR_DIST_BACKEND: the hooks bench.py has for exactly this); on a multi-GPU node the same code path
+    runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVPTR_BENCH_DEVICE="0", MVPTR_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    o = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert o.returncode == 0, o.stderr.decode()[-2000:]
+    line = json.loads(o.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 32
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["ms_per_step"] > 0
+    assert abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 0.02 * line["value"]
