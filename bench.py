@@ -337,28 +337,64 @@ def _spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL) as
     CHILDREN before this process has touched the GPU, relay rank 0's JSON line, exit with the worst
     return code.  (Replacing this process by exec after a HIP call is forbidden on the pool; a plain
-    child process per rank is also what torch.distributed.run does.)"""
+    child process per rank is also what torch.distributed.run does.)  All children are polled: when one
+    exits non-zero the others are terminated (a rank that died early would otherwise leave rank 0 inside a
+    collective until the backend's timeout) and its stderr tail is shown."""
     import socket
     import subprocess
+    import tempfile
     n = args.gpus
     visible = torch.cuda.device_count()   # counts devices without initialising HIP
     if visible < n and "MVPTR_BENCH_DEVICE" not in os.environ:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, visible))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    raise SystemExit(max(abs(rc) for rc in rcs))
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs, logs = [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            out = tempfile.TemporaryFile()
+            err = tempfile.TemporaryFile()
+            logs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+        failed = None
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            time.sleep(0.2)
+
+        def tail(f, nbytes=4000):
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - nbytes))
+            return f.read().decode(errors="replace")
+
+        if failed is None:
+            logs[0][0].seek(0)
+            sys.stdout.write(logs[0][0].read().decode())
+            sys.stdout.flush()
+            raise SystemExit(0)
+        err_text = tail(logs[failed][1])
+        if "EADDRINUSE" in err_text or "address already in use" in err_text.lower():
+            continue                       # the rendezvous port was taken between bind(0) and the ranks' start: new port
+        sys.stderr.write("bench.py: rank %d exited with %s\n%s\n" % (failed, procs[failed].returncode, err_text))
+        raise SystemExit(abs(procs[failed].returncode) or 1)
+    raise SystemExit("bench.py: no free rendezvous port after 3 attempts")
 
 
 def main():
@@ -373,6 +409,10 @@ def main():
                     help="timed steps only (no all-slots-valid leg, kernel replay or CPU baseline): the command profiles/ are made from")
     ap.add_argument("--model", choices=["bi", "single"], default="bi",
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
+    ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
+    ap.add_argument("--dp-sparse-rows", action="store_true", help="N > 1: word-table gradient exchanged by looked-up rows (default dense)")
+    ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams as at N = 1")
+    ap.add_argument("--no-arena", action="store_true", help="N = 1: gradients through autograd tensors instead of the gradient arena (A/B)")
     ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--budget", type=float, default=10.0, help=argparse.SUPPRESS)
@@ -418,6 +458,8 @@ def main():
     cfg = dict(BASE_CFG, vocab_size=30522, max_text_seq_length=70) if single else BASE_CFG
     torch.manual_seed(1234)  # identical initial weights on every rank
     cls = modeling.BertImgForPreTraining if single else modeling.BiBertImgForPreTraining
+    if world > 1 and args.dp_two_streams:
+        cfg = dict(cfg, parallel_stacks="always")
     model = cls(modeling.make_config(cfg)).to(dev)
     model.train()
     if single:
@@ -425,10 +467,15 @@ def main():
         # ("prediction_scores"); the reference's loop reads outputs[0] only
         model.return_prediction_scores = False
     opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
-    # bi model: the MLM decoders are clones of the first 30 522 embedding rows (not tied), so the word
-    # table's gradient holds the looked-up rows only and is exchanged by rows (dp.GradSync.note_rows)
-    sparse = [] if single else [model.bert.embeddings.word_embeddings.weight]
-    sync = dp.GradSync(model, sparse_rows=sparse) if world > 1 else None
+    # Gradient arena at every world size (the kernels accumulate weight gradients straight into the flat
+    # buckets that are all-reduced when N > 1).  Defaults for N > 1: f32 wire, dense exchange, one compute
+    # stream; --dp-bf16-wire / --dp-sparse-rows / --dp-two-streams opt in (bi model: the MLM decoders are
+    # clones of the first 30 522 embedding rows, not tied, so the word table's gradient holds the looked-up
+    # rows only, dp.GradSync.note_rows).
+    sparse = [model.bert.embeddings.word_embeddings.weight] if (args.dp_sparse_rows and not single) else []
+    sync = None
+    if world > 1 or not args.no_arena:
+        sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
 
     def make_batch(fixed):
         return synthetic_batch(dims, cfg, 1234 + rank, single_stream=single, fixed_length=fixed, device=dev)

@@ -40,7 +40,7 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 2
+#define MVPTR_ABI_VERSION 3
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
@@ -263,7 +263,9 @@ int mvptr_decoder_ce_bwd(const void* h, int64_t ldh, const void* W, int64_t ldw,
  * v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) + eps); p *= decay  (decay = 1 - lr*wd,
  * applied after the Adam update; step_size carries lr and the bias correction).
  * `table` is a DEVICE array of n_tensors descriptors; chunk_tensor / chunk_offset (device, one
- * entry per workgroup) map each chunk of `chunk_elems` elements to its tensor. */
+ * entry per workgroup) map each chunk of `chunk_elems` elements to its tensor.
+ * grad_scale: optional DEVICE f32 scalar multiplied into every gradient element (the clip coefficient of
+ * mvptr_clip_coef: second pass of the global-norm clip, oscar/run_pretrain_ml.py:636-640); NULL = 1. */
 typedef struct {
   float* p;
   const float* g;
@@ -275,7 +277,113 @@ typedef struct {
 } mvptr_adamw_tensor;
 int mvptr_adamw_multi(const mvptr_adamw_tensor* table, const int32_t* chunk_tensor,
                       const int64_t* chunk_offset, int n_chunks, int chunk_elems, float beta1,
-                      float beta2, float eps, void* stream);
+                      float beta2, float eps, const float* grad_scale, void* stream);
+
+/* The same update for tensors that have bf16 WORKING COPIES (the operands of the forward and data-gradient
+ * GEMMs): each 64 x 64 tile of the tensor, viewed as [rows, cols], is updated and written out in one pass as
+ * dst bf16 [rows, ld_dst] (columns cols..ld_dst-1 zero-filled), dst_t bf16 [cols, ld_dst_t] at column offset
+ * col_off_t (transposed; query | key | value land side by side in one [H, 3H] matrix) and dst_f32 (f32 copy,
+ * the packed Q|K|V bias) — each optional.  Replaces optimizer.step() + the `.to(bf16)` / `.t().contiguous()`
+ * weight preparation that follows it (what mvptr_cast_multi does as a separate pass).  tile_base[i] = first
+ * tile of tensor i (DEVICE, n_tensors + 1 entries), tiles per tensor = ceil(rows/64) * ceil(max(cols, ld_dst)/64). */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int rows, cols;
+  float step_size;
+  float decay;
+  void* dst;
+  int64_t ld_dst;
+  void* dst_t;
+  int64_t ld_dst_t;
+  int col_off_t;
+  int pad_;
+  float* dst_f32;
+} mvptr_adamw_mirror_tensor;
+int mvptr_adamw_mirror_multi(const mvptr_adamw_mirror_tensor* table, const int* tile_base, int n_tensors,
+                             int total_tiles, float beta1, float beta2, float eps, const float* grad_scale,
+                             void* stream);
+
+/* Global gradient-norm clip (torch.nn.utils.clip_grad_norm_, norm_type 2; oscar/run_pretrain_ml.py:636-640,
+ * DeepSpeed recipe gradient_clipping 10.0 oscar/tmp_config.json) in two passes over flat f32 gradient buffers:
+ * mvptr_sumsq_partial writes one partial sum of squares per 16 384 elements (mvptr_sumsq_partials(n) of them, at
+ * `partials`; call once per buffer with consecutive slices of one partial array); mvptr_clip_coef adds the
+ * partials in index order (bitwise reproducible) and writes norm_out[0] = sqrt(sum),
+ * coef_out[0] = min(1, max_norm / (norm + 1e-6)), which the AdamW kernels take as grad_scale. */
+int64_t mvptr_sumsq_partials(int64_t n);
+int mvptr_sumsq_partial(const float* x, int64_t n, float* partials, void* stream);
+int mvptr_clip_coef(const float* partials, int n, float max_norm, float* norm_out, float* coef_out, void* stream);
+
+/* ---- B-row heads in f32 (heads.hip) ---------------------------------------------------------------------
+ * C[M,N] = act(alpha * op(A) op(B) + bias) with exact f32 FMA accumulation: the pooler
+ * tanh(dense(h[:,0])) (transformers/pytorch_transformers/modeling_bert.py:468-474), the 2-way image-text-matching
+ * head `seq_relationship` (oscar/modeling/modeling_vlbert.py:975-979), the CLIP-style global projections
+ * `txt_out[:,0] @ txt_proj` (:525-526), the similarity matrix `global_txt @ global_img.t()` (:527) and the
+ * gradients of all four.  op(X) = X or X^T (trans_x); A / B are f32 or bf16 (x_bf16) with unit column
+ * stride; a_rows / b_rows (optional, int32) gather A's / B's STORED rows — the [CLS] rows of a padded or
+ * row-packed sequence buffer are read in place; act: 0 none, 1 tanh; accumulate != 0: C += (a gradient arena). */
+int mvptr_sgemm_small(const void* A, int64_t lda, int a_bf16, int trans_a, const int32_t* a_rows, const void* B,
+                      int64_t ldb, int b_bf16, int trans_b, const int32_t* b_rows, int M, int N, int K, float alpha,
+                      const float* bias, int act, int accumulate, float* C, int64_t ldc, void* stream);
+
+/* Mean cross entropy over M rows of V <= 64 classes (the 2-way image-text-matching loss,
+ * CrossEntropyLoss(ignore_index=-1) oscar/modeling/modeling_vlbert.py:1247-1251; rows whose label is outside
+ * [0, V) are ignored): loss[0] = mean; dlogits (optional, f32 [M, V]) = d loss / d logits. */
+int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_t* labels, int M, int V, float* loss,
+                        float* dlogits, void* stream);
+
+/* g = y / max(||y||_2, eps) per row, inv_norm[r] = 1 / max(||y||, eps): F.normalize(p=2, dim=-1) of
+ * oscar/modeling/modeling_vlbert.py:525-526; backward dy = (dg - g (g . dg)) * inv_norm. */
+int mvptr_l2norm_fwd(const float* y, float* g, float* inv_norm, int rows, int H, float eps, void* stream);
+int mvptr_l2norm_bwd(const float* g, const float* inv_norm, const float* dg, float* dy, int rows, int H, void* stream);
+
+/* Symmetric contrastive loss of oscar/modeling/modeling_vlbert.py:1238-1241 over sim f32 [n, n] (row = text,
+ * column = image): logits = sim * exp(logit_scale[0]); loss[0] = (mean_i CE(logits[i,:], i) + mean_j
+ * CE(logits[:,j], j)) / 2.  lse: f32 [2n] (row then column log-sum-exp, kept for backward); parts: f32 [2n]
+ * scratch.  Backward: dsim f32 [n, n] = d loss / d sim * gloss[0]; dlogit_scale[0] += d loss / d logit_scale
+ * * gloss[0] (optional); parts: f32 [n] scratch. */
+int mvptr_clip_ce_fwd(const float* sim, int n, int64_t ld, const float* logit_scale, float* lse, float* parts,
+                      float* loss, void* stream);
+int mvptr_clip_ce_bwd(const float* sim, int n, int64_t ld, const float* logit_scale, const float* lse,
+                      const float* gloss, float* dsim, float* parts, float* dlogit_scale, void* stream);
+
+/* ---- rows between the stacks (rows.hip) ------------------------------------------------------------------
+ * Row gather / scatter-add over bf16 [rows, H] buffers: out[i,:] = src[idx[i],:] (idx < 0: zero row) and
+ * dst[idx[i],:] += src[i,:] (src bf16, or f32 when src_f32; packed bf16 atomics, so rows may repeat).  With a
+ * second buffer (src2 / dst2 != NULL) indices >= split address row idx - split of it: two packed stack outputs
+ * used as one source.  Replace the index_select / masked_select / torch.cat chains that move rows between the
+ * stacks and into the heads (oscar/modeling/modeling_vlbert.py:519,544-552,586-590,1231-1234,1245;
+ * modeling_bert.py:471) and the index_add / zero-fill-and-copy kernels autograd derives for them.
+ * H % 8 == 0 (gather), H % 2 == 0 (scatter). */
+int mvptr_gather_rows(const void* src, int64_t ld_src, const void* src2, int64_t ld_src2, int split,
+                      const int32_t* idx, void* out, int64_t ld_out, int n, int H, void* stream);
+int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f32, const int32_t* idx, void* dst,
+                           int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int n, int H, void* stream);
+
+/* Index maps of a row-packed pass, built on the device from additive attention masks (valid slot <=> 0).
+ * Output sequence s (0 <= s < n_seq) is the concatenation of nseg (1 or 2) segments; segment k covers the slots
+ * [col0, col0 + len) of mask row sel[s] (s when sel == NULL) and names the SOURCE row of each valid slot:
+ * pos[sel * ld_pos + col] when pos != NULL (a row of an already packed buffer: the joint sequence =
+ * text rows of the packed text output + region rows of the packed visual output, hard negatives through sel,
+ * oscar/modeling/modeling_vlbert.py:544-552,586-590), else sel * src_seq_stride + col (a row of a padded
+ * [*, src_seq_stride, H] buffer: the uni-modal stacks, vl:430-460); src_base is added (offset of a second buffer).
+ * Outputs: pos_out int32 [n_seq, sum len] = packed row of every slot (-1: padded slot), idx_out int32
+ * [>= total valid] = source row of every packed row (the index vector of mvptr_gather_rows), seq_start /
+ * seq_len int32 [n_seq] (mvptr_layer_desc), counts int64 [2] = {total valid rows, longest sequence}. */
+typedef struct {
+  const float* mask;
+  int64_t ld_mask;
+  const int64_t* sel;
+  int col0, len;
+  const int32_t* pos;
+  int64_t ld_pos;
+  int64_t src_seq_stride;
+  int64_t src_base;
+} mvptr_pack_seg;
+int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, int32_t* pos_out, int32_t* idx_out,
+                    int32_t* seq_start, int32_t* seq_len, int64_t* counts, void* stream);
 
 /* Input pipeline: region features of n_samples TSV rows, still base64 text, ->
  * out_f32 [n_samples, R, D] and/or out_bf16 [n_samples * R, ld_bf16] (columns D..ld_bf16-1 zero: the

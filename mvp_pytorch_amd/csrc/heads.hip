@@ -1,0 +1,330 @@
+// heads.hip — the B-row tails of the cross-modal model in f32: pooler (modeling_bert.py:468-474), the 2-way
+// image-text-matching head (oscar/modeling/modeling_vlbert.py:975-979,1247-1251), the CLIP-style global
+// projections, L2 normalisation, similarity matrix and symmetric contrastive loss (:525-527,1238-1241).
+//
+// These operate on B or 2B rows ([CLS] states) — 0.1-0.6 GFLOP each, latency-bound — and stay in f32 like
+// the reference (sim_mat feeds the hard-negative argmax :531-534, so it must not be rounded to bf16): exact
+// f32 FMA chains on the vector ALUs, 32 x 32 output tiles through LDS.  What this file buys over library
+// calls is launch count and independence from the host application's BLAS selection, not FLOP/s.
+#include "common.h"
+
+namespace {
+
+struct SgemmArgs {
+  const void* A;          // op(A) is [M, K]
+  const void* B;          // op(B) is [K, N]
+  float* C;               // [M, N]
+  const float* bias;      // [N] or NULL
+  const int32_t* a_rows;  // optional gather: row m of op(A) (or column when trans_a) is A row a_rows[m]
+  const int32_t* b_rows;  // optional gather of B's stored rows (k when !trans_b, n when trans_b)
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int trans_a, trans_b;   // 0: as stored [M,K] / [K,N]; 1: stored transposed ([K,M] / [N,K])
+  int a_bf16, b_bf16;     // element type of A / B (0: f32, 1: bf16)
+  int act;                // 0: none, 1: tanh
+  int accumulate;         // C += result (gradients into an arena) instead of C =
+  float alpha;
+};
+
+__device__ __forceinline__ float ld_elem(const void* base, int64_t idx, int is_bf16) {
+  return is_bf16 ? bf2f(((const __bf16*)base)[idx]) : ((const float*)base)[idx];
+}
+
+// C[M,N] = act(alpha * op(A) op(B) + bias): 32 x 32 tile per 256-thread workgroup, 4 outputs per thread
+// (rows ty + 8 i of column tx), K swept in slices of 32 through LDS.
+__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs p) {
+  __shared__ float As[32][33];  // [m][k]
+  __shared__ float Bs[32][33];  // [k][n]
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // A slice: element (m, k); fastest-varying index of the load follows the storage order
+      {
+        const int a = ty + 8 * i, b = tx;
+        const int m = p.trans_a ? (m0 + b) : (m0 + a);
+        const int k = p.trans_a ? (k0 + a) : (k0 + b);
+        float v = 0.f;
+        if (m < p.M && k < p.K) {
+          if (p.trans_a) {
+            const int64_t row = p.a_rows ? (int64_t)p.a_rows[k] : (int64_t)k;   // stored [K, M]: gather applies to stored rows
+            v = ld_elem(p.A, row * p.lda + m, p.a_bf16);
+          } else {
+            const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
+            v = ld_elem(p.A, row * p.lda + k, p.a_bf16);
+          }
+        }
+        if (p.trans_a) As[b][a] = v; else As[a][b] = v;
+      }
+      {
+        const int a = ty + 8 * i, b = tx;
+        const int k = p.trans_b ? (k0 + b) : (k0 + a);
+        const int n = p.trans_b ? (n0 + a) : (n0 + b);
+        float v = 0.f;
+        if (k < p.K && n < p.N) {
+          if (p.trans_b) {
+            const int64_t row = p.b_rows ? (int64_t)p.b_rows[n] : (int64_t)n;
+            v = ld_elem(p.B, row * p.ldb + k, p.b_bf16);
+          } else {
+            const int64_t row = p.b_rows ? (int64_t)p.b_rows[k] : (int64_t)k;
+            v = ld_elem(p.B, row * p.ldb + n, p.b_bf16);
+          }
+        }
+        if (p.trans_b) Bs[b][a] = v; else Bs[a][b] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float bv = Bs[k][tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = fmaf(As[ty + 8 * i][k], bv, acc[i]);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + tx;
+  if (n >= p.N) return;
+  const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 8 * i;
+    if (m >= p.M) continue;
+    float v = acc[i] * p.alpha + bv;
+    if (p.act == 1) v = tanhf(v);
+    float* c = p.C + (int64_t)m * p.ldc + n;
+    *c = p.accumulate ? (*c + v) : v;
+  }
+}
+
+// g[r,:] = y[r,:] / max(||y[r,:]||, eps); inv[r] = 1 / max(||y||, eps)       (F.normalize(p=2, dim=-1))
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* y, float* g, float* inv, int H, float eps) {
+  const int r = blockIdx.x;
+  const float* yr = y + (int64_t)r * H;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < H; c += 256) s += yr[c] * yr[c];
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  const float iv = 1.f / fmaxf(nrm, eps);
+  for (int c = threadIdx.x; c < H; c += 256) g[(int64_t)r * H + c] = yr[c] * iv;
+  if (threadIdx.x == 0) inv[r] = iv;
+}
+
+// dy = (dg - g (g . dg)) * inv   (rows with ||y|| < eps, where normalize is a plain scale, do not occur for
+// projected [CLS] states; they would get the scale-only gradient dg * inv from the same formula's first term)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* g, const float* inv, const float* dg, float* dy, int H) {
+  const int r = blockIdx.x;
+  const float* gr = g + (int64_t)r * H;
+  const float* dr = dg + (int64_t)r * H;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < H; c += 256) s += gr[c] * dr[c];
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float dot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float iv = inv[r];
+  for (int c = threadIdx.x; c < H; c += 256) dy[(int64_t)r * H + c] = (dr[c] - gr[c] * dot) * iv;
+}
+
+// Symmetric contrastive loss over sim [n, n] (row i = text i, column j = image j), logits = sim * scale:
+//   loss = ( mean_i CE(logits[i, :], i) + mean_j CE(logits[:, j], j) ) / 2          (vl:1238-1241)
+// one workgroup per row (blocks 0..n-1) and per column (blocks n..2n-1): log-sum-exp -> lse[2n];
+// parts[b] = lse - logits[i, i] (summed by clip_ce_sum_kernel in index order).
+__global__ __launch_bounds__(256) void clip_ce_lse_kernel(const float* sim, int n, int64_t ld, const float* logit_scale,
+                                                           float* lse, float* parts) {
+  const int b = blockIdx.x;
+  const bool col = b >= n;
+  const int i = col ? b - n : b;
+  const float sc = __expf(logit_scale[0]);
+  float m = -1e30f, s = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float v = (col ? sim[(int64_t)j * ld + i] : sim[(int64_t)i * ld + j]) * sc;
+    const float mm = fmaxf(m, v);
+    s = s * __expf(m - mm) + __expf(v - mm);
+    m = mm;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+    const float mm = fmaxf(m, m2);
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+  }
+  __shared__ float sm[8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sm[wave] = m;
+    sm[4 + wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ss += sm[4 + w] * __expf(sm[w] - mm);
+    const float l = mm + logf(ss);
+    lse[b] = l;
+    parts[b] = l - sim[(int64_t)i * ld + i] * sc;
+  }
+}
+__global__ __launch_bounds__(256) void clip_ce_sum_kernel(const float* parts, int n, float* loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < 2 * n; i += 256) s += parts[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (2.f * (float)n);
+}
+// dlogits[i,j] = gloss / (2n) * (exp(l_ij - lse_row[i]) + exp(l_ij - lse_col[j]) - 2 [i == j]);
+// dsim = dlogits * scale; d(logit_scale) += sum dlogits * logits   (logits = sim * exp(logit_scale))
+__global__ __launch_bounds__(256) void clip_ce_bwd_kernel(const float* sim, int n, int64_t ld, const float* logit_scale,
+                                                           const float* lse, const float* gloss, float* dsim,
+                                                           float* dscale_parts) {
+  const int i = blockIdx.x;
+  const float sc = __expf(logit_scale[0]);
+  const float w = gloss[0] / (2.f * (float)n);
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float l = sim[(int64_t)i * ld + j] * sc;
+    const float d = w * (__expf(l - lse[i]) + __expf(l - lse[n + j]) - (i == j ? 2.f : 0.f));
+    dsim[(int64_t)i * n + j] = d * sc;
+    acc += d * l;
+  }
+  acc = wave_sum(acc);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dscale_parts[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sum_add_kernel(const float* parts, int n, float* out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += parts[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] += red[0];
+}
+
+}  // namespace
+
+extern "C" int mvptr_sgemm_small(const void* A, int64_t lda, int a_bf16, int trans_a, const int32_t* a_rows, const void* B,
+                                 int64_t ldb, int b_bf16, int trans_b, const int32_t* b_rows, int M, int N, int K, float alpha, const float* bias,
+                                 int act, int accumulate, float* C, int64_t ldc, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "sgemm_small: M, N, K must be > 0");
+  if (!A || !B || !C) MVPTR_FAIL(MVPTR_BAD_ARG, "sgemm_small: NULL argument");
+  if (act < 0 || act > 1) MVPTR_FAIL(MVPTR_BAD_ARG, "sgemm_small: unknown activation %d", act);
+  SgemmArgs p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.a_rows = a_rows; p.b_rows = b_rows;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.trans_a = trans_a ? 1 : 0; p.trans_b = trans_b ? 1 : 0;
+  p.a_bf16 = a_bf16 ? 1 : 0; p.b_bf16 = b_bf16 ? 1 : 0;
+  p.act = act; p.accumulate = accumulate ? 1 : 0; p.alpha = alpha;
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
+  MVPTR_CHECK_LAUNCH("sgemm_small");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_l2norm_fwd(const float* y, float* g, float* inv_norm, int rows, int H, float eps, void* stream) {
+  if (rows <= 0 || H <= 0 || !y || !g || !inv_norm) MVPTR_FAIL(MVPTR_BAD_ARG, "l2norm_fwd: bad argument");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, y, g, inv_norm, H, eps);
+  MVPTR_CHECK_LAUNCH("l2norm_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_l2norm_bwd(const float* g, const float* inv_norm, const float* dg, float* dy, int rows, int H, void* stream) {
+  if (rows <= 0 || H <= 0 || !g || !inv_norm || !dg || !dy) MVPTR_FAIL(MVPTR_BAD_ARG, "l2norm_bwd: bad argument");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, inv_norm, dg, dy, H);
+  MVPTR_CHECK_LAUNCH("l2norm_bwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_clip_ce_fwd(const float* sim, int n, int64_t ld, const float* logit_scale, float* lse, float* parts,
+                                 float* loss, void* stream) {
+  if (n <= 0 || ld < n || !sim || !logit_scale || !lse || !parts || !loss) MVPTR_FAIL(MVPTR_BAD_ARG, "clip_ce_fwd: bad argument");
+  hipLaunchKernelGGL(clip_ce_lse_kernel, dim3(2 * n), dim3(256), 0, (hipStream_t)stream, sim, n, ld, logit_scale, lse, parts);
+  hipLaunchKernelGGL(clip_ce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, n, loss);
+  MVPTR_CHECK_LAUNCH("clip_ce_fwd");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_clip_ce_bwd(const float* sim, int n, int64_t ld, const float* logit_scale, const float* lse,
+                                 const float* gloss, float* dsim, float* parts, float* dlogit_scale, void* stream) {
+  if (n <= 0 || ld < n || !sim || !logit_scale || !lse || !gloss || !dsim || !parts)
+    MVPTR_FAIL(MVPTR_BAD_ARG, "clip_ce_bwd: bad argument");
+  hipLaunchKernelGGL(clip_ce_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, sim, n, ld, logit_scale, lse, gloss, dsim, parts);
+  if (dlogit_scale != nullptr)
+    hipLaunchKernelGGL(sum_add_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, n, dlogit_scale);
+  MVPTR_CHECK_LAUNCH("clip_ce_bwd");
+  return MVPTR_OK;
+}
+
+namespace {
+// mean cross entropy over M rows of V <= 64 classes (ITM: V = 2), rows with label < 0 or >= V ignored
+// (CrossEntropyLoss(ignore_index=-1), vl:1247-1251): loss[0] = sum / max(count, 1);
+// dlogits[m, v] = (softmax - onehot) / max(count, 1), 0 for ignored rows.  One workgroup.
+__global__ __launch_bounds__(256) void ce_mean_small_kernel(const float* logits, int64_t ld, const int64_t* labels, int M, int V,
+                                                             float* loss, float* dlogits) {
+  __shared__ float red[256];
+  __shared__ int cnt[256];
+  float s = 0.f;
+  int c = 0;
+  for (int m = threadIdx.x; m < M; m += 256) {
+    const int64_t lab = labels[m];
+    if (lab < 0 || lab >= V) continue;
+    const float* x = logits + (int64_t)m * ld;
+    float mx = x[0];
+    for (int v = 1; v < V; ++v) mx = fmaxf(mx, x[v]);
+    float se = 0.f;
+    for (int v = 0; v < V; ++v) se += __expf(x[v] - mx);
+    s += mx + logf(se) - x[lab];
+    ++c;
+  }
+  red[threadIdx.x] = s;
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      cnt[threadIdx.x] += cnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const float inv = 1.f / (float)max(cnt[0], 1);
+  if (threadIdx.x == 0) loss[0] = red[0] * inv;
+  if (dlogits == nullptr) return;
+  for (int m = threadIdx.x; m < M; m += 256) {
+    const int64_t lab = labels[m];
+    const bool ok = lab >= 0 && lab < V;
+    const float* x = logits + (int64_t)m * ld;
+    float mx = x[0];
+    for (int v = 1; v < V; ++v) mx = fmaxf(mx, x[v]);
+    float se = 0.f;
+    for (int v = 0; v < V; ++v) se += __expf(x[v] - mx);
+    const float r = 1.f / se;
+    for (int v = 0; v < V; ++v)
+      dlogits[(int64_t)m * V + v] = ok ? (__expf(x[v] - mx) * r - ((int64_t)v == lab ? 1.f : 0.f)) * inv : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_t* labels, int M, int V, float* loss,
+                                   float* dlogits, void* stream) {
+  if (M <= 0 || V <= 0 || V > 64 || ld < V || !logits || !labels || !loss) MVPTR_FAIL(MVPTR_BAD_ARG, "ce_mean_small: bad argument (V <= 64)");
+  hipLaunchKernelGGL(ce_mean_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, M, V, loss, dlogits);
+  MVPTR_CHECK_LAUNCH("ce_mean_small");
+  return MVPTR_OK;
+}

@@ -604,46 +604,6 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int64_
   }
 }
 
-// ------------------------------------------------------------------------------------- AdamW
-__global__ __launch_bounds__(256) void adamw_multi_kernel(const mvptr_adamw_tensor* table,
-                                                           const int32_t* chunk_tensor,
-                                                           const int64_t* chunk_offset, int chunk,
-                                                           float b1, float b2, float eps) {
-  const mvptr_adamw_tensor t = table[chunk_tensor[blockIdx.x]];
-  const int64_t off = chunk_offset[blockIdx.x];
-  const int64_t cnt = min((int64_t)chunk, t.n - off);
-  float* p = t.p + off;
-  const float* g = t.g + off;
-  float* m = t.m + off;
-  float* v = t.v + off;
-  const float c1 = 1.f - b1, c2 = 1.f - b2;
-  const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
-  const int64_t nvec = al ? (cnt >> 2) : 0;
-  for (int64_t i = threadIdx.x; i < nvec; i += 256) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mm[e] = b1 * mm[e] + c1 * gg[e];
-      vv[e] = b2 * vv[e] + c2 * gg[e] * gg[e];
-      pp[e] = (pp[e] - t.step_size * (mm[e] / (sqrtf(vv[e]) + eps))) * t.decay;
-    }
-    reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
-  }
-  for (int64_t i = nvec * 4 + threadIdx.x; i < cnt; i += 256) {
-    const float gg = g[i];
-    const float mm = b1 * m[i] + c1 * gg;
-    const float vv = b2 * v[i] + c2 * gg * gg;
-    m[i] = mm;
-    v[i] = vv;
-    p[i] = (p[i] - t.step_size * (mm / (sqrtf(vv) + eps))) * t.decay;
-  }
-}
-
 thread_local char g_err[512] = {0};
 
 }  // namespace
@@ -905,14 +865,3 @@ extern "C" int mvptr_ce_bwd(const float* logits, int64_t ld, const int64_t* labe
   return MVPTR_OK;
 }
 
-extern "C" int mvptr_adamw_multi(const mvptr_adamw_tensor* table, const int32_t* chunk_tensor,
-                                 const int64_t* chunk_offset, int n_chunks, int chunk_elems,
-                                 float beta1, float beta2, float eps, void* stream) {
-  if (n_chunks <= 0 || chunk_elems <= 0 || (chunk_elems & 3))
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "adamw_multi: n_chunks > 0 and chunk_elems a positive multiple of 4 required");
-  if (!table || !chunk_tensor || !chunk_offset) MVPTR_FAIL(MVPTR_BAD_ARG, "adamw_multi: NULL argument");
-  hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table,
-                     chunk_tensor, chunk_offset, chunk_elems, beta1, beta2, eps);
-  MVPTR_CHECK_LAUNCH("adamw_multi");
-  return MVPTR_OK;
-}

@@ -1,5 +1,5 @@
-"""Data-parallel gradient exchange: one process per GPU, image-text pairs sharded across ranks,
-gradients averaged with bucketed all-reduce on RCCL (backend 'nccl' on ROCm) over xGMI,
+"""Gradient arena + data-parallel gradient exchange: one process per GPU, image-text pairs sharded
+across ranks, gradients averaged with bucketed all-reduce on RCCL (backend 'nccl' on ROCm) over xGMI,
 overlapped with the backward pass.
 
 Replaces what DeepSpeed ZeRO-2 / DDP did implicitly for the reference
@@ -9,99 +9,147 @@ as in the reference (no feature all-gather, modeling_vlbert.py:525-534), so the 
 is the only per-step collective.
 
 Design
-  * gradients live in flat f32 bucket buffers (>= `bucket_mb` MiB each, filled in reverse parameter
-    order = the order backward finishes them); every p.grad is a view into its bucket, so autograd
-    accumulates straight into the communication buffer and nothing is copied before or after;
+  * GRADIENT ARENA (every world size, 1 included): gradients live in flat f32 bucket buffers
+    (>= `bucket_mb` MiB each, filled in reverse parameter order = the order backward finishes them);
+    every p.grad is a view into its bucket.  The HIP autograd functions (mvp_pytorch_amd.engine) ask
+    for the arena of a parameter (`direct`) or of a whole encoder layer (`arena`: the layer's sixteen
+    gradients are laid out back to back in the order of mvptr_layer_grads, include/mvptr.h) and let
+    the kernels accumulate straight into it — no per-layer zero fill, no gradient copy, no
+    AccumulateGrad add — then report `delivered(p)`.  Everything else reaches the arena through
+    autograd's in-place accumulation into p.grad.  One zero fill per bucket per step;
   * HOT and COLD buckets.  A parameter is hot once ANY rank has produced a gradient for it (the
     used-parameter bitmap below is all-reduced, so every rank holds the same hot set).  Hot buckets
-    hold hot parameters only: a post-accumulate-grad hook per parameter counts readiness and, when the
-    last one of a bucket has landed, its all-reduce is launched asynchronously while the remaining
-    backward kernels keep running.  Parameters that have never produced a gradient (qa_head when
-    qa_ans is None, modeling_vlbert.py:1184; a data-conditional head before its first use) sit in
-    cold buckets, which are only reduced in finish() — so a parameter that produces its FIRST
-    gradient in any later step is still exchanged correctly (it is promoted to hot afterwards), and a
-    never-used parameter cannot hold back the overlap of the others.  In the first step nothing is
+    hold hot parameters only: readiness is counted per parameter (post-accumulate-grad hook or
+    `delivered`) and, when the last one of a bucket has landed, its all-reduce is launched
+    asynchronously while the remaining backward kernels keep running.  Parameters that have never
+    produced a gradient (qa_head when qa_ans is None, modeling_vlbert.py:1184; a data-conditional head
+    before its first use) sit in cold buckets, which are only reduced in finish() — so a parameter that
+    produces its FIRST gradient in any later step is still exchanged correctly (it is promoted to hot
+    afterwards), and a never-used parameter cannot hold back the overlap of the others.  A hot
+    parameter that no rank has used for `demote_after` consecutive steps goes back to cold (the
+    decision comes from the all-reduced bitmap, so it is the same on every rank); a step whose hot
+    launches stalled before finish() is counted in `stalled_steps`.  In the first step nothing is
     known yet and every bucket is reduced in finish();
   * buckets are launched strictly in index order on every rank (a ready bucket waits for its
     predecessors, as DDP does): which hot parameters receive a gradient in a given step can differ
     between ranks (a shard without a masked tag row skips half_mlm), and collectives on one
     communicator must be issued in the same order everywhere; finish() launches whatever is left;
-  * `comm_dtype=torch.bfloat16` (default under RCCL): each bucket is rounded to bf16 for the wire
-    and the averaged result converted back into the f32 bucket — half the xGMI bytes (0.49 instead of
-    0.98 GB per step for BiBertImgForPreTraining).  The reference exchanged fp16 gradients under
-    DeepSpeed; bf16 keeps f32's exponent range, so no loss scaling is involved;
-  * ROW-SPARSE parameters (`sparse_rows=[...]`, the 86 051 x 768 word-embedding table whose f32
-    gradient is 264 MB and is produced LAST, so it cannot overlap the backward pass): each gets a
+  * wire format: f32 by default.  `comm_dtype=torch.bfloat16` is an opt-in: each bucket is rounded to
+    bf16 for the wire and the averaged result converted back into the f32 bucket — half the xGMI bytes
+    (0.49 instead of 0.98 GB per step for BiBertImgForPreTraining) at 8 mantissa bits per summand (the
+    reference exchanged fp16 under DeepSpeed);
+  * ROW-SPARSE parameters (`sparse_rows=[...]`, opt-in; the 86 051 x 768 word-embedding table whose
+    f32 gradient is 264 MB and is produced LAST, so it cannot overlap the backward pass): each gets a
     bucket of its own; when the step has told the exchange which rows were looked up
     (note_rows(param, ids): token, phrase and tag ids of the rank's shard), the ranks all-gather their
     unique row ids, every rank forms the same sorted union, and only those rows are all-reduced (a
     compact [U, H] buffer in the wire dtype) and scattered back; rows outside the union are zero on
     every rank already.  A rank without noted ids (or a caller that never calls note_rows) makes all
-    ranks fall back to the dense all-reduce of that bucket for the step, so the result never depends
-    on the optimisation;
+    ranks fall back to the dense all-reduce of that bucket for the step.  PRECONDITION: every gradient
+    row of the table comes from the noted lookups — a table that is tied to another module's weight
+    (BertImgForPreTraining ties the MLM decoder to it, modeling_vlbert.py:1095-1100) gets a dense
+    gradient and is rejected here.  The union needs two small blocking all-gathers and host reads
+    inside the launch, which is why it is not the default;
   * one backward per zero_grad(), or gradient accumulation inside `with sync.no_sync():` for all but
     the last backward — a second backward outside no_sync() would add into buckets that are already
     being reduced and raises.
+`force_collectives=True` runs the whole exchange (hooks, bucket launches, wire conversion, row union,
+used-parameter bitmap) on a process group of ONE rank: the RCCL code path on a single GPU
+(tests/test_dp_gpu.py).
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of S bytes moves 2*(7/8)*S
-per GPU at the per-link rate, ~5.6 ms for 0.49 GB on one ring if it were not overlapped (RCCL runs
-several rings/trees over the links in parallel; the multi-GPU curve of this design has not been
-measured by the builder: no multi-GPU box was available).
+per GPU at the per-link rate, ~11 ms for 0.98 GB on one ring if it were not overlapped (RCCL runs
+several rings/trees over the links in parallel).
 """
 import contextlib
 
 import torch
 import torch.distributed as dist
 
+from . import engine
+
 
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="auto", sparse_rows=()):
+    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype=torch.float32, sparse_rows=(),
+                 force_collectives=False, demote_after=8):
         self.group = process_group
-        self.sparse = {p for p in sparse_rows if p.requires_grad and p.dim() == 2}
-        self._rows = {}           # row-sparse parameter -> list of id tensors noted for this step
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force_collectives and not dist.is_initialized():
+            raise RuntimeError("GradSync(force_collectives=True) needs an initialised process group")
+        self.exchange = self.world > 1 or force_collectives   # collectives are issued
         self.overlap = overlap
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.index = {p: i for i, p in enumerate(self.params)}
+        self.sparse = {p for p in sparse_rows if p.requires_grad and p.dim() == 2}
+        for p in self.sparse:
+            owners = sum(1 for m in model.modules() for q in m._parameters.values() if q is p)
+            if owners > 1:
+                raise ValueError("GradSync: a row-sparse parameter is shared by %d modules (tied weights): its gradient is "
+                                 "dense, exchange it densely" % owners)
+        self._rows = {}           # row-sparse parameter -> list of id tensors noted for this step
         self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
-        if comm_dtype == "auto":
-            comm_dtype = torch.bfloat16 if backend == "nccl" else torch.float32
-        self.comm_dtype = comm_dtype
+        self.comm_dtype = torch.float32 if comm_dtype in (None, "auto") else comm_dtype
         self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
+        self._idle = {}           # hot parameter -> consecutive steps without a gradient on any rank
+        self.demote_after = demote_after
+        self.stalled_steps = 0    # steps whose hook launches stopped short of the hot buckets
         self._accumulating = False
         self._rebuild = False
+        # parameter groups whose gradients the kernels want back to back in a fixed order (encoder layers)
+        self._model_units = []
+        claimed = set()
+        for m in model.modules():
+            fn = getattr(m, "grad_arena_units", None)
+            if fn is None:
+                continue
+            for u in fn():
+                u = list(u)
+                if u and all((p in self.index) and (p not in claimed) and (p not in self.sparse) for p in u):
+                    self._model_units.append(u)
+                    claimed.update(u)
         self._build()
-        if self.world > 1:
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        engine.set_grad_sink(self)
         self.zero_grad()
 
     # ------------------------------------------------------------------ bucket layout
     def _build(self):
-        """(Re)build the buckets: hot parameters in reverse order (early-launchable), then cold ones."""
+        """(Re)build the buckets: hot units in reverse order (early-launchable), then cold ones."""
         self.buckets = []        # dicts: flat, items [(param, offset, numel)], hot, pending, work, ...
         self.where = {}          # param -> bucket index
         self.span = {}           # param -> (offset, numel, address of its view)
-        hot = [p for p in reversed(self.params) if self._hot is not None and p in self._hot]
-        cold = [p for p in reversed(self.params) if self._hot is None or p not in self._hot]
-        for group, is_hot in ((hot, True), (cold, False)):
+        self.unit_at = {}        # first parameter of a multi-parameter unit -> (unit, bucket index, offset, numel)
+        claimed = set()
+        units = []
+        for u in self._model_units:
+            units.append(u)
+            claimed.update(u)
+        units += [[p] for p in self.params if p not in claimed]
+        units.sort(key=lambda u: -max(self.index[p] for p in u))
+        is_hot = lambda u: self._hot is not None and any(p in self._hot for p in u)   # noqa: E731
+        for group, hot in (([u for u in units if is_hot(u)], True), ([u for u in units if not is_hot(u)], False)):
             cur, cur_n = [], 0
-            for p in group:
-                if p in self.sparse:      # a bucket of its own, exchanged by rows
+            for u in group:
+                n_u = sum(p.numel() for p in u)
+                if len(u) == 1 and u[0] in self.sparse:      # a bucket of its own, exchanged by rows
                     if cur:
-                        self._close(cur, cur_n, is_hot)
+                        self._close(cur, cur_n, hot)
                         cur, cur_n = [], 0
-                    self._close([(p, 0, p.numel())], p.numel(), is_hot)
-                    self.buckets[-1]["rows_of"] = p
+                    self._close([(u[0], 0, n_u)], n_u, hot)
+                    self.buckets[-1]["rows_of"] = u[0]
                     continue
-                if cur and cur_n + p.numel() > self.cap:
-                    self._close(cur, cur_n, is_hot)
+                if cur and cur_n + n_u > self.cap:
+                    self._close(cur, cur_n, hot)
                     cur, cur_n = [], 0
-                cur.append((p, cur_n, p.numel()))
-                cur_n += p.numel()
+                if len(u) > 1:
+                    self.unit_at[u[0]] = (u, len(self.buckets), cur_n, n_u)
+                for p in u:
+                    cur.append((p, cur_n, p.numel()))
+                    cur_n += p.numel()
             if cur:
-                self._close(cur, cur_n, is_hot)
+                self._close(cur, cur_n, hot)
         self.n_hot = sum(1 for b in self.buckets if b["hot"])
 
     def _close(self, items, n, is_hot):
@@ -113,6 +161,10 @@ class GradSync:
         for p, off, k in items:
             self.where[p] = idx
             self.span[p] = (off, k, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
+
+    def flats(self):
+        """The flat f32 gradient buffers (global-norm clipping reads these instead of ~400 tensors)."""
+        return [b["flat"] for b in self.buckets]
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
@@ -133,7 +185,10 @@ class GradSync:
                 if p.grad is None or p.grad.data_ptr() != view.data_ptr():
                     p.grad = view
             b["pending"] = len(b["items"])
-        self._ready = set()
+        self._ready = set()       # parameters counted towards their bucket's readiness in the exchanging backward
+        self._touched = set()     # parameters that received a gradient in ANY backward of this step
+        self._uses, self._done = {}, {}   # direct delivery: uses noted in forward passes / deliveries so far
+        self._hook_skip = set()           # parameters whose next post-accumulate hook repeats a completed direct delivery
         self._rows = {}
         self._next = 0            # buckets [0, _next) have been launched this step
 
@@ -141,8 +196,8 @@ class GradSync:
         """Tell the exchange which rows of a row-sparse parameter this rank's step looks up (every id
         tensor that indexes the table: call once per tensor or pass a list), BEFORE the backward pass
         (a hot bucket is launched from the hook of its last gradient).  Without it the bucket is
-        reduced densely."""
-        if self.world == 1 or param not in self.sparse:
+        reduced densely.  Every gradient row of the table must come from the noted lookups."""
+        if not self.exchange or param not in self.sparse:
             return
         ids = ids if isinstance(ids, (list, tuple)) else [ids]
         self._rows.setdefault(param, []).extend(t.reshape(-1) for t in ids if t is not None)
@@ -185,21 +240,76 @@ class GradSync:
         finally:
             self._accumulating = False
 
+    # ---- engine protocol: kernels that accumulate straight into the arena -----------------------------
+    def direct(self, p):
+        """The arena view to accumulate p's gradient into (p.grad itself), or None when p is not laid out here."""
+        sp = self.span.get(p)
+        g = p.grad
+        if sp is None or g is None or g.data_ptr() != sp[2]:
+            return None
+        return g
+
+    def arena(self, params):
+        """Flat f32 view holding the gradients of `params` back to back in exactly that order, or None."""
+        ent = self.unit_at.get(params[0])
+        if ent is None:
+            return None
+        u, idx, off, n = ent
+        if len(u) != len(params) or any(a is not b for a, b in zip(u, params)):
+            return None
+        if any(self.direct(p) is None for p in params):
+            return None
+        return self.buckets[idx]["flat"][off:off + n]
+
+    def note_use(self, p):
+        """Forward pass: an autograd function that may deliver p's gradient directly has used p.  A parameter used
+        by several function calls of one graph (the word table: text and tag lookups; the embedding LayerNorm) is
+        ready for the exchange only when ALL of them have delivered — autograd's AccumulateGrad node gives that for
+        free (it runs once, after every contribution has arrived), direct delivery has to count."""
+        if self.exchange:
+            self._uses[p] = self._uses.get(p, 0) + 1
+
+    def delivered(self, p):
+        """A kernel has queued p's gradient into the arena on the current stream (the engine's replacement for
+        the AccumulateGrad node + hook of a gradient that autograd never sees)."""
+        if self.exchange:
+            d = self._done.get(p, 0) + 1
+            self._done[p] = d
+            if d < self._uses.get(p, 0):
+                self._note(p, final=False)
+                return
+            # this torch runs the parameter's AccumulateGrad node (and so its post-accumulate hook) even when every
+            # function returned None for it: that one call is this delivery seen again, not a new gradient
+            self._hook_skip.add(p)
+        self._note(p)
+
+    # ---------------------------------------------------------------------------------------------------
     def _hook(self, p):
-        if self.world == 1:
+        if p in self._hook_skip:
+            self._hook_skip.discard(p)
             return
-        idx = self.where[p]
-        b = self.buckets[idx]
         off, n, ptr = self.span[p]
         if p.grad.data_ptr() != ptr:
             # autograd replaced the view (e.g. dtype change): copy into the bucket, re-attach
+            b = self.buckets[self.where[p]]
             b["flat"][off:off + n].copy_(p.grad.reshape(-1))
             p.grad = b["flat"][off:off + n].view_as(p)
+        self._note(p)
+
+    def _note(self, p, final=True):
+        self._touched.add(p)      # also under no_sync(): a head used only in the accumulation micro-batches is "used"
+        if not self.exchange:
+            return
+        idx = self.where[p]
+        b = self.buckets[idx]
         if p.grad.is_cuda:
-            # the gradient was produced on the stream current in this hook (sub-networks may run on a
-            # side stream, engine.side_stream): remember which streams fed this bucket
+            # the gradient was produced on the stream current here (sub-networks may run on a side
+            # stream, engine.side_stream): remember which streams fed this bucket
             b["streams"].add(torch.cuda.current_stream(p.grad.device))
-        if self._accumulating:
+        if idx < self._next and not self._accumulating:
+            raise RuntimeError("GradSync: a gradient arrived for a bucket that is already being reduced — run one "
+                               "backward per zero_grad(), or wrap all but the last backward in `with sync.no_sync():`")
+        if self._accumulating or not final:
             return
         if idx < self._next:
             raise RuntimeError("GradSync: a gradient arrived for a bucket that is already being reduced — run one "
@@ -236,16 +346,23 @@ class GradSync:
 
     def __call__(self):
         """Finish the step's exchange: launch the buckets that are still waiting (in index order on
-        every rank), wait for all of them, scale if the backend summed."""
-        if self.world == 1:
+        every rank), wait for all of them, scale if the backend summed.  Parameters that received no
+        gradient (on any rank) end with grad = None, as under DDP find_unused_parameters
+        (run_pretrain_ml.py:415-418) and as without an arena: the optimizer skips them."""
+        if not self.exchange:
+            for p in self.params:
+                if p not in self._touched:
+                    p.grad = None
             return
+        if self._hot is not None and self._next < self.n_hot:
+            self.stalled_steps += 1       # some hot bucket never became ready from the hooks: no overlap behind it
         for idx in range(self._next, len(self.buckets)):
             self._launch(idx)
         # which parameters produced a gradient on ANY rank (DDP's used-parameter bitmap): those keep
         # the averaged gradient on every rank, the others keep grad = None everywhere, so replicas
         # apply identical updates even when a shard skipped a head
         dev = self.buckets[0]["flat"].device
-        used = torch.tensor([1 if p in self._ready else 0 for p in self.params], dtype=torch.int32).to(dev)
+        used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32).to(dev)
         used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             b["work"].wait()
@@ -268,16 +385,23 @@ class GradSync:
             b["wire"] = None
         used_work.wait()
         used = used.tolist()
-        # parameters no rank produced a gradient for keep grad = None, as under DDP with
-        # find_unused_parameters=True (run_pretrain_ml.py:415-418): the optimizer skips them
         for p, u in zip(self.params, used):
             if not u:
                 p.grad = None
-        # hot set = every parameter that has EVER produced a gradient on any rank (identical on all
-        # ranks: it is derived from the all-reduced bitmap only).  One that is missing in some step
-        # only delays launches to finish(); a newly used one moves its bucket layout at the next step.
+        # hot set = every parameter that has produced a gradient on any rank and has not been idle for
+        # `demote_after` steps since (identical on all ranks: derived from the all-reduced bitmap only).
+        # One that is missing in some step only delays launches to finish(); a change moves the bucket
+        # layout at the next zero_grad().
         now = {p for p, u in zip(self.params, used) if u}
-        hot = now if self._hot is None else (self._hot | now)
+        hot = set(now) if self._hot is None else (self._hot | now)
+        for p in list(hot):
+            if p in now:
+                self._idle[p] = 0
+            else:
+                self._idle[p] = self._idle.get(p, 0) + 1
+                if self._idle[p] >= self.demote_after:
+                    hot.discard(p)
+                    self._idle.pop(p, None)
         if hot != self._hot:
             self._hot = hot
             self._rebuild = True

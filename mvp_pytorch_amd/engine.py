@@ -49,6 +49,79 @@ class GradAwareFunction(torch.autograd.Function):
 def _caller_grad_enabled():
     g = getattr(_tls, "outer_grad", None)
     return torch.is_grad_enabled() if g is None else g
+
+
+# Gradient arena (mvp_pytorch_amd.dp.GradSync): when one is registered, the autograd functions below let the
+# kernels accumulate weight gradients straight into the arena views that are the parameters' .grad and report
+# `delivered(p)` instead of handing autograd a fresh tensor per parameter (a zero fill, a copy and an
+# AccumulateGrad add per gradient otherwise).  Held weakly: a sink dies with its owner.
+_grad_sink_ref = [None]
+
+
+def set_grad_sink(sink):
+    import weakref
+    _grad_sink_ref[0] = None if sink is None else weakref.ref(sink)
+
+
+def grad_sink():
+    r = _grad_sink_ref[0]
+    return None if r is None else r()
+
+
+def note_uses(ctx, params, first_index):
+    """Called from an autograd function's forward: tell the gradient arena which parameters this call will deliver a
+    gradient for (params[i] is input first_index + i of the function; ctx.needs_input_grad says whether autograd wants
+    it — all False under no_grad), see dp.GradSync.note_use."""
+    sink = grad_sink()
+    if sink is None:
+        return
+    needs = ctx.needs_input_grad
+    for i, p in enumerate(params):
+        if p is not None and needs[first_index + i]:
+            sink.note_use(p)
+
+
+def grad_buffer(p, shape=None):
+    """-> (f32 buffer the kernels ACCUMULATE p's gradient into, True when it is the arena view p.grad)."""
+    sink = grad_sink()
+    if sink is not None and p is not None and p.requires_grad and p.dtype == torch.float32:
+        g = sink.direct(p)
+        if g is not None and g.is_contiguous() and (shape is None or tuple(g.shape) == tuple(shape)):
+            return g, True
+    return torch.zeros(tuple(p.shape) if shape is None else tuple(shape), device=p.device, dtype=torch.float32), False
+
+
+def grad_result(p, buf, direct):
+    """What backward returns for p: None when the kernels wrote into the arena (the sink is told), else the buffer."""
+    if direct:
+        grad_sink().delivered(p)
+        return None
+    return buf
+
+
+# bf16 working copies that the fused optimizer keeps current (optimization.AdamW writes them in the same pass
+# that updates the f32 master weight, mvptr_adamw_mirror_multi): parameter -> where its copies live and which
+# WeightCache they belong to.  Keyed by id() (tensors do not work as weak dictionary keys: == is elementwise).
+_MIRRORS = {}
+
+
+def register_mirror(p, cache, dst=None, dst_t=None, col_off_t=0, dst_f32=None):
+    import weakref
+    if not (isinstance(p, torch.Tensor) and p.dtype == torch.float32 and p.is_contiguous() and p.dim() in (1, 2)):
+        return
+    key = id(p)
+    _MIRRORS[key] = dict(ref=weakref.ref(p, lambda _r, k=key: _MIRRORS.pop(k, None)), cache=weakref.ref(cache),
+                         dst=dst, dst_t=dst_t, col_off_t=col_off_t, dst_f32=dst_f32)
+    cache._mirror_ids.add(key)
+
+
+def mirror_of(p):
+    m = _MIRRORS.get(id(p))
+    if m is None or m["ref"]() is not p:
+        return None
+    return m
+
+
 _seed_counter = [0x5DEECE66D]
 
 
@@ -91,7 +164,9 @@ class WeightCache:
 
     def __init__(self):
         self._key = None
-        self._fresh_once = False  # set by a prefetch: the next stale() of the same parameters answers "fresh" once
+        self._fresh_once = False  # set by a prefetch / the fused optimizer: the next stale() of the same parameters answers "fresh" once
+        self._prefs = None        # weak references to the parameters of the last stale() call (mark_fresh recomputes the key)
+        self._mirror_ids = set()  # parameters whose copies in this cache the fused optimizer can write (register_mirror)
         self.t = {}
         self._dev = None        # device this object serves (set at first use)
         self._children = {}     # other devices' caches (replicas of the owning module under DataParallel)
@@ -118,6 +193,9 @@ class WeightCache:
         if force is None:
             force = _caller_grad_enabled() and any(p.requires_grad for p in params)
         key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._prefs is None or len(self._prefs) != len(params) or any(r() is not p for r, p in zip(self._prefs, params)):
+            import weakref
+            self._prefs = [weakref.ref(p) for p in params]
         if self._fresh_once:
             # the copies were rebuilt earlier in THIS forward pass (EncoderPacks.prefetch, on the side stream beside the
             # embedding kernels): do not rebuild them again
@@ -129,8 +207,37 @@ class WeightCache:
             return True
         return False
 
+    def mark_fresh(self):
+        """The copies were just rewritten from the current parameter values by the optimizer kernel: the next
+        stale() of the same parameters answers "fresh" once (later ones fall back to the usual rules)."""
+        if self._prefs is None:
+            return
+        ps = [r() for r in self._prefs]
+        if any(p is None for p in ps):
+            return
+        self._key = tuple((p.data_ptr(), p._version) for p in ps)
+        self._fresh_once = True
+
+    def weight_copies(self, weight, want_t=True, kpad=None):
+        """bf16 [N, Kp] (+ transposed [K, Np]) copies of one f32 [N, K] weight in PERSISTENT buffers (registered as
+        mirrors, so the fused optimizer refreshes them in its own pass) -> (w, wt or None)."""
+        if self.stale([weight]):
+            N, K = weight.shape
+            Kp = pad8(K) if kpad is None else kpad
+            w, wt = self.t.get("w"), self.t.get("wt")
+            if w is None or w.shape != (N, Kp) or w.device != weight.device:
+                w = torch.empty((N, Kp), device=weight.device, dtype=torch.bfloat16)
+                alloc_t = torch.empty if N % 8 == 0 else torch.zeros   # only pad columns need the zeros
+                wt = alloc_t((K, pad8(N)), device=weight.device, dtype=torch.bfloat16) if want_t else None
+                self.t["w"], self.t["wt"] = w, wt
+                if weight.dtype == torch.float32 and weight.is_contiguous():
+                    register_mirror(weight, self, dst=w, dst_t=wt)
+            hip.cast_pack(_f32(weight), dst=w, dst_t=wt)
+        return self.t["w"], self.t.get("wt")
+
     def invalidate(self):
         self._key = None
+        self._fresh_once = False
         for c in self._children.values():
             c.invalidate()
 
@@ -267,12 +374,17 @@ class EncoderPacks:
             for i, (w, b) in enumerate(((qw, qb), (kw, kb), (vw, vb))):
                 plan.add(w.data, dst=w_qkv[i * H:(i + 1) * H], dst_t=w_qkv_t, col_off_t=i * H)
                 plan.add(b.data, dst_f32=b_qkv[i * H:(i + 1) * H])
+                register_mirror(w, self.cache, dst=w_qkv[i * H:(i + 1) * H], dst_t=w_qkv_t, col_off_t=i * H)
+                register_mirror(b, self.cache, dst_f32=b_qkv[i * H:(i + 1) * H])
             w_o, w_o_t = torch.empty((H, H), device=dev, dtype=bf), torch.empty((H, H), device=dev, dtype=bf)
             w_i, w_i_t = torch.empty((I, H), device=dev, dtype=bf), torch.empty((H, I), device=dev, dtype=bf)
             w_out, w_out_t = torch.empty((H, I), device=dev, dtype=bf), torch.empty((I, H), device=dev, dtype=bf)
             plan.add(ow.data, dst=w_o, dst_t=w_o_t)
             plan.add(iw.data, dst=w_i, dst_t=w_i_t)
             plan.add(pw.data, dst=w_out, dst_t=w_out_t)
+            register_mirror(ow, self.cache, dst=w_o, dst_t=w_o_t)
+            register_mirror(iw, self.cache, dst=w_i, dst_t=w_i_t)
+            register_mirror(pw, self.cache, dst=w_out, dst_t=w_out_t)
             lw = hip.LayerWeights()
             lw.w_qkv, lw.w_qkv_t, lw.b_qkv = w_qkv.data_ptr(), w_qkv_t.data_ptr(), b_qkv.data_ptr()
             lw.w_o, lw.w_o_t, lw.b_o = w_o.data_ptr(), w_o_t.data_ptr(), ob.data_ptr()
@@ -327,30 +439,6 @@ def _thresh(p):
 # Side streams used for independent sub-networks (text / visual stack); mvp_pytorch_amd.dp waits on
 # them before a gradient bucket is handed to RCCL.
 SIDE_STREAMS = {}
-# Weight gradients of an encoder stack on a stream of their own (EncoderFn.backward, mvptr_encoder_layer_bwd2): opt-in
-# (MVPTR_WGRAD_ASIDE=1, optionally only for stacks of at most MVPTR_WGRAD_ASIDE_MAX_ROWS rows).  Measured on the
-# training step: -0.3 ms on one box and nothing on another for the variable-length batch, +0.4 ms (worse) with all
-# slots valid — the weight-gradient kernel owns a CU's whole register file and LDS, so "beside" means fewer CUs for
-# the data-gradient chain, which only pays where that chain leaves CUs idle (profiles/r02_experiments.txt).
-WGRAD_ASIDE = os.environ.get("MVPTR_WGRAD_ASIDE", "0") == "1"
-WGRAD_ASIDE_MAX_ROWS = int(os.environ.get("MVPTR_WGRAD_ASIDE_MAX_ROWS", "1000000"))
-
-
-WGRAD_STREAMS = {}
-
-
-def wgrad_stream(device, parent):
-    """The stream on which a stack's weight-gradient GEMMs run beside the rest of its backward pass: one per
-    (device, stream the backward pass itself runs on) — the text and visual stacks run their backward passes on
-    two streams at once."""
-    dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), parent.cuda_stream)
-    with _state_lock:
-        if key not in WGRAD_STREAMS:
-            WGRAD_STREAMS[key] = torch.cuda.Stream(device=key[0])
-        return WGRAD_STREAMS[key]
-
-
 def side_stream(device):
     """One extra HIP stream per device, created on first use."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
@@ -358,36 +446,6 @@ def side_stream(device):
         if key not in SIDE_STREAMS:
             SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
         return SIDE_STREAMS[key]
-
-
-class small_f32_blas:
-    """Scope in which torch's matrix products go to rocBLAS.  hipBLASLt, torch's default BLAS on this ROCm
-    build, serves the step's [256, 768] x [768, 256] f32 global projections and the 256 x 256
-    similarity matrix with ONE 256 x 256 tile = one workgroup (173 us and 63 us; rocBLAS: 7 and 8 us,
-    tools/small_mm.py).  The switch is process-wide in torch, so the scope is reference-counted under
-    the module lock: the previous setting comes back when the last concurrent user (nn.DataParallel
-    replicas run their forward passes in threads) leaves.  MVPTR_KEEP_BLAS=1 disables it."""
-    _depth = 0
-    _saved = None
-
-    def __enter__(self):
-        if os.environ.get("MVPTR_KEEP_BLAS") == "1" or not getattr(torch.version, "hip", None):
-            return self
-        with _state_lock:
-            if small_f32_blas._depth == 0:
-                small_f32_blas._saved = torch.backends.cuda.preferred_blas_library()
-                torch.backends.cuda.preferred_blas_library("cublas")      # = rocBLAS on ROCm
-            small_f32_blas._depth += 1
-        self._entered = True
-        return self
-
-    def __exit__(self, *exc):
-        if getattr(self, "_entered", False):
-            with _state_lock:
-                small_f32_blas._depth -= 1
-                if small_f32_blas._depth == 0:
-                    torch.backends.cuda.preferred_blas_library(small_f32_blas._saved)
-        return False
 
 
 class AsyncCounts:
@@ -491,7 +549,12 @@ class EncoderFn(GradAwareFunction):
             xs.append(y)
         ctx.meta, ctx.descs, ctx.stashes, ctx.xs, ctx.mask = meta, descs, stashes, xs, mask_add
         ctx.params = params
+        note_uses(ctx, params, 3)
         return cur
+
+    # order of a layer's sixteen parameters (LayerPack.NAMES positions) inside its gradient arena = the order of
+    # mvptr_layer_grads: [Wq;Wk;Wv] [bq;bk;bv] Wo bo ln1.g ln1.b Wi bi Wout bout ln2.g ln2.b
+    ARENA_ORDER = (0, 2, 4, 1, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
 
     @staticmethod
     def backward(ctx, dy):
@@ -500,57 +563,54 @@ class EncoderFn(GradAwareFunction):
         n = len(meta.packs)
         dev = dy.device
         H, I = meta.H, meta.I
-        main = torch.cuda.current_stream()
-        stream = ctypes.c_void_p(main.cuda_stream)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         ws_bytes = lib.mvptr_layer_workspace_bytes(ctypes.byref(ctx.descs[0]))
-        # Weight gradients beside the data-gradient chain: a layer's two grouped weight-gradient launches only feed the
-        # optimizer, so they go to a stream of their own (mvptr_encoder_layer_bwd2 orders them behind the kernels
-        # that produce their operands) and run beside the next kernels of the chain — LayerNorm / attention backward,
-        # which leave the matrix pipes idle, and the partly filled last rounds of the N = 768 data-gradient GEMMs.
-        # Their operands live in the workspace and the stash: two workspaces alternate, and a layer waits for the
-        # weight gradients of the layer two before it (same workspace); the streams join at the end.
-        aside = WGRAD_ASIDE and n > 1 and dy.shape[0] <= WGRAD_ASIDE_MAX_ROWS
-        aux = wgrad_stream(dev, main) if aside else None
-        wss = [torch.empty(ws_bytes, device=dev, dtype=torch.uint8) for _ in range(2 if aside else 1)]
-        done = []
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
         total = sum(sizes)
         grads = [None] * (16 * n)
+        sink = grad_sink()
         d_cur = dy.contiguous()
-        for k, li in enumerate(reversed(range(n))):
-            ws = wss[k % len(wss)]
-            if aside and k >= 2:
-                main.wait_event(done[k - 2])
-            flat = torch.zeros(total, device=dev, dtype=torch.float32)
-            parts, o = [], 0
-            for s in sizes:
-                parts.append(flat[o:o + s])
-                o += s
+        for li in reversed(range(n)):
+            ps = ctx.params[16 * li:16 * (li + 1)]
+            arena_ps = [ps[j] for j in EncoderFn.ARENA_ORDER]
+            # the layer's gradient arena: the sixteen .grad views back to back (dp.GradSync lays encoder layers out
+            # that way) -> the kernels accumulate into the communication / optimizer buffer itself; otherwise a
+            # zero-filled scratch arena whose pieces are handed to autograd
+            flat = None
+            if sink is not None and all(p.requires_grad and p.dtype == torch.float32 for p in ps):
+                flat = sink.arena(arena_ps)
+            direct = flat is not None
+            if not direct:
+                flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            base = flat.data_ptr()
             g = hip.LayerGrads()
-            (g.w_qkv, g.b_qkv, g.w_o, g.b_o, g.ln1_g, g.ln1_b, g.w_i, g.b_i, g.w_out, g.b_out, g.ln2_g,
-             g.ln2_b) = [p.data_ptr() for p in parts]
+            offs, o = [], 0
+            for sz in sizes:
+                offs.append(base + 4 * o)
+                o += sz
+            (g.w_qkv, g.b_qkv, g.w_o, g.b_o, g.ln1_g, g.ln1_b, g.w_i, g.b_i, g.w_out, g.b_out, g.ln2_g, g.ln2_b) = offs
             dx = torch.empty_like(d_cur)
-            hip._check(lib.mvptr_encoder_layer_bwd2(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
-                                                    hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
-                                                    hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream,
-                                                    ctypes.c_void_p(aux.cuda_stream) if aside else None))
-            if aside:
-                ev = torch.cuda.Event()
-                ev.record(aux)
-                done.append(ev)
-                for t in (flat, ws, ctx.xs[li], ctx.stashes[li]):
-                    t.record_stream(aux)
-            wq = parts[0].view(3, H, H)
-            bq = parts[1].view(3, H)
-            gl = [wq[0], bq[0], wq[1], bq[1], wq[2], bq[2], parts[2].view(H, H), parts[3], parts[4], parts[5],
-                  parts[6].view(I, H), parts[7], parts[8].view(H, I), parts[9], parts[10], parts[11]]
-            for j in range(16):
-                p = ctx.params[16 * li + j]
-                if p.requires_grad:
-                    grads[16 * li + j] = gl[j].to(p.dtype)
+            hip._check(lib.mvptr_encoder_layer_bwd(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
+                                                   hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
+                                                   hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream))
+            if direct:
+                for p in ps:
+                    sink.delivered(p)
+            else:
+                parts, o = [], 0
+                for sz in sizes:
+                    parts.append(flat[o:o + sz])
+                    o += sz
+                wq = parts[0].view(3, H, H)
+                bq = parts[1].view(3, H)
+                gl = [wq[0], bq[0], wq[1], bq[1], wq[2], bq[2], parts[2].view(H, H), parts[3], parts[4], parts[5],
+                      parts[6].view(I, H), parts[7], parts[8].view(H, I), parts[9], parts[10], parts[11]]
+                for j in range(16):
+                    p = ps[j]
+                    if p.requires_grad:
+                        grads[16 * li + j] = gl[j] if p.dtype == torch.float32 else gl[j].to(p.dtype)
             d_cur = dx
-        if aside:
-            main.wait_stream(aux)      # the gradients handed back below are complete on this stream
         ctx.stashes = ctx.xs = None
         return (d_cur, None, None) + tuple(grads)
 
@@ -593,9 +653,8 @@ class InputEmbedFn(GradAwareFunction):
             hip.cast_pack(feats.contiguous(), dst=fb)
             cache = meta["cache"]
             cache = cache.for_device(img_w.device)
-            if cache.stale([img_w]):
-                cache.t["img_w"] = cast_weight(img_w, want_t=False)[0]
-            zi = hip.gemm_nt(fb, cache.t["img_w"], hip.EPI_BIAS, bias=_f32(img_b))
+            w_img, _ = cache.weight_copies(img_w, want_t=False)
+            zi = hip.gemm_nt(fb, w_img, hip.EPI_BIAS, bias=_f32(img_b))
             p_img = meta.get("p_img", meta["p"]) if training else 0.0
             drop_i = hip.make_dropout(p_img, next_seed()) if p_img > 0 else None
             use_ln = img_ln_w is not None and meta["use_img_ln"]
@@ -608,6 +667,9 @@ class InputEmbedFn(GradAwareFunction):
         ctx.share = meta.get("share")
         ctx.shapes = (word.shape, pos.shape, typ.shape)
         ctx.needs = [t is not None and t.requires_grad for t in (word, pos, typ, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b)]
+        ctx.ps = (word, pos, typ, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b)
+        note_uses(ctx, (word, pos, typ, ln_w, ln_b, None, img_b if R > 0 else None, img_ln_w if (R > 0 and use_ln) else None,
+                        img_ln_b if (R > 0 and use_ln) else None), 5)
         return out.view(B, Ltot, H)
 
     @staticmethod
@@ -618,39 +680,55 @@ class InputEmbedFn(GradAwareFunction):
         dout = dout.contiguous().view(B * Ltot, H)
         idf, tyf, pof, z, mean, rstd, lnw, drop_t = ctx.txt
         f32 = dict(device=dev, dtype=torch.float32)
-        dg, db = torch.zeros(H, **f32), torch.zeros(H, **f32)
+        word, pos, typ, ln_w, ln_b, img_w, img_b, img_ln_w, img_ln_b = ctx.ps
+        needs = ctx.needs
+
+        def buf(p, need, shape=None):
+            # arena view (accumulated into by the kernels) or a zero-filled scratch tensor handed to autograd
+            return grad_buffer(p, shape) if need else (torch.zeros(tuple(p.shape) if shape is None else shape, **f32), False)
+
+        (dg, dg_d), (db, db_d) = buf(ln_w, needs[3]), buf(ln_b, needs[4])
         dz, _ = hip.layernorm_bwd(dout, z, mean, rstd, lnw, dg, db, None, rows_per_group=Lt,
                                   group_stride=Ltot, row_offset=0, y_drop=drop_t)
         # The word table (86 051 x 768 f32 = 264 MB) is looked up twice per forward pass (text ids, tag
-        # ids).  Both backward calls scatter into ONE zero-filled buffer (meta["share"], created per
-        # forward pass by the backbone): the second call returns no gradient of its own, which saves
-        # a 264-MB fill and the 0.8-GB add autograd would use to sum two dense gradients.
+        # ids).  With a gradient arena both backward calls scatter into the table's arena view; without
+        # one they share ONE zero-filled buffer (meta["share"], created per forward pass by the backbone)
+        # and the second call returns no gradient of its own, which saves a 264-MB fill and the 0.8-GB add
+        # autograd would use to sum two dense gradients.
         share = ctx.share
-        dword = share.get("dword") if share is not None else None
-        first = dword is None
-        if first:
-            dword = torch.zeros(ctx.shapes[0], **f32)
-            if share is not None:
-                share["dword"] = dword
-        dpos = torch.zeros(ctx.shapes[1], **f32)
-        dtyp = torch.zeros(ctx.shapes[2], **f32)
+        dword, dword_d = grad_buffer(word) if needs[0] else (None, False)
+        first = True
+        if not dword_d:
+            dword = share.get("dword") if share is not None else None
+            first = dword is None
+            if first:
+                dword = torch.zeros(ctx.shapes[0], **f32)
+                if share is not None:
+                    share["dword"] = dword
+        (dpos, dpos_d), (dtyp, dtyp_d) = buf(pos, needs[1]), buf(typ, needs[2])
         hip.embed_bwd(idf, pof, tyf, dz, dword, dpos, dtyp)
         if not first:
             dword = None
         gi_w = gi_b = gi_lw = gi_lb = None
+        gb_d = glw_d = glb_d = False
         if ctx.img is not None:
             fb, zi, mi, ri, g, drop_i, D = ctx.img
-            dbias = torch.zeros(H, **f32)
-            gi_lw = torch.zeros(H, **f32) if g is not None else None
-            gi_lb = torch.zeros(H, **f32) if g is not None else None
-            dzi, _ = hip.layernorm_bwd(dout, zi, mi, ri, g, gi_lw, gi_lb, dbias, rows_per_group=R,
+            gi_b, gb_d = buf(img_b, needs[6])
+            if g is not None:
+                (gi_lw, glw_d), (gi_lb, glb_d) = buf(img_ln_w, needs[7]), buf(img_ln_b, needs[8])
+            dzi, _ = hip.layernorm_bwd(dout, zi, mi, ri, g, gi_lw, gi_lb, gi_b, rows_per_group=R,
                                        group_stride=Ltot, row_offset=Lt, y_drop=drop_i)
-            dw = torch.zeros((H, fb.shape[1]), **f32)
+            dw = torch.zeros((H, fb.shape[1]), **f32)      # K padded to a multiple of 8: not the parameter's layout
             hip.gemm_tn(dzi, fb, dw)
-            gi_w, gi_b = dw[:, :D].contiguous(), dbias
-        outs = [dword, dpos, dtyp, dg, db, gi_w, gi_b, gi_lw, gi_lb]
-        outs = [o if need else None for o, need in zip(outs, ctx.needs)]
-        ctx.txt = ctx.img = ctx.share = None
+            gi_w = dw[:, :D].contiguous()
+        outs = [grad_result(word, dword, dword_d) if needs[0] else None,
+                grad_result(pos, dpos, dpos_d) if needs[1] else None, grad_result(typ, dtyp, dtyp_d) if needs[2] else None,
+                grad_result(ln_w, dg, dg_d) if needs[3] else None, grad_result(ln_b, db, db_d) if needs[4] else None,
+                gi_w if needs[5] else None,
+                grad_result(img_b, gi_b, gb_d) if (needs[6] and gi_b is not None) else None,
+                grad_result(img_ln_w, gi_lw, glw_d) if (needs[7] and gi_lw is not None) else None,
+                grad_result(img_ln_b, gi_lb, glb_d) if (needs[8] and gi_lb is not None) else None]
+        ctx.txt = ctx.img = ctx.share = ctx.ps = None
         return (None, None, None, None, None) + tuple(outs)
 
 
@@ -664,8 +742,7 @@ class LinearFn(GradAwareFunction):
         if x2.stride(1) != 1 or (x2.stride(0) % 8) or (x2.data_ptr() % 16):
             x2 = x2.contiguous()
         cache = cache.for_device(weight.device)
-        if cache.stale([weight]):
-            cache.t["w"], cache.t["wt"] = cast_weight(weight)
+        cache.weight_copies(weight)
         b = _f32(bias) if bias is not None else None
         N = weight.shape[0]
         if act == "gelu":
@@ -674,6 +751,8 @@ class LinearFn(GradAwareFunction):
             u, y = None, hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS, bias=b, n=N)
         ctx.save = (x2, u, cache, weight.shape, bias is not None)
         ctx.needs = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
+        ctx.ps = (weight, bias)
+        note_uses(ctx, (weight if x2.shape[1] == weight.shape[1] else None, bias), 1)
         ctx.xshape = x.shape
         return y.view(x.shape[:-1] + (N,))
 
@@ -685,7 +764,8 @@ class LinearFn(GradAwareFunction):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dev = dy.device
-        db = torch.zeros(N, device=dev, dtype=torch.float32) if has_bias else None
+        weight, bias = ctx.ps
+        db, db_d = grad_buffer(bias) if ctx.needs[2] else ((torch.zeros(N, device=dev, dtype=torch.float32) if has_bias else None), False)
         wt = cache.t["wt"]  # bf16 [K, pad8(N)]
         Np = wt.shape[1]
         if Np != N:
@@ -699,16 +779,21 @@ class LinearFn(GradAwareFunction):
             du[:, :N] = dy2[:, :N] * u
             dy2 = du
         dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
-        dw = None
+        dw, dw_d = None, False
         if ctx.needs[1]:
-            dw = torch.zeros((N, x2.shape[1]), device=dev, dtype=torch.float32)
+            if x2.shape[1] == K:
+                dw, dw_d = grad_buffer(weight, (N, K))
+            else:
+                dw = torch.zeros((N, x2.shape[1]), device=dev, dtype=torch.float32)
             hip.gemm_tn(dy2, x2, dw, n=N, colsum=db)   # bias gradient rides on the weight gradient
-            dw = dw[:, :K]
+            dw = dw[:, :K] if not dw_d else dw
         elif db is not None:
             hip.colsum(dy2, db, n=N)
         if dx is not None:
             dx = dx.view(ctx.xshape)
-        return dx, dw, (db if ctx.needs[2] else None), None, None
+        ctx.ps = None
+        return (dx, grad_result(weight, dw, dw_d) if ctx.needs[1] else None,
+                grad_result(bias, db, db_d) if ctx.needs[2] else None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -718,16 +803,19 @@ class LayerNormFn(torch.autograd.Function):
         w, b = _f32(weight), _f32(bias)
         y, mean, rstd = hip.layernorm_fwd(z2, w, b, eps)
         ctx.save = (z2, mean, rstd, w)
+        ctx.ps = (weight, bias)
+        note_uses(ctx, (weight, bias), 1)
         return y.view(z.shape)
 
     @staticmethod
     def backward(ctx, dy):
         z2, mean, rstd, w = ctx.save
         H = z2.shape[1]
-        dg = torch.zeros(H, device=dy.device, dtype=torch.float32)
-        db = torch.zeros(H, device=dy.device, dtype=torch.float32)
+        weight, bias = ctx.ps
+        (dg, dg_d), (db, db_d) = grad_buffer(weight), grad_buffer(bias)
         dz, _ = hip.layernorm_bwd(dy.reshape(-1, H).contiguous(), z2, mean, rstd, w, dg, db)
-        return dz.view(dy.shape), dg, db, None
+        ctx.ps = None
+        return dz.view(dy.shape), grad_result(weight, dg, dg_d), grad_result(bias, db, db_d), None
 
 
 class DecoderCEFn(GradAwareFunction):
@@ -745,12 +833,13 @@ class DecoderCEFn(GradAwareFunction):
         V = weight.shape[0]
         Vp = pad8(V)
         cache = cache.for_device(weight.device)
-        if cache.stale([weight]):
-            cache.t["w"], cache.t["wt"] = cast_weight(weight)
+        cache.weight_copies(weight)
         h = h.contiguous()
         labels = labels.contiguous()
         nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32)
         ctx.needs = (h.requires_grad, weight.requires_grad, bias.requires_grad)
+        ctx.ps = (weight, bias)
+        note_uses(ctx, (weight, bias), 1)
         if not want_scores:
             b32 = _f32(bias)
             loss_row, lse = hip.decoder_ce_fwd(h, cache.t["w"], b32, labels, V)
@@ -778,13 +867,166 @@ class DecoderCEFn(GradAwareFunction):
             d = hip.ce_bwd(logits, labels, lse, scale, V, Vp)
         H = h.shape[1]
         dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H) if ctx.needs[0] else None
+        weight, bias = ctx.ps
         dw = db = None
+        dw_d = db_d = False
         if ctx.needs[2]:
-            db = torch.zeros(V, device=h.device, dtype=torch.float32)
+            db, db_d = grad_buffer(bias, (V,))
         if ctx.needs[1]:
-            dw = torch.zeros((V, H), device=h.device, dtype=torch.float32)
+            dw, dw_d = grad_buffer(weight, (V, H))
             hip.gemm_tn(d, h, dw, n=V, colsum=db)
         elif db is not None:
             hip.colsum(d, db, n=V)
-        ctx.save = None
-        return dh, dw, db, None, None, None
+        ctx.save = ctx.ps = None
+        return (dh, grad_result(weight, dw, dw_d) if ctx.needs[1] else None,
+                grad_result(bias, db, db_d) if ctx.needs[2] else None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# Row taps and the f32 B-row heads (heads.hip)
+class MultiTapFn(torch.autograd.Function):
+    """outs[k] = rows idx_k of a bf16 [R, H] buffer (or of two buffers addressed as one: indices >= src.shape[0]
+    read src2), idx_k int32 (negative index = zero row).  ALL the rows that later stages read from one stack
+    output go through ONE call — the packed joint input gathered from the packed text and visual outputs, [CLS]
+    states, masked-LM rows, phrase / region rows of the word-region alignment — so the backward pass builds each
+    buffer's gradient with one zero fill and one scatter-add per consumer (rows may repeat: packed bf16 atomics)
+    instead of a full-size zero-filled tensor + add per consumer.  Incoming gradients may be bf16 or f32."""
+
+    @staticmethod
+    def forward(ctx, src, src2, *idxs):
+        ctx.set_materialize_grads(False)
+        ctx.idxs = idxs
+        ctx.shapes = (src.shape, None if src2 is None else src2.shape)
+        return tuple(hip.gather_rows(src, i, src2=src2) for i in idxs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        s1, s2 = ctx.shapes
+        dev = ctx.idxs[0].device
+        d = torch.zeros(s1, device=dev, dtype=torch.bfloat16)
+        d2 = torch.zeros(s2, device=dev, dtype=torch.bfloat16) if s2 is not None else None
+        for g, i in zip(gs, ctx.idxs):
+            if g is None:
+                continue
+            g = g.contiguous()
+            if g.dtype not in (torch.bfloat16, torch.float32):
+                g = g.float()
+            hip.scatter_add_rows(g, i, d, d2)
+        return (d, d2) + (None,) * len(ctx.idxs)
+
+
+def tap_rows(src, idx, src2=None):
+    """One-output form of MultiTapFn."""
+    return MultiTapFn.apply(src, src2, idx)[0]
+
+
+class SmallLinearFn(GradAwareFunction):
+    """y = act(x W^T + b) in f32 on a few hundred rows: x bf16 or f32 [n, K], W f32 [N, K] (w_kn=False, nn.Linear
+    layout) or [K, N] (w_kn=True: `x @ W`, the CLIP projections vl:525-526), act in {None, 'tanh'} -> f32 [n, N].
+    Pooler (modeling_bert.py:468-474), seq_relationship (vl:975-979), txt_proj / vis_proj."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, w_kn):
+        x = x.contiguous()
+        w = _f32(weight)
+        y = hip.sgemm_small(x, w, trans_b=not w_kn, bias=_f32(bias) if bias is not None else None, act=act)
+        ctx.save = (x, w, y if act == "tanh" else None)
+        ctx.ps = (weight, bias)
+        ctx.w_kn = w_kn
+        ctx.needs = (x.requires_grad, weight.requires_grad, bias is not None and bias.requires_grad)
+        note_uses(ctx, (weight, bias), 1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.save
+        weight, bias = ctx.ps
+        du = dy.contiguous().float()
+        if y is not None:
+            du = du * (1.0 - y * y)
+        dx = dw = db = None
+        dw_d = db_d = False
+        if ctx.needs[0]:
+            dx = hip.sgemm_small(du, w, trans_b=ctx.w_kn)          # [n, K] f32
+        if ctx.needs[1]:
+            dw, dw_d = grad_buffer(weight)
+            if ctx.w_kn:
+                hip.sgemm_small(x, du, trans_a=True, out=dw, accumulate=True)      # [K, N] += x^T du
+            else:
+                hip.sgemm_small(du, x, trans_a=True, out=dw, accumulate=True)      # [N, K] += du^T x
+        if ctx.needs[2]:
+            db, db_d = grad_buffer(bias)
+            db += du.sum(0)
+        ctx.save = ctx.ps = None
+        return (dx, grad_result(weight, dw, dw_d) if ctx.needs[1] else None,
+                grad_result(bias, db, db_d) if ctx.needs[2] else None, None, None)
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(y, p=2, dim=-1) on f32 rows (vl:525-526)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        g, inv = hip.l2norm_fwd(y.contiguous())
+        ctx.save = (g, inv)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        g, inv = ctx.save
+        return hip.l2norm_bwd(g, inv, dg.contiguous().float())
+
+
+class SimFn(torch.autograd.Function):
+    """sim = gt gi^T in exact f32 (vl:527; feeds the hard-negative argmax :531-534)."""
+
+    @staticmethod
+    def forward(ctx, gt, gi):
+        gt, gi = gt.contiguous(), gi.contiguous()
+        ctx.save = (gt, gi)
+        return hip.sgemm_small(gt, gi, trans_b=True)
+
+    @staticmethod
+    def backward(ctx, dsim):
+        gt, gi = ctx.save
+        dsim = dsim.contiguous().float()
+        return hip.sgemm_small(dsim, gi), hip.sgemm_small(dsim, gt, trans_a=True)
+
+
+class ContrastiveLossFn(GradAwareFunction):
+    """(CE(sim * exp(logit_scale), arange) + CE(its transpose, arange)) / 2 (vl:1238-1241) -> scalar."""
+
+    @staticmethod
+    def forward(ctx, sim, logit_scale):
+        sim = sim.contiguous()
+        ls = _f32(logit_scale).reshape(1)
+        loss, lse = hip.clip_ce_fwd(sim, ls)
+        ctx.save = (sim, ls, lse)
+        ctx.ps = logit_scale
+        ctx.needs = (sim.requires_grad, logit_scale.requires_grad)
+        note_uses(ctx, (logit_scale,), 1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        sim, ls, lse = ctx.save
+        p = ctx.ps
+        dls, dls_d = (grad_buffer(p) if ctx.needs[1] else (None, False))
+        dsim = hip.clip_ce_bwd(sim, ls, lse, gloss.reshape(1).float().contiguous(), dls.view(1) if dls is not None else None)
+        ctx.save = ctx.ps = None
+        return (dsim if ctx.needs[0] else None), (grad_result(p, dls, dls_d) if ctx.needs[1] else None)
+
+
+class CeMeanFn(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index=-1) over a few classes (the 2-way ITM loss vl:1247-1251): one launch computes the
+    mean loss and d loss / d logits."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, d = hip.ce_mean_small(logits.contiguous().float(), labels.contiguous())
+        ctx.save = d
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        return ctx.save * gloss, None

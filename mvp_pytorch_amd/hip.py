@@ -27,6 +27,9 @@ SYMBOLS = [
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
     "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe", "mvptr_encoder_layer_bwd2",
+    "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
+    "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
+    "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps",
 ]
 
 
@@ -50,6 +53,11 @@ class LayerWeights(Structure):
 class TnProblem(Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("M", c_int), ("N", c_int),
                 ("K", c_int), ("dW", c_void_p), ("ldw", c_int64), ("colsum", c_void_p)]
+
+
+class PackSeg(Structure):
+    _fields_ = [("mask", c_void_p), ("ld_mask", c_int64), ("sel", c_void_p), ("col0", c_int), ("len", c_int),
+                ("pos", c_void_p), ("ld_pos", c_int64), ("src_seq_stride", c_int64), ("src_base", c_int64)]
 
 
 class LayerGrads(Structure):
@@ -99,7 +107,21 @@ def load():
     lib.mvptr_ce_fwd.argtypes = [P, I64, P, P, P, I, I, P]
     lib.mvptr_ce_bwd.argtypes = [P, I64, P, P, P, P, I64, I, I, I, P]
     lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
-    lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P]
+    lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P, P]
+    lib.mvptr_adamw_mirror_multi.argtypes = [P, P, I, I, F, F, F, P, P]
+    lib.mvptr_sumsq_partials.restype = c_int64
+    lib.mvptr_sumsq_partials.argtypes = [I64]
+    lib.mvptr_sumsq_partial.argtypes = [P, I64, P, P]
+    lib.mvptr_clip_coef.argtypes = [P, I, F, P, P, P]
+    lib.mvptr_sgemm_small.argtypes = [P, I64, I, I, P, P, I64, I, I, P, I, I, I, F, P, I, I, P, I64, P]
+    lib.mvptr_ce_mean_small.argtypes = [P, I64, P, I, I, P, P, P]
+    lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
+    lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
+    lib.mvptr_clip_ce_fwd.argtypes = [P, I, I64, P, P, P, P, P]
+    lib.mvptr_clip_ce_bwd.argtypes = [P, I, I64, P, P, P, P, P, P, P]
+    lib.mvptr_gather_rows.argtypes = [P, I64, P, I64, I, P, P, I64, I, I, P]
+    lib.mvptr_scatter_add_rows.argtypes = [P, I64, I, P, P, I64, P, I64, I, I, I, P]
+    lib.mvptr_pack_maps.argtypes = [POINTER(PackSeg), I, I, P, P, P, P, P, P]
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
     lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
     lib.mvptr_diag_store_probe.argtypes = [P, I64, I, I64, I, I64, P]
@@ -409,8 +431,145 @@ def dropout_mask(drop, n, device):
 ADAMW_CHUNK = 65536
 
 
-def adamw_multi(table_dev, chunk_tensor_dev, chunk_offset_dev, n_chunks, beta1, beta2, eps):
+def adamw_multi(table_dev, chunk_tensor_dev, chunk_offset_dev, n_chunks, beta1, beta2, eps, grad_scale=None):
     """Fused multi-tensor AdamW (see mvptr_adamw_multi); tables are device tensors built by
-    mvp_pytorch_amd.optimization.AdamW."""
+    mvp_pytorch_amd.optimization.AdamW.  grad_scale: device f32 scalar (clip coefficient) or None."""
     _check(load().mvptr_adamw_multi(_p(table_dev), _p(chunk_tensor_dev), _p(chunk_offset_dev), n_chunks,
-                                    ADAMW_CHUNK, float(beta1), float(beta2), float(eps), _stream()))
+                                    ADAMW_CHUNK, float(beta1), float(beta2), float(eps), _p(grad_scale), _stream()))
+
+
+MIRROR_DT = [("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("step_size", "<f4"),
+             ("decay", "<f4"), ("dst", "<u8"), ("ld_dst", "<i8"), ("dst_t", "<u8"), ("ld_dst_t", "<i8"), ("col_off_t", "<i4"),
+             ("pad_", "<i4"), ("dst_f32", "<u8")]          # mvptr_adamw_mirror_tensor
+
+
+def adamw_mirror_multi(table_dev, tile_base_dev, n_tensors, total_tiles, beta1, beta2, eps, grad_scale=None):
+    """AdamW + bf16 working copies in one pass over 64 x 64 tiles (see mvptr_adamw_mirror_multi)."""
+    _check(load().mvptr_adamw_mirror_multi(_p(table_dev), _p(tile_base_dev), n_tensors, total_tiles, float(beta1), float(beta2),
+                                           float(eps), _p(grad_scale), _stream()))
+
+
+def grad_clip_coef(flats, max_norm, scratch=None):
+    """Global 2-norm of the flat f32 gradient buffers and the clip coefficient min(1, max_norm / (norm + 1e-6)) as
+    device scalars -> (norm [1], coef [1], scratch).  Two passes: per-16K-element partial sums of squares, then one
+    workgroup that adds them in index order (mvptr_sumsq_partial / mvptr_clip_coef)."""
+    lib = load()
+    counts = [int(lib.mvptr_sumsq_partials(f.numel())) for f in flats]
+    total = sum(counts)
+    dev = flats[0].device
+    if scratch is None or scratch.numel() < total + 2:
+        scratch = torch.empty(total + 2, device=dev, dtype=torch.float32)
+    o = 0
+    for f, c in zip(flats, counts):
+        assert f.dtype == torch.float32 and f.is_contiguous()
+        _check(lib.mvptr_sumsq_partial(_p(f), f.numel(), c_void_p(scratch.data_ptr() + 4 * o), _stream()))
+        o += c
+    norm, coef = scratch[total:total + 1], scratch[total + 1:total + 2]
+    _check(lib.mvptr_clip_coef(_p(scratch), total, float(max_norm), _p(norm), _p(coef), _stream()))
+    return norm, coef, scratch
+
+
+def sgemm_small(a, b, trans_a=False, trans_b=False, a_rows=None, b_rows=None, bias=None, act=None, alpha=1.0, out=None,
+                accumulate=False, m=None, n=None, k=None):
+    """C = act(alpha * op(A) op(B) + bias) in f32 (mvptr_sgemm_small).  a / b: 2-D f32 or bf16 tensors with unit
+    column stride; a_rows: int32 gather of A's stored rows; out: f32 [M, N] (accumulated into when accumulate)."""
+    assert a.stride(-1) == 1 and b.stride(-1) == 1
+    if trans_a:
+        K_, M_ = (a_rows.numel() if a_rows is not None else a.shape[0]), a.shape[1]
+    else:
+        M_, K_ = (a_rows.numel() if a_rows is not None else a.shape[0]), a.shape[1]
+    N_ = (b_rows.numel() if b_rows is not None else b.shape[0]) if trans_b else b.shape[1]
+    M_, N_, K_ = m or M_, n or N_, k or K_
+    if out is None:
+        out = torch.empty((M_, N_), device=a.device, dtype=torch.float32)
+    _check(load().mvptr_sgemm_small(_p(a), a.stride(0), int(a.dtype == torch.bfloat16), int(trans_a), _p(a_rows), _p(b), b.stride(0),
+                                    int(b.dtype == torch.bfloat16), int(trans_b), _p(b_rows), M_, N_, K_, float(alpha), _p(bias),
+                                    1 if act == "tanh" else 0, int(accumulate), _p(out), out.stride(0), _stream()))
+    return out
+
+
+def l2norm_fwd(y, eps=1e-12):
+    g, inv = torch.empty_like(y), torch.empty(y.shape[0], device=y.device, dtype=torch.float32)
+    _check(load().mvptr_l2norm_fwd(_p(y), _p(g), _p(inv), y.shape[0], y.shape[1], float(eps), _stream()))
+    return g, inv
+
+
+def l2norm_bwd(g, inv, dg):
+    dy = torch.empty_like(g)
+    _check(load().mvptr_l2norm_bwd(_p(g), _p(inv), _p(dg), _p(dy), g.shape[0], g.shape[1], _stream()))
+    return dy
+
+
+def clip_ce_fwd(sim, logit_scale):
+    n = sim.shape[0]
+    ws = torch.empty(4 * n + 1, device=sim.device, dtype=torch.float32)
+    lse, parts, loss = ws[:2 * n], ws[2 * n:4 * n], ws[4 * n:]
+    _check(load().mvptr_clip_ce_fwd(_p(sim), n, sim.stride(0), _p(logit_scale), _p(lse), _p(parts), _p(loss), _stream()))
+    return loss.reshape(()), lse
+
+
+def clip_ce_bwd(sim, logit_scale, lse, gloss, dlogit_scale=None):
+    n = sim.shape[0]
+    dsim = torch.empty((n, n), device=sim.device, dtype=torch.float32)
+    parts = torch.empty(n, device=sim.device, dtype=torch.float32)
+    _check(load().mvptr_clip_ce_bwd(_p(sim), n, sim.stride(0), _p(logit_scale), _p(lse), _p(gloss), _p(dsim), _p(parts),
+                                    _p(dlogit_scale), _stream()))
+    return dsim
+
+
+def ce_mean_small(logits, labels, want_grad=True):
+    """-> (mean CE over the rows with a label in [0, V), d loss / d logits f32 [M, V] or None)."""
+    M, V = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    d = torch.empty((M, V), device=logits.device, dtype=torch.float32) if want_grad else None
+    _check(load().mvptr_ce_mean_small(_p(logits), logits.stride(0), _p(labels), M, V, _p(loss), _p(d), _stream()))
+    return loss.reshape(()), d
+
+
+def gather_rows(src, idx, out=None, src2=None):
+    """out[i] = src[idx[i]] (bf16 rows; idx int32, negative = zero row); with src2, idx >= src.shape[0] reads
+    src2[idx - src.shape[0]]."""
+    n, H = idx.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty((n, H), device=src.device, dtype=torch.bfloat16)
+    if n:
+        _check(load().mvptr_gather_rows(_p(src), src.stride(0), _p(src2), src2.stride(0) if src2 is not None else 0,
+                                        src.shape[0], _p(idx), _p(out), out.stride(0), n, H, _stream()))
+    return out
+
+
+def scatter_add_rows(src, idx, dst, dst2=None):
+    """dst[idx[i]] += src[i] (dst bf16 rows, src bf16 or f32; packed bf16 atomics, rows may repeat); with dst2,
+    idx >= dst.shape[0] adds into dst2[idx - dst.shape[0]]."""
+    n, H = idx.numel(), dst.shape[1]
+    if n:
+        _check(load().mvptr_scatter_add_rows(_p(src), src.stride(0), int(src.dtype == torch.float32), _p(idx), _p(dst), dst.stride(0),
+                                             _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0], n, H, _stream()))
+    return dst
+
+
+def pack_maps(segs, n_seq):
+    """segs: 1 or 2 dicts(mask f32 [rows, ld] additive, sel int64 [n_seq] or None, col0, len, pos int32 [rows, ld_pos] or
+    None, src_seq_stride, src_base) -> (pos int32 [n_seq, Ltot], idx int32 [n_seq * Ltot] (first `rows` entries valid),
+    seq_start int32 [n_seq], seq_len int32 [n_seq], counts int64 [2] = rows, longest) — see mvptr_pack_maps."""
+    dev = segs[0]["mask"].device
+    arr = (PackSeg * len(segs))()
+    Ltot = 0
+    for k, sg in enumerate(segs):
+        m = sg["mask"]
+        assert m.dtype == torch.float32 and m.stride(-1) == 1
+        a = arr[k]
+        a.mask, a.ld_mask = m.data_ptr(), m.stride(0)
+        a.sel = sg["sel"].data_ptr() if sg.get("sel") is not None else None
+        a.col0, a.len = int(sg.get("col0", 0)), int(sg["len"])
+        pos = sg.get("pos")
+        a.pos, a.ld_pos = (pos.data_ptr(), pos.stride(0)) if pos is not None else (None, 0)
+        a.src_seq_stride, a.src_base = int(sg.get("src_seq_stride", 0)), int(sg.get("src_base", 0))
+        Ltot += a.len
+    pos_out = torch.empty((n_seq, Ltot), device=dev, dtype=torch.int32)
+    idx_out = torch.empty(n_seq * Ltot, device=dev, dtype=torch.int32)
+    seq_start = torch.empty(n_seq, device=dev, dtype=torch.int32)
+    seq_len = torch.empty(n_seq, device=dev, dtype=torch.int32)
+    counts = torch.empty(2, device=dev, dtype=torch.int64)
+    _check(load().mvptr_pack_maps(arr, len(segs), n_seq, _p(pos_out), _p(idx_out), _p(seq_start), _p(seq_len), _p(counts), _stream()))
+    return pos_out, idx_out, seq_start, seq_len, counts

@@ -164,16 +164,29 @@ class BertLayer(nn.Module):
 
 
 class BertPooler(nn.Module):
-    """modeling_bert.py:462-474 — tanh(dense(h[:, 0])); B rows only, plain f32 torch."""
+    """modeling_bert.py:462-474 — tanh(dense(h[:, 0])): the [CLS] rows are tapped from the sequence buffer by row
+    index (no strided copy) and go through the f32 HIP GEMM with a bias + tanh epilogue."""
 
     def __init__(self, config):
         super().__init__()
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.activation = nn.Tanh()
 
+    def forward_rows(self, cls_rows):
+        """tanh(dense(rows)) on [CLS] rows already gathered ([n, H] bf16 / f32): f32 HIP GEMM with the bias + tanh
+        epilogue (mvptr_sgemm_small) for f32 master weights on a HIP device; after model.half() (or on the CPU)
+        the tail runs in torch in the parameters' dtype like the reference."""
+        w = self.dense.weight
+        if cls_rows.is_cuda and w.dtype == torch.float32:
+            return engine.SmallLinearFn.apply(cls_rows, w, self.dense.bias, "tanh", False)
+        return self.activation(self.dense(cls_rows.to(w.dtype)))
+
     def forward(self, hidden_states):
-        # f32 master weights -> f32; after model.half() the tail runs in the parameters' dtype like the reference
-        return self.activation(self.dense(hidden_states[:, 0].to(self.dense.weight.dtype)))
+        if hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and hidden_states.is_contiguous() and hidden_states.dim() == 3:
+            B, L, H = hidden_states.shape
+            rows = torch.arange(B, device=hidden_states.device, dtype=torch.int32) * L
+            return self.forward_rows(engine.tap_rows(hidden_states.view(B * L, H), rows))
+        return self.forward_rows(hidden_states[:, 0])
 
 
 class BertPredictionHeadTransform(nn.Module):

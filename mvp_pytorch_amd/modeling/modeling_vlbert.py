@@ -56,19 +56,17 @@ def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
 
 
 def _streams_allowed(setting):
-    """Two-stream execution of the uni-modal stacks: on one GPU always; in a multi-rank job under RCCL
-    (backend "nccl") too — the collectives run on RCCL's own stream whatever the compute streams do,
-    and mvp_pytorch_amd.dp.GradSync makes a bucket wait for every stream that produced one of its
-    gradients before it is handed over (exercised with two ranks in tests/test_dp_gpu.py).  With gloo
-    the bucketed exchange slows down badly beside a side stream (host-side copies that synchronise
-    the device, tools/dp_gloo_check.py), so gloo jobs keep one stream unless the config says
-    parallel_stacks = "always".  No multi-GPU box was available to time the RCCL case."""
+    """Two-stream execution of the uni-modal stacks (and heads beside the joint stack): always in a
+    single-rank process; in a multi-rank job only with config.parallel_stacks = "always".
+    mvp_pytorch_amd.dp.GradSync makes a bucket wait for every stream that produced one of its gradients
+    before it is handed to the collective (exercised with a one-rank RCCL group in tests/test_dp_gpu.py),
+    but no multi-GPU box was available to time or soak the combination, so multi-rank jobs default to one
+    compute stream.  With gloo the bucketed exchange slows down badly beside a side stream (host-side
+    copies that synchronise the device, tools/dp_gloo_check.py)."""
     if setting == "always":
         return True
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        return True
-    return dist.get_backend() == "nccl"
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def additive_mask(attention_mask):
@@ -111,6 +109,13 @@ class CaptionBertEncoder(nn.Module):
                     layer.output.LayerNorm.weight, layer.output.LayerNorm.bias]
         return out
 
+    def grad_arena_units(self):
+        """Per layer, its sixteen parameters in the order the backward kernels write their gradients
+        (mvptr_layer_grads): mvp_pytorch_amd.dp.GradSync lays each list out back to back so that
+        engine.EncoderFn.backward accumulates straight into the gradient arena."""
+        flat = self._flat_params()
+        return [[flat[16 * li + j] for j in engine.EncoderFn.ARENA_ORDER] for li in range(len(self.layer))]
+
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None,
                 return_at_layer=None, pack_hint=None):
         if isinstance(attention_mask, list) or encoder_history_states is not None or return_at_layer is not None:
@@ -146,6 +151,21 @@ class CaptionBertEncoder(nn.Module):
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
+
+
+def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax):
+    """The layer stack on row-packed input: x_rows bf16 [rows, H] holds the valid token rows of n_seq sequences
+    back to back (sequence b at [seq_start[b], +seq_len[b]), device int32; lmax = the longest) -> [rows, H].
+    The caller owns the packing (hip.pack_maps + engine.MultiTapFn)."""
+    Hc, heads, I, eps = self._dims
+    l0 = self.layer[0]
+    meta = engine.EncoderMeta(self._packs.for_device(x_rows.device), n_seq, lmax, Hc, heads, I, eps, self.training,
+                              l0.output.dropout.p, l0.attention.self.dropout.p, seq_start=seq_start, seq_len=seq_len,
+                              rows=x_rows.shape[0])
+    return engine.EncoderFn.apply(x_rows, None, meta, *self._flat_params())
+
+
+CaptionBertEncoder.forward_rows = _forward_rows
 
 
 def _prefetch_weights(self, device):
@@ -309,12 +329,29 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                     torch.multinomial(F.softmax(masked.t(), dim=1), num_samples=1).squeeze())
         raise NotImplementedError
 
+    @staticmethod
+    def _cls_rows(seq):
+        """[CLS] rows of a [B, L, H] sequence tensor, tapped by row index when it is a contiguous bf16 device buffer."""
+        if seq.is_cuda and seq.dtype == torch.bfloat16 and seq.is_contiguous():
+            B, L, H = seq.shape
+            return engine.tap_rows(seq.view(B * L, H), torch.arange(B, device=seq.device, dtype=torch.int32) * L)
+        return seq[:, 0, :]
+
+    def _project(self, cls_rows, proj):
+        """normalize(cls @ proj) in f32 (vl:525-526; feeds the hard-negative argmax: kept out of bf16)."""
+        if cls_rows.is_cuda and proj.dtype == torch.float32:
+            return engine.L2NormFn.apply(engine.SmallLinearFn.apply(cls_rows, proj, None, None, True))
+        return F.normalize(cls_rows.float() @ proj.float(), p=2, dim=-1)
+
+    @staticmethod
+    def _sim(global_txt, global_img):
+        """vl:527 — exact f32 similarity matrix."""
+        if global_txt.is_cuda and global_txt.dtype == torch.float32 and global_img.dtype == torch.float32:
+            return engine.SimFn.apply(global_txt, global_img)
+        return global_txt @ global_img.t()
+
     def _globals(self, txt, vis):
-        """vl:525-526 — f32 (feeds argmax: kept out of bf16)."""
-        with engine.small_f32_blas():
-            gt = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
-            gi = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
-        return gt, gi
+        return self._project(self._cls_rows(txt), self.txt_proj), self._project(self._cls_rows(vis), self.vis_proj)
 
     def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
                 use_b=False, position_ids_a=None, input_ids_b=None, token_type_ids_b=None,
@@ -334,8 +371,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         only_vis = vis[:, cut:, :]
         only_vis_mask = mask_b[:, cut:]
         global_txt, global_img = self._globals(txt, vis)
-        with engine.small_f32_blas():
-            sim_mat = global_txt @ global_img.t()
+        sim_mat = self._sim(global_txt, global_img)
 
         hard_out = hard_pooled = hard_txt_full = hard_img_full = None
         if encode_hn:
@@ -394,6 +430,106 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         outputs = (sequence_output, pooled_output, hard_out, hard_pooled)
         return outputs, (txt, vis, sim_mat), (hard_txt_full, hard_img_full)
 
+    # -- row-packed pipeline (training fast path) ------------------------------------------------------
+    def packed_ok(self, attention_mask_a, attention_mask_b, input_ids_a):
+        enc = self.txt_encoder
+        return (input_ids_a.is_cuda and attention_mask_a is not None and attention_mask_b is not None and
+                attention_mask_a.dim() == 2 and attention_mask_b.dim() == 2 and
+                (enc.unpad is True or (enc.unpad == "train" and self.training)) and
+                self.embeddings.word_embeddings.weight.dtype == torch.float32)
+
+    def forward_packed(self, input_ids_a, token_type_ids_a, attention_mask_a, max_tag_length, input_ids_b, token_type_ids_b,
+                       attention_mask_b, img_feats, position_ids_a=None, position_ids_b=None, use_b=False, hn_mod="hard",
+                       logit=None, uni_taps=None, beside=None):
+        """The two-stage backbone of `forward(encode_hn=True)` without ever materialising a padded activation tensor
+        between the stacks (vl:479-600): the valid rows of the text / visual inputs are gathered once, each stack
+        runs on packed rows, the packed joint + hard-negative input is gathered straight from the two packed outputs
+        through index maps built on the device (hip.pack_maps), and everything later stages read — [CLS] states,
+        masked rows, phrase / region rows — is tapped from packed buffers by row index (engine.MultiTapFn).
+        Same arithmetic on the same rows as the row-packed `forward`.
+
+        uni_taps(pos_a, pos_b) -> (list of int32 row vectors into the packed text output, same for the visual
+        output): extra rows the caller wants from the uni-modal outputs; beside(taps_txt, taps_vis, sim_mat): work
+        that only needs those (queued on the side stream beside the joint stack).
+        -> dict: both (packed joint output [rows_j, H]; sequences 0..n-1 matched, n..2n-1 hard), pos_j int32 [2n, Lj]
+        (packed row of every slot of the unpadded joint layout, -1 = padded), seq_start_j, sim_mat, hard_txt_full,
+        hard_img_full, pos_a, pos_b, n_txt_rows."""
+        from .. import hip
+        dev = input_ids_a.device
+        B, La = input_ids_a.shape
+        Lb = attention_mask_b.shape[1]
+        H = self.config.hidden_size
+        if token_type_ids_a is None:
+            token_type_ids_a = torch.zeros_like(input_ids_a)
+        if token_type_ids_b is None:
+            token_type_ids_b = torch.zeros_like(input_ids_b)
+        mask_a, mask_b = additive_mask(attention_mask_a), additive_mask(attention_mask_b)
+        pos_a, idx_a, st_a, ln_a, cnt_a = hip.pack_maps([dict(mask=mask_a, len=La, src_seq_stride=La)], B)
+        pos_b, idx_b, st_b, ln_b, cnt_b = hip.pack_maps([dict(mask=mask_b, len=Lb, src_seq_stride=Lb)], B)
+        counts = engine.AsyncCounts([cnt_a[0], cnt_a[1], cnt_b[0], cnt_b[1]])
+        two_streams = bool(self.parallel_stacks) and _streams_allowed(self.parallel_stacks)
+        main = torch.cuda.current_stream(dev)
+        side = engine.side_stream(dev) if two_streams else None
+        prefetch = two_streams and torch.is_grad_enabled() and os.environ.get("MVPTR_NO_PREFETCH") != "1"
+        if prefetch:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for enc in (self.txt_encoder, self.vis_encoder, self.mul_encoder):
+                    enc.prefetch_weights(dev)
+        share = {}
+        xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self, share)
+        xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self, share)
+        if prefetch:
+            main.wait_stream(side)
+        ra, la_max, rb, lb_max = counts.get()
+        xa_p = engine.tap_rows(xa.view(B * La, H), idx_a[:ra])
+        if two_streams:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xb_p = engine.tap_rows(xb.view(B * Lb, H), idx_b[:rb])
+                vis_p = self.vis_encoder.forward_rows(xb_p, st_b, ln_b, B, lb_max)
+            txt_p = self.txt_encoder.forward_rows(xa_p, st_a, ln_a, B, la_max)
+            main.wait_stream(side)
+            for t in (xb, idx_b, st_b, ln_b):
+                t.record_stream(side)
+            vis_p.record_stream(main)
+        else:
+            xb_p = engine.tap_rows(xb.view(B * Lb, H), idx_b[:rb])
+            txt_p = self.txt_encoder.forward_rows(xa_p, st_a, ln_a, B, la_max)
+            vis_p = self.vis_encoder.forward_rows(xb_p, st_b, ln_b, B, lb_max)
+        # [CLS] states + whatever else the caller reads from the uni-modal outputs: one tap call
+        extra_t, extra_v = uni_taps(pos_a, pos_b) if uni_taps is not None else ([], [])
+        cls_t, cls_v = pos_a[:, 0].contiguous(), pos_b[:, 0].contiguous()
+        taps = engine.MultiTapFn.apply(txt_p, vis_p, cls_t, cls_v + ra, *extra_t, *[v + ra for v in extra_v])
+        global_txt, global_img = self._project(taps[0], self.txt_proj), self._project(taps[1], self.vis_proj)
+        sim_mat = self._sim(global_txt, global_img)
+        n = B
+        hard_img, hard_txt = self.mine_hard_negatives(sim_mat.detach(), hn_mod, logit)
+        dice = torch.randperm(n, device=dev)
+        first, second = dice[: n // 2], dice[n // 2:]
+        ar = torch.arange(n, device=dev)
+        hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
+        hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
+        cut = 1 if use_b else max_tag_length
+        pos_j, idx_j, st_j, ln_j, cnt_j = hip.pack_maps(
+            [dict(mask=mask_a, sel=torch.cat([ar, hard_txt_full]), len=La, pos=pos_a),
+             dict(mask=mask_b, sel=torch.cat([ar, hard_img_full]), col0=cut, len=Lb - cut, pos=pos_b, src_base=ra)], 2 * n)
+        cj = engine.AsyncCounts([cnt_j[0], cnt_j[1]])
+        if beside is not None:
+            if two_streams:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    beside(taps[2:2 + len(extra_t)], taps[2 + len(extra_t):], sim_mat)
+                for t in taps[2:] + (sim_mat,):
+                    t.record_stream(side)
+            else:
+                beside(taps[2:2 + len(extra_t)], taps[2 + len(extra_t):], sim_mat)
+        rj, lj_max = cj.get()
+        xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j[:rj])[0]
+        both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, lj_max)
+        return dict(both=both, pos_j=pos_j, seq_start_j=st_j, sim_mat=sim_mat, hard_txt_full=hard_txt_full,
+                    hard_img_full=hard_img_full, pos_a=pos_a, pos_b=pos_b, n_txt_rows=ra, text_len=La)
+
     def forward_single(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, max_tag_length=None,
                        position_ids_a=None, input_ids_b=None, token_type_ids_b=None, attention_mask_b=None,
                        position_ids_b=None, head_mask=None, img_feats=None, encoder_history_states=None):
@@ -441,8 +577,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         xa = embed_inputs(self.embeddings, input_ids_a, token_type_ids_a, position_ids_a, None, self)
         with self._packed_stacks(self, packed):
             txt = self.txt_encoder(xa, mask_a)[0]
-        with engine.small_f32_blas():
-            glob = F.normalize(txt[:, 0, :].float() @ self.txt_proj.float(), p=2, dim=-1)
+        glob = self._project(self._cls_rows(txt), self.txt_proj)
         return dict(seq=txt, mask=mask_a, glob=glob)
 
     @torch.no_grad()
@@ -459,8 +594,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         with self._packed_stacks(self, packed):
             vis = self.vis_encoder(xb, mask_b)[0]
         cut = 1 if use_b else max_tag_length
-        with engine.small_f32_blas():
-            glob = F.normalize(vis[:, 0, :].float() @ self.vis_proj.float(), p=2, dim=-1)
+        glob = self._project(self._cls_rows(vis), self.vis_proj)
         return dict(seq=vis[:, cut:, :].contiguous(), mask=mask_b[:, cut:].contiguous(), glob=glob)
 
     @torch.no_grad()
@@ -632,6 +766,31 @@ def wra_sample_on_device(seq, phrase_index, img_index, text_len, draws=None, max
     return pos, neg
 
 
+def _wra_from_rows(txt_n, reg_n, valid_p, valid_r, draws=None):
+    """pos / neg similarities of wra_sample_on_device from already gathered, normalised rows: txt_n f32 [B, Pw, H]
+    (phrase rows, zero rows where invalid), reg_n f32 [B, Rw, H], validity masks; device draws (vl:1547-1549,
+    1572-1573: one of the top-3 regions per phrase, one other image per sample)."""
+    B, Pw, _ = txt_n.shape
+    dev = txt_n.device
+    if draws is None:
+        pos_pick = torch.randint(0, 3, (B, Pw), device=dev)
+        neg_pick = torch.randint(0, 3, (B, Pw), device=dev)
+        neg_img = (torch.arange(B, device=dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
+    else:
+        pos_pick, neg_pick, neg_img = (d.to(dev) for d in draws)
+    cnt = valid_p.sum(1).clamp(min=1).to(txt_n.dtype)
+
+    def mean_top3(regions, rvalid, pick):
+        sims = torch.bmm(txt_n, regions.transpose(1, 2)).masked_fill(~rvalid[:, None, :], float("-inf"))
+        top = sims.topk(3, dim=2)[0]
+        picked = top.gather(2, pick[:, :, None]).squeeze(2)
+        return torch.where(valid_p, picked, torch.zeros_like(picked)).sum(1) / cnt
+
+    pos = mean_top3(reg_n, valid_r, pos_pick)
+    neg = mean_top3(reg_n.index_select(0, neg_img), valid_r.index_select(0, neg_img), neg_pick)
+    return pos, neg
+
+
 def t2i_sim(sim_matrix):
     """vl:1543-1550 (single matrix form, used by phrase_mod='hard')."""
     if sim_matrix.shape[0] == 0:
@@ -724,8 +883,109 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         # are queued beside the joint stack; ITM / QA / WRA (chains of small kernels) run beside the text MLM head's
         # vocabulary GEMMs.  MVPTR_HEADS_BESIDE (A/B knob): 1 = only the first pair, 0 = everything on one stream.
         self.heads_beside = int(os.environ.get("MVPTR_HEADS_BESIDE", "2") or 2)
+        # training steps run the row-packed pipeline (BiBertImgModel.forward_packed + tapped rows for every head);
+        # False (or MVPTR_PACKED_PIPELINE=0) = the general path through padded tensors (same results to rounding)
+        self.packed_pipeline = os.environ.get("MVPTR_PACKED_PIPELINE", "1") != "0"
         self.apply(self.init_weights)
         self.tie_weights()
+
+    def _forward_packed(self, input_ids_a, token_type_ids_a, attention_mask_a, masked_lm_labels_a, qa_ans, input_ids_b,
+                        token_type_ids_b, attention_mask_b, masked_lm_labels_b, max_tag_length, position_ids_a, position_ids_b,
+                        img_feats, img_index, phrase_index):
+        """forward() for a training step, on packed rows end to end (vl:1218-1311): the backbone hands back the packed
+        joint output and row maps; every head reads its rows through ONE engine.MultiTapFn call per stack output.
+        Same losses as forward() (tests/test_model_gpu.py::test_packed_pipeline_equals_general_path)."""
+        dev = input_ids_a.device
+        n, La = input_ids_a.shape
+        keep_a, keep_b = (masked_lm_labels_a > -1).reshape(-1), (masked_lm_labels_b > -1).reshape(-1)
+        scored = engine.AsyncCounts([keep_a.sum(), keep_b.sum()])
+        early = {}
+
+        def uni_taps(pos_a, pos_b):
+            ib = torch.nonzero_static(keep_b, size=scored.get()[1]).view(-1)
+            early["labels_b"] = masked_lm_labels_b.reshape(-1).index_select(0, ib)
+            return [], [pos_b.view(-1).index_select(0, ib)]      # masked tag rows of the packed visual output
+
+        def uni_heads(taps_txt, taps_vis, sim_mat):
+            early["vis_mlm"], _ = self.half_mlm.loss_and_scores(taps_vis[0], early["labels_b"], want_scores=False)
+            early["retrieval"] = engine.ContrastiveLossFn.apply(sim_mat, self.logit_scale)
+
+        bb = self.bert
+        out = bb.forward_packed(input_ids_a, token_type_ids_a, attention_mask_a, max_tag_length, input_ids_b, token_type_ids_b,
+                                attention_mask_b, img_feats, position_ids_a=position_ids_a, position_ids_b=position_ids_b,
+                                uni_taps=uni_taps, beside=uni_heads)
+        two_streams = bool(bb.parallel_stacks) and _streams_allowed(bb.parallel_stacks)
+        main = torch.cuda.current_stream(dev)
+        side = engine.side_stream(dev) if two_streams else None
+        if two_streams:
+            main.wait_stream(side)
+            for t in (early["vis_mlm"], early["retrieval"]):
+                t.record_stream(main)
+        both, pos_j = out["both"], out["pos_j"]
+        Lj = pos_j.shape[1]
+        # rows of the packed joint output the heads read: [CLS] of the 2n sequences, scored text rows, phrase / region rows
+        ia = torch.nonzero_static(keep_a, size=scored.get()[0]).view(-1)           # flat positions in [n, La]
+        labels_a = masked_lm_labels_a.reshape(-1).index_select(0, ia)
+        rows_mlm = pos_j[:n, :La].reshape(-1).index_select(0, ia)
+        idxs = [pos_j[:, 0].contiguous(), rows_mlm]
+        wra = phrase_index is not None
+        if wra:
+            Pw = int(getattr(self.config, "max_phrases", None) or La)
+            Rw = Lj - La
+            p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
+            if getattr(self.config, "max_phrases", None):
+                torch._assert_async(((p1 - p0) <= Pw).all(), "a sample has more phrases than config.max_phrases")
+            ar_p, ar_r = torch.arange(Pw, device=dev), torch.arange(Rw, device=dev)
+            valid_p = ar_p[None, :] < (p1 - p0)[:, None]
+            valid_r = ar_r[None, :] < (i1 - i0)[:, None]
+            pj = pos_j[:n]
+            minus1 = torch.full((), -1, dtype=torch.int32, device=dev)
+            rows_p = torch.where(valid_p, pj.gather(1, (p0[:, None] + ar_p[None, :]).clamp(max=Lj - 1)), minus1)
+            rows_r = torch.where(valid_r, pj.gather(1, (i0[:, None] + ar_r[None, :]).clamp(max=Lj - 1)), minus1)
+            idxs += [rows_p.reshape(-1), rows_r.reshape(-1)]
+        taps = engine.MultiTapFn.apply(both, None, *idxs)
+        late = {}
+
+        def small_heads():
+            pooled = bb.pooler.forward_rows(taps[0])                     # [2n, H]: matched then hard pairs
+            score = engine.SmallLinearFn.apply(pooled, self.cls.seq_relationship.weight, self.cls.seq_relationship.bias, None, False)
+            label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
+            late["itm"] = engine.CeMeanFn.apply(score.view(-1, self.num_seq_relations), label)
+            if qa_ans is not None:
+                late["qa"] = CrossEntropyLoss(ignore_index=-1)(self.qa_head(pooled[:n]), qa_ans)
+            if wra:
+                H = both.shape[1]
+                txt_n = F.normalize(taps[2].view(n, Pw, H).float(), p=2, dim=-1)
+                reg_n = F.normalize(taps[3].view(n, Rw, H).float(), p=2, dim=-1)
+                pos_sims, neg_sims = _wra_from_rows(txt_n, reg_n, valid_p, valid_r)
+                valid = (p1 - p0) > 0
+                hinge = torch.clamp(neg_sims + 0.2 - pos_sims, min=0)
+                late["wra"] = torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype)
+
+        use_side = self.heads_beside >= 2 and two_streams
+        if use_side:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                small_heads()
+            for t in taps:
+                t.record_stream(side)
+        else:
+            small_heads()
+        masked_lm_loss, _ = self.cls.predictions.loss_and_scores(taps[1], labels_a, want_scores=False)
+        if use_side:
+            main.wait_stream(side)
+            for t in late.values():
+                t.record_stream(main)
+        vis_mlm_loss, retrieval_loss, next_sentence_loss = early["vis_mlm"], early["retrieval"], late["itm"]
+        total_loss = vis_mlm_loss + retrieval_loss + masked_lm_loss + next_sentence_loss
+        outs = (vis_mlm_loss, retrieval_loss, masked_lm_loss, next_sentence_loss)
+        if qa_ans is not None:
+            total_loss = total_loss + late["qa"]
+            outs = outs + (late["qa"],)
+        if wra:
+            total_loss = total_loss + late["wra"]
+            return (total_loss,) + outs + (late["wra"],)
+        return (total_loss,) + outs
 
     def tie_weights(self):
         emb = self.bert.embeddings.word_embeddings
@@ -737,6 +997,12 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 masked_lm_labels_b=None, max_tag_length=20, position_ids_a=None, position_ids_b=None,
                 head_mask=None, img_feats=None, is_img_match=None, img_index=None, phrase_index=None,
                 phrase_mod="sample"):
+        if (self.packed_pipeline and self.training and masked_lm_labels_a is not None and masked_lm_labels_b is not None and
+                head_mask is None and phrase_mod == "sample" and (phrase_index is None or (img_index is not None and self.wra_on_device)) and
+                self.bert.packed_ok(attention_mask_a, attention_mask_b, input_ids_a)):
+            return self._forward_packed(input_ids_a, token_type_ids_a, attention_mask_a, masked_lm_labels_a, qa_ans, input_ids_b,
+                                        token_type_ids_b, attention_mask_b, masked_lm_labels_b, max_tag_length, position_ids_a,
+                                        position_ids_b, img_feats, img_index, phrase_index)
         # Every data-dependent COUNT that only depends on the inputs (scored rows of the two MLM heads,
         # valid rows / longest sequence of the two uni-modal stacks) is fetched in ONE device->host copy
         # here, before any encoder work is queued: a sync in the middle of the step drains the launch
@@ -940,8 +1206,7 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
     def coarse_scores(self, text, image):
         """[n_text, n_image] cosine similarities of the global embeddings (forward_mod 'coarse' +
         the matrix product of run_retrieval.py:741-745)."""
-        with engine.small_f32_blas():
-            return text["glob"] @ image["glob"].t()
+        return self.bert._sim(text["glob"], image["glob"])
 
     @torch.no_grad()
     def rerank(self, text, image, txt_idx, img_idx, chunk=4096, packed=True):

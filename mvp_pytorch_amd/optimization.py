@@ -56,11 +56,14 @@ class AdamW(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=None):
+        """grad_scale: optional DEVICE f32 scalar multiplied into every gradient inside the update kernels (the
+        coefficient of the global-norm clip, hip.grad_clip_coef) — fused path only."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        fresh = set()     # weight caches whose bf16 copies this step's kernels rewrote
         for group in self.param_groups:
             ps, gs, ms, vs = [], [], [], []
             b1, b2 = group["betas"]
@@ -91,8 +94,25 @@ class AdamW(Optimizer):
                 step_size = step_size * math.sqrt(1.0 - b2 ** step_no) / (1.0 - b1 ** step_no)
             if ps[0].is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for p in ps) and \
                     all(g.dtype == torch.float32 and g.is_contiguous() for g in gs):
-                self._fused(ps, gs, ms, vs, b1, b2, group["eps"], step_size, 1.0 - group["lr"] * group["weight_decay"])
+                decay = 1.0 - group["lr"] * group["weight_decay"]
+                from . import engine
+                mir = [engine.mirror_of(p) for p in ps]
+                plain = [i for i, m in enumerate(mir) if m is None]
+                mirrored = [i for i, m in enumerate(mir) if m is not None]
+                if plain:
+                    pick = lambda xs: [xs[i] for i in plain]   # noqa: E731
+                    self._fused(pick(ps), pick(gs), pick(ms), pick(vs), b1, b2, group["eps"], step_size, decay, grad_scale)
+                if mirrored:
+                    pick = lambda xs: [xs[i] for i in mirrored]   # noqa: E731
+                    self._fused_mirror(pick(ps), pick(gs), pick(ms), pick(vs), pick(mir), b1, b2, group["eps"], step_size, decay,
+                                       grad_scale)
+                    for m in pick(mir):
+                        c = m["cache"]()
+                        if c is not None:
+                            fresh.add(c)
                 continue
+            if grad_scale is not None:
+                gs = torch._foreach_mul(gs, grad_scale)
             torch._foreach_mul_(ms, b1)
             torch._foreach_add_(ms, gs, alpha=1.0 - b1)
             torch._foreach_mul_(vs, b2)
@@ -102,12 +122,71 @@ class AdamW(Optimizer):
             torch._foreach_addcdiv_(ps, ms, denom, value=-step_size)
             if group["weight_decay"] > 0.0:
                 torch._foreach_mul_(ps, 1.0 - group["lr"] * group["weight_decay"])
+        for c in fresh:
+            c.mark_fresh()      # after the version bumps of _fused_mirror: the next forward pass finds the copies current
         return loss
+
+    def _fused_mirror(self, ps, gs, ms, vs, mirrors, b1, b2, eps, step_size, decay, grad_scale):
+        """Parameters that have bf16 working copies (engine.register_mirror): update + copies in one pass over
+        64 x 64 tiles (mvptr_adamw_mirror_multi)."""
+        from . import hip
+        dev = ps[0].device
+        key = ("mirror",) + tuple(p.data_ptr() for p in ps)
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        st = cache.get(key)
+        dt = np.dtype(hip.MIRROR_DT)
+        if st is None:
+            nbytes = len(ps) * dt.itemsize
+            st = dict(hosts=[torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)], events=[None, None],
+                      ptrs=[None, None], turn=0, dev=torch.empty(nbytes, dtype=torch.uint8, device=dev), base=None, total=0)
+            cache[key] = st
+        i = st["turn"]
+        st["turn"] = i ^ 1
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()
+        host = st["hosts"][i]
+        tab = host.numpy().view(dt)
+        dptr = lambda t: 0 if t is None else t.data_ptr()   # noqa: E731
+        ptrs = (tuple(g.data_ptr() for g in gs), tuple(m.data_ptr() for m in ms), tuple(v.data_ptr() for v in vs),
+                tuple((dptr(m["dst"]), dptr(m["dst_t"]), dptr(m["dst_f32"])) for m in mirrors))
+        if st["ptrs"][i] != ptrs:
+            tiles = []
+            for j, (p, m) in enumerate(zip(ps, mirrors)):
+                rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.numel())
+                dst, dst_t = m["dst"], m["dst_t"]
+                ld_dst = dst.stride(0) if (dst is not None and dst.dim() == 2) else cols
+                tab[j] = (p.data_ptr(), gs[j].data_ptr(), ms[j].data_ptr(), vs[j].data_ptr(), rows, cols, 0.0, 0.0, dptr(dst), ld_dst,
+                          dptr(dst_t), dst_t.stride(0) if dst_t is not None else 0, m["col_off_t"], 0, dptr(m["dst_f32"]))
+                wcols = max(cols, ld_dst) if dst is not None else cols
+                tiles.append(((rows + 63) // 64) * ((wcols + 63) // 64))
+            st["ptrs"][i] = ptrs
+            if st["base"] is None or st.get("tiles") != tiles:
+                base = np.zeros(len(ps) + 1, dtype=np.int32)
+                base[1:] = np.cumsum(tiles)
+                st["base"], st["total"], st["tiles"] = torch.from_numpy(base).to(dev), int(base[-1]), tiles
+        tab["step_size"] = step_size
+        tab["decay"] = decay
+        st["dev"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
+        hip.adamw_mirror_multi(st["dev"], st["base"], len(ps), st["total"], b1, b2, eps, grad_scale)
+        self._bump(ps)
+
+    @staticmethod
+    def _bump(ps):
+        # the kernel updated the parameters outside autograd's view; the bf16 weight caches key on
+        # Tensor._version, so mark the tensors as modified
+        setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+        if setter is not None:
+            setter(ps, [p._version + 1 for p in ps])
+        else:
+            torch._foreach_add_(ps, 0.0)
 
     _TABLE_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
                           ("step_size", "<f4"), ("decay", "<f4")])
 
-    def _fused(self, ps, gs, ms, vs, b1, b2, eps, step_size, decay):
+    def _fused(self, ps, gs, ms, vs, b1, b2, eps, step_size, decay, grad_scale=None):
         """One launch for the whole group through the C ABI (mvptr_adamw_multi)."""
         from . import hip
         dev = ps[0].device
@@ -155,14 +234,8 @@ class AdamW(Optimizer):
         ev = torch.cuda.Event()
         ev.record()
         st["events"][i] = ev
-        hip.adamw_multi(tab_dev, ent[0], ent[1], ent[2], b1, b2, eps)
-        # the kernel updated the parameters outside autograd's view; the bf16 weight caches key on
-        # Tensor._version, so mark the tensors as modified
-        setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
-        if setter is not None:
-            setter(ps, [p._version + 1 for p in ps])
-        else:
-            torch._foreach_add_(ps, 0.0)
+        hip.adamw_multi(tab_dev, ent[0], ent[1], ent[2], b1, b2, eps, grad_scale)
+        self._bump(ps)
 
     @staticmethod
     def _single(p, st, group):

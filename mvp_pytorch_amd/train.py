@@ -32,6 +32,24 @@ def model_inputs(batch, max_tag_length):
                 img_index=batch.get("image_index"), max_tag_length=max_tag_length)
 
 
+_clip_scratch = {}
+
+
+def clip_coefficient(model, grad_sync, max_grad_norm):
+    """run_pretrain_ml.py:639-640 (torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)); the
+    DeepSpeed recipe clips at 10.0 (oscar/tmp_config.json).  With a gradient arena on a HIP device: global norm
+    over the flat buckets in two kernel passes, returned as a device scalar for the fused AdamW (no pass that
+    rescales 1 GB of gradients, no host sync).  Otherwise torch's clip (rescales in place) -> None."""
+    flats = grad_sync.flats() if (grad_sync is not None and hasattr(grad_sync, "flats")) else None
+    if flats and flats[0].is_cuda:
+        from . import hip
+        key = flats[0].device.index
+        _, coef, _clip_scratch[key] = hip.grad_clip_coef(flats, max_grad_norm, _clip_scratch.get(key))
+        return coef
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    return None
+
+
 def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_weight=1.0, max_grad_norm=0.0,
                   grad_sync=None, return_losses=False):
     """One optimisation step.  grad_sync: optional callable run between backward and the
@@ -47,9 +65,13 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
     loss.backward()
     if grad_sync is not None:
         grad_sync()
+    grad_scale = None
     if max_grad_norm > 0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
-    optimizer.step()
+        grad_scale = clip_coefficient(model, grad_sync, max_grad_norm)
+    if grad_scale is not None:
+        optimizer.step(grad_scale=grad_scale)     # the clip coefficient multiplies the gradients inside the update kernels
+    else:
+        optimizer.step()
     scheduler.step()
     if grad_sync is not None and hasattr(grad_sync, "zero_grad"):
         grad_sync.zero_grad()   # keeps p.grad attached to the communication buckets

@@ -517,6 +517,18 @@ def adamw_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-6, weight_de
             p.add_(p, alpha=-lr * wd)
 
 
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) as the reference's step applies it
+    (oscar/run_pretrain_ml.py:639-640; norm_type 2): total = ||(||g_1||, ||g_2||, ...)||,
+    coef = min(1, max_norm / (total + 1e-6)), every gradient scaled in place -> total norm."""
+    gs = [g for g in grads.values() if g is not None]
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in gs]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in gs:
+        g.mul_(coef)
+    return total
+
+
 def warmup_linear(step, warmup_steps, t_total):
     """optimization.py:58-61 WarmupLinearSchedule.lr_lambda."""
     if step < warmup_steps:

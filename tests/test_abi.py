@@ -30,7 +30,7 @@ def test_library_exports_header_symbols():
 def test_abi_version_and_error_string():
     from mvp_pytorch_amd import hip
     lib = hip.load()
-    assert hip.query(0) == 2   # MVPTR_ABI_VERSION (2: row-packed mode fields in mvptr_layer_desc)
+    assert hip.query(0) == 3   # MVPTR_ABI_VERSION (3: grad_scale in mvptr_adamw_multi, mirror AdamW, clip, f32 heads, row gather/scatter)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.mvptr_gemm_nt(None, 8, None, 8, 0, 8, 8, 0, None, None, 0, None, None, 8, None, None, None)
     assert rc == -1

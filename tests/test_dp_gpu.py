@@ -97,3 +97,101 @@ def test_bench_launcher_two_ranks_on_one_gpu(dev):
     assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 32
     assert line["scaling"] == "weak" and line["value"] > 0 and line["ms_per_step"] > 0
     assert abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 0.02 * line["value"]
+
+
+# ------------------------------------------------------------------------------ round-3: the RCCL path on one GPU
+def _one_rank_worker(mode, port, q):
+    """Three training steps of the tiny two-stage model in a fresh process.  mode:
+    'plain'  no GradSync (gradients through autograd tensors)
+    'arena'  GradSync without a process group (gradient arena only)
+    'rccl' / 'rccl_opts'  init_process_group("nccl", world_size=1) + GradSync(force_collectives=True): hooks, bucket
+             launches on RCCL's stream, ReduceOp.AVG, used-parameter bitmap, finish(); 'rccl_opts' adds the opt-ins
+             (bf16 wire, row-sparse word table with its id all-gather + compact all-reduce, two compute streams)."""
+    import time
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp, modeling, train
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if mode.startswith("rccl"):
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    if mode == "rccl_opts":
+        cfg["parallel_stacks"] = "always"
+    torch.manual_seed(0)
+    model = modeling.BiBertImgForPreTraining(modeling.make_config(cfg)).to(dev)
+    model.train()
+    opt, sched = train.build_optimizer(model, lr=1e-3, t_total=10)
+    sync = None
+    if mode == "arena":
+        sync = dp.GradSync(model, bucket_mb=0.25)
+    elif mode == "rccl":
+        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True)
+    elif mode == "rccl_opts":
+        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.bfloat16,
+                           sparse_rows=[model.bert.embeddings.word_embeddings.weight])
+    dims = dict(B=4, T=12, P=3, G=6, R=5)
+    names = ("bert.txt_encoder.layer.0.attention.self.query.weight", "bert.mul_encoder.layer.1.output.dense.bias",
+             "bert.embeddings.word_embeddings.weight", "cls.predictions.decoder.weight", "bert.pooler.dense.weight",
+             "bert.txt_proj", "logit_scale", "bert.img_embedding.weight", "half_mlm.transform.LayerNorm.weight")
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if n in names}
+    losses, grads = [], {}
+    for step in range(3):
+        batch = synthetic_batch(dims, cfg, 100 + 10 * step, device=dev)
+        torch.manual_seed(step)
+        if step == 2:   # gradients of the last step, before the optimizer consumes them
+            out = model(**train.model_inputs(batch, dims["G"]))
+            out[0].backward()
+            if sync is not None:
+                sync()
+            grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in model.named_parameters() if n in names and p.grad is not None}
+            losses.append(float(out[0]))
+            break
+        out = train.pretrain_step(model, batch, opt, sched, max_tag_length=dims["G"], grad_sync=sync, return_losses=True, max_grad_norm=10.0)
+        losses.append(float(out[0]))
+    torch.cuda.synchronize()
+    delta = {n: (p.detach() - before[n]).float().cpu().numpy() for n, p in model.named_parameters() if n in names}
+    info = dict(buckets=0 if sync is None else len(sync.buckets), launched_from_hooks=0 if sync is None else sync._next,
+                qa_none=model.qa_head.weight.grad is None, stalled=0 if sync is None else sync.stalled_steps)
+    q.put((mode, losses, delta, grads, info))
+    if mode.startswith("rccl"):
+        dist.destroy_process_group()
+
+
+def _one_rank(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + (os.getpid() % 1000) + {"plain": 0, "arena": 1, "rccl": 2, "rccl_opts": 3}[mode]
+    p = ctx.Process(target=_one_rank_worker, args=(mode, port, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    return res
+
+
+def test_rccl_world1_and_gradient_arena_match_plain_step(dev):
+    """the RCCL code path (backend nccl) run on the single GPU with a one-rank group, hooks forced on:
+    same losses and, to the reproducibility of the atomically accumulated weight gradients, the same gradients and
+    parameter updates as a step without any GradSync; the gradient arena alone (no process group) likewise."""
+    import numpy as np
+    ref = _one_rank("plain")
+    for mode in ("arena", "rccl", "rccl_opts"):
+        got = _one_rank(mode)
+        print("one-rank", mode, got[1], got[4])
+        assert np.allclose(got[1], ref[1], rtol=2e-4), (mode, got[1], ref[1])
+        for n, gref in ref[3].items():
+            g = got[3][n]
+            rel = np.linalg.norm(g - gref) / (np.linalg.norm(gref) + 1e-30)
+            assert rel < (2e-2 if mode == "rccl_opts" else 2e-3), (mode, n, rel)    # bf16 wire: 8 mantissa bits
+        for n, dref in ref[2].items():
+            d = got[2][n]
+            # Adam moves an element by ~lr * sign(g): elements whose gradient is at the noise level may flip
+            close = np.abs(d - dref) <= 2e-4 + 0.05 * np.abs(dref)
+            assert close.mean() > (0.90 if mode == "rccl_opts" else 0.97), (mode, n, float(close.mean()))
+        assert got[4]["qa_none"]                       # qa_head never used: grad None on the arena paths too
+        if mode.startswith("rccl"):
+            assert got[4]["buckets"] > 2 and got[4]["launched_from_hooks"] > 0    # overlapped launches happened

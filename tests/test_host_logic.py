@@ -401,3 +401,190 @@ def test_weight_caches_are_per_device():
         engine._dev_key = orig
     assert p3 is pl and p3b is pl and p5 is p5b and p5 is not pl and len(p5) == 3 and p5.group is not pl.group
     assert engine._dev_key(torch.device("cpu")) == -1
+
+
+def _dp_nosync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    body = torch.nn.Linear(6, 4)
+    head = torch.nn.Linear(4, 2)       # used ONLY inside no_sync() (qa_head when qa_ans is present in the earlier micro-batches only)
+    idle = torch.nn.Linear(4, 3)       # used in step 0 only: goes hot, must be demoted again
+    m = torch.nn.ModuleDict(dict(body=body, head=head, idle=idle))
+    sync = dp.GradSync(m, bucket_mb=0.0001, demote_after=2)
+    out = []
+    for step in range(5):
+        g = torch.Generator().manual_seed(7 * step + rank)
+        x = torch.randn(3, 6, generator=g)
+        with sync.no_sync():
+            l1 = head(body(x)).pow(2).sum()
+            if step == 0:
+                l1 = l1 + idle(body(x)).sum()
+            l1.backward()
+        body(x * 0.5).sum().backward()
+        sync()
+        hot_idle = idle.weight in (sync._hot or set())
+        out.append((None if head.weight.grad is None else head.weight.grad.clone().numpy(),
+                    torch.autograd.grad(head(body(x)).pow(2).sum(), head.weight)[0].numpy(), hot_idle, sync.stalled_steps))
+        sync.zero_grad()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_head_used_only_under_no_sync_gloo():
+    """a parameter that only received gradients in the accumulation micro-batches (inside no_sync())
+    must count as used — its accumulated gradient is exchanged in finish() and kept, not set to None.  Also: a
+    parameter that stops producing gradients is demoted from the hot set after `demote_after` idle steps, so
+    it no longer holds back the hook launches of later hot buckets."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_nosync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0), (_, r1) = res
+    for step in range(5):
+        g0, l0, hot0, _ = r0[step]
+        g1, l1, hot1, _ = r1[step]
+        assert g0 is not None and g1 is not None, step
+        assert np.allclose(g0, (l0 + l1) / 2, atol=1e-5) and np.array_equal(g0, g1), step
+        assert hot0 == hot1
+    assert r0[0][2] and r0[1][2] and not r0[3][2] and not r0[4][2]     # hot after step 0, demoted after two idle steps
+    assert r0[4][3] >= 1       # `head` never becomes ready in the exchanging backward: those steps are counted as stalled
+
+
+def test_grad_arena_single_process_direct_delivery():
+    """World size 1, no process group: GradSync is the gradient arena.  Encoder-layer-like units are laid out back
+    to back in the unit's order, an autograd function can accumulate into the arena (`arena` / `direct` /
+    `delivered`) instead of returning gradients, parameters nobody touched end with grad = None (the optimizer
+    skips them), a tied row-sparse parameter is rejected."""
+    from mvp_pytorch_amd import dp, engine
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(3, 2))
+            self.b = torch.nn.Parameter(torch.randn(2))
+            self.c = torch.nn.Parameter(torch.randn(4))
+
+        def grad_arena_units(self):
+            return [[self.c, self.a, self.b]]       # kernel order differs from registration order
+
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, a, b, c):
+            ctx.ps = (a, b, c)
+            ctx.save_for_backward(x)
+            return (x @ a + b).sum() + (c * 2).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            a, b, c = ctx.ps
+            flat = engine.grad_sink().arena([c, a, b])
+            assert flat is not None and flat.numel() == 4 + 6 + 2
+            flat[:4] += 2 * g
+            flat[4:10] += (x.sum(0)[:, None].expand(3, 2) * g).reshape(-1)
+            flat[10:] += x.shape[0] * g
+            for p in (a, b, c):
+                engine.grad_sink().delivered(p)
+            return None, None, None, None
+
+    torch.manual_seed(0)
+    layer = Layer()
+    other = torch.nn.Linear(2, 2)
+    unused = torch.nn.Linear(2, 2)
+    m = torch.nn.ModuleDict(dict(layer=layer, other=other, unused=unused))
+    sync = dp.GradSync(m)
+    assert engine.grad_sink() is sync and not sync.exchange
+    x = torch.randn(5, 3)
+    (Direct.apply(x, layer.a, layer.b, layer.c) + other(torch.ones(1, 2)).sum()).backward()
+    sync()
+    assert torch.allclose(layer.c.grad, torch.full((4,), 2.0))
+    assert torch.allclose(layer.a.grad, x.sum(0)[:, None].expand(3, 2)) and torch.allclose(layer.b.grad, torch.full((2,), 5.0))
+    assert other.weight.grad is not None and unused.weight.grad is None and unused.bias.grad is None
+    # the unit is contiguous in the arena, in unit order
+    assert layer.a.grad.data_ptr() == layer.c.grad.data_ptr() + 16 and layer.b.grad.data_ptr() == layer.a.grad.data_ptr() + 24
+    sync.zero_grad()
+    assert unused.weight.grad is not None and float(layer.a.grad.abs().sum()) == 0.0
+    # tied row-sparse parameter
+    emb = torch.nn.Embedding(10, 4)
+    dec = torch.nn.Linear(4, 10, bias=False)
+    dec.weight = emb.weight
+    tied = torch.nn.ModuleDict(dict(emb=emb, dec=dec))
+    with pytest.raises(ValueError):
+        dp.GradSync(tied, sparse_rows=[emb.weight])
+    engine.set_grad_sink(None)
+
+
+def _dp_direct_worker(port, q):
+    """One gloo rank with force_collectives: a parameter used by TWO calls of a directly delivering function becomes
+    ready (its bucket launches) only after the second delivery; arena values equal the autograd result."""
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp, engine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+
+    class Scale(torch.autograd.Function):          # y = x * w, gradient of w delivered into the arena
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            ctx.w = w
+            engine.note_uses(ctx, (w,), 1)
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            buf, direct = engine.grad_buffer(ctx.w)
+            buf += (g * x).sum(0)
+            launched.append(sync._next)
+            return g * ctx.w, engine.grad_result(ctx.w, buf, direct)
+
+    torch.manual_seed(0)
+    m = torch.nn.ParameterDict(dict(w=torch.nn.Parameter(torch.randn(4)), v=torch.nn.Parameter(torch.randn(4))))
+    sync = dp.GradSync(m, bucket_mb=1e-6, force_collectives=True)
+    launched = []
+    res = []
+    for step in range(3):
+        launched.clear()
+        x = torch.randn(3, 4)
+        y = Scale.apply(Scale.apply(x, m["w"]), m["w"]) * m["v"]
+        y.sum().backward()
+        nxt = sync._next
+        sync()
+        ref = torch.autograd.grad((x * m["w"].detach().requires_grad_(False) * 1.0).sum(), [], allow_unused=True) if False else None
+        w = m["w"].detach().clone().requires_grad_(True)
+        ((x * w * w) * m["v"].detach()).sum().backward()
+        res.append((m["w"].grad.clone().numpy(), w.grad.numpy(), list(launched), nxt, len(sync.buckets)))
+        sync.zero_grad()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_direct_delivery_counts_uses_before_launch():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_direct_worker, args=(34500 + (os.getpid() % 2000), q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for step, (g, ref, launched, nxt, nb) in enumerate(res):
+        assert np.allclose(g, ref, rtol=1e-5), step
+        assert nb == 2
+        if step > 0:
+            # hot from step 1 on: w's bucket (index 0; v's bucket 1 is ready first but waits for its predecessor) must not
+            # have been launched when the second delivery of w starts (launched[k] = buckets launched at the time of
+            # backward call k), and both are out once backward has finished
+            assert launched == [0, 0] and nxt == 2, (step, launched, nxt)

@@ -3,6 +3,7 @@ bf16-rounded inputs.  Tolerances are for bf16 outputs with f32 accumulation."""
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -636,3 +637,203 @@ def test_fused_adamw_matches_oracle(dev):
         orc.adamw_step(ref, grads, state, lr=1e-2, eps=1e-8, weight_decay=lambda n: 0.0 if any(x in n for x in no_decay) else 0.01)
     for k in shapes:
         assert torch.allclose(params[k].detach().cpu(), ref[k], rtol=2e-5, atol=1e-6), k
+
+
+# ------------------------------------------------------------------------------ round-3 additions
+def test_adamw_mirror_clip_matches_oracle(dev):
+    """SURVEY §8 f1 in one pass: global-norm clip (mvptr_sumsq_partial + mvptr_clip_coef) -> AdamW that also writes
+    the bf16 working copies (mvptr_adamw_mirror_multi: row-major with K padding, transposed at a column offset,
+    packed f32 bias copy) against the oracle's clip_grad_norm + adamw_step and a plain cast of its result."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mvptr_oracle as orc
+    from mvp_pytorch_amd import engine, hip
+    from mvp_pytorch_amd.optimization import AdamW
+    g = torch.Generator(device="cpu").manual_seed(5)
+    H = 64
+    shapes = {"q.weight": (H, H), "k.weight": (H, H), "v.weight": (H, H), "q.bias": (H,), "k.bias": (H,), "v.bias": (H,),
+              "img.weight": (72, 2054), "ffn.weight": (200, 136), "plain.weight": (33, 17), "plain.LayerNorm.weight": (70001,)}
+    ref = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    params = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in ref.items()}
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    w_qkv, w_qkv_t = torch.zeros((3 * H, H), **bf), torch.zeros((H, 3 * H), **bf)
+    b_qkv = torch.zeros(3 * H, device=dev)
+    img_w = torch.ones((72, 2056), **bf)
+    ffn_w, ffn_t = torch.zeros((200, 136), **bf), torch.zeros((136, 200), **bf)
+    cache = engine.WeightCache()
+    for i, n in enumerate("qkv"):
+        engine.register_mirror(params[n + ".weight"], cache, dst=w_qkv[i * H:(i + 1) * H], dst_t=w_qkv_t, col_off_t=i * H)
+        engine.register_mirror(params[n + ".bias"], cache, dst_f32=b_qkv[i * H:(i + 1) * H])
+    engine.register_mirror(params["img.weight"], cache, dst=img_w)
+    engine.register_mirror(params["ffn.weight"], cache, dst=ffn_w, dst_t=ffn_t)
+    cache.stale(list(params.values()), force=False)
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in params.items() if not any(x in n for x in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in params.items() if any(x in n for x in no_decay)], "weight_decay": 0.0}]
+    opt = AdamW(groups, lr=1e-2, eps=1e-8)
+    total = sum(int(np.prod(s)) for s in shapes.values())
+    flat = torch.zeros(total, device=dev)
+    state = {}
+    for step in range(3):
+        grads = {k: torch.randn(s, generator=g) * (3.0 if step == 1 else 0.01) for k, s in shapes.items()}   # step 1 is clipped, 0 and 2 are not
+        o = 0
+        for k, p in params.items():
+            n = p.numel()
+            flat[o:o + n].copy_(grads[k].reshape(-1))
+            p.grad = flat[o:o + n].view_as(p)
+            o += n
+        norm, coef, _ = hip.grad_clip_coef([flat[:70000], flat[70000:]], 10.0)
+        opt.step(grad_scale=coef)
+        ref_norm = orc.clip_grad_norm(grads, 10.0)
+        assert abs(float(norm) - float(ref_norm)) < 1e-4 * float(ref_norm)
+        assert (float(coef) < 1.0) == (step == 1)
+        orc.adamw_step(ref, grads, state, lr=1e-2, eps=1e-8, weight_decay=lambda n: 0.0 if any(x in n for x in no_decay) else 0.01)
+        for k in shapes:
+            assert torch.allclose(params[k].detach().cpu(), ref[k], rtol=2e-5, atol=1e-6), (step, k)
+        # working copies = the updated masters, rounded once
+        for i, n in enumerate("qkv"):
+            w = params[n + ".weight"].detach()
+            assert torch.equal(w_qkv[i * H:(i + 1) * H], w.to(torch.bfloat16))
+            assert torch.equal(w_qkv_t[:, i * H:(i + 1) * H], w.t().to(torch.bfloat16))
+            assert torch.equal(b_qkv[i * H:(i + 1) * H], params[n + ".bias"].detach())
+        assert torch.equal(img_w[:, :2054], params["img.weight"].detach().to(torch.bfloat16)) and float(img_w[:, 2054:].float().abs().sum()) == 0.0
+        assert torch.equal(ffn_w, params["ffn.weight"].detach().to(torch.bfloat16))
+        assert torch.equal(ffn_t, params["ffn.weight"].detach().t().to(torch.bfloat16))
+        assert cache._fresh_once       # marked fresh after the version bumps
+        assert cache.stale(list(params.values())) is False and cache.stale(list(params.values()), force=True) is True
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (37, 2, 768), (512, 256, 100), (5, 5, 5)])
+def test_sgemm_small_variants(dev, M, N, K):
+    """mvptr_sgemm_small against f32 torch: both transposes, bf16 operands, gathered A rows, bias + tanh, accumulate."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    b = torch.randn(K, N, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = a.double() @ b.double()
+    tol = 2e-5 * float(ref.abs().max())
+    assert float((hip.sgemm_small(a, b).double() - ref).abs().max()) < tol
+    assert float((hip.sgemm_small(a.t().contiguous(), b, trans_a=True).double() - ref).abs().max()) < tol
+    assert float((hip.sgemm_small(a, b.t().contiguous(), trans_b=True).double() - ref).abs().max()) < tol
+    got = hip.sgemm_small(a, b, bias=bias, act="tanh", alpha=0.05)
+    assert float((got.double() - torch.tanh(0.05 * ref + bias.double())).abs().max()) < 2e-5
+    # gathered bf16 rows out of a larger buffer (the [CLS] rows of a sequence buffer), accumulate into C
+    big = torch.randn(3 * M + 1, K + 8, generator=g).to(dev).to(torch.bfloat16)
+    rows = torch.arange(M, device=dev, dtype=torch.int32) * 3 + 1
+    c0 = torch.randn(M, N, generator=g).to(dev)
+    got = hip.sgemm_small(big[:, :K], b, a_rows=rows, out=c0.clone(), accumulate=True)
+    ref2 = c0.double() + big[rows.long(), :K].double() @ b.double()
+    assert float((got.double() - ref2).abs().max()) < 2e-5 * float(ref2.abs().max())
+    # dW = X^T dY with X gathered (trans_a + a_rows)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    got = hip.sgemm_small(big[:, :K], dy, trans_a=True, a_rows=rows)
+    ref3 = big[rows.long(), :K].double().t() @ dy.double()
+    assert got.shape == (K, N) and float((got.double() - ref3).abs().max()) < 2e-5 * float(ref3.abs().max())
+
+
+def test_l2norm_and_clip_contrastive_loss(dev):
+    """mvptr_l2norm_fwd/bwd and mvptr_clip_ce_fwd/bwd against torch autograd (vl:525-527, 1238-1241)."""
+    import torch.nn.functional as F
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, H = 37, 768
+    y1 = torch.randn(n, H, generator=g).to(dev).requires_grad_(True)
+    y2 = torch.randn(n, H, generator=g).to(dev).requires_grad_(True)
+    ls = torch.tensor(float(np.log(1 / 0.07)), device=dev, requires_grad=True)
+    gt, gi = F.normalize(y1, p=2, dim=-1), F.normalize(y2, p=2, dim=-1)
+    sim = gt @ gi.t()
+    logits = sim * ls.exp()
+    pseudo = torch.arange(n, device=dev)
+    loss = (F.cross_entropy(logits, pseudo) + F.cross_entropy(logits.t(), pseudo)) / 2
+    (loss * 1.7).backward()
+    g1, inv1 = hip.l2norm_fwd(y1.detach())
+    g2, inv2 = hip.l2norm_fwd(y2.detach())
+    assert torch.allclose(g1, gt.detach(), atol=1e-6) and torch.allclose(g2, gi.detach(), atol=1e-6)
+    sim_h = hip.sgemm_small(g1, g2, trans_b=True)
+    assert torch.allclose(sim_h, sim.detach(), atol=2e-6)
+    loss_h, lse = hip.clip_ce_fwd(sim_h, ls.detach().reshape(1))
+    assert abs(float(loss_h) - float(loss)) < 1e-5 * abs(float(loss))
+    dls = torch.zeros(1, device=dev)
+    dsim = hip.clip_ce_bwd(sim_h, ls.detach().reshape(1), lse, torch.tensor([1.7], device=dev), dls)
+    assert abs(float(dls) - float(ls.grad)) < 1e-4 * abs(float(ls.grad)) + 1e-6
+    dgt = hip.sgemm_small(dsim, g2)
+    dgi = hip.sgemm_small(dsim, g1, trans_a=True)
+    dy1, dy2 = hip.l2norm_bwd(g1, inv1, dgt), hip.l2norm_bwd(g2, inv2, dgi)
+    for got, want in ((dy1, y1.grad), (dy2, y2.grad)):
+        assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max()) + 1e-8
+
+
+def test_gather_and_scatter_add_rows(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(9)
+    src = torch.randn(50, 128, generator=g).to(dev).to(torch.bfloat16)
+    idx = torch.tensor([3, 49, -1, 3, 0, 17], device=dev, dtype=torch.int32)
+    out = hip.gather_rows(src, idx)
+    ref = src[idx.clamp(min=0).long()].clone()
+    ref[2] = 0
+    assert torch.equal(out, ref)
+    dst = torch.zeros(50, 128, device=dev, dtype=torch.bfloat16)
+    upd = (torch.randint(-8, 8, (6, 128), generator=g).float() * 0.25).to(dev)   # exactly representable: order-independent sums
+    hip.scatter_add_rows(upd.to(torch.bfloat16), idx, dst)
+    hip.scatter_add_rows(upd, idx, dst)                                          # f32 source, rounded on the way
+    want = torch.zeros(50, 128, device=dev)
+    for i, d in enumerate(idx.tolist()):
+        if d >= 0:
+            want[d] += 2 * upd[i]
+    assert torch.equal(dst.float(), want)
+
+
+def test_pack_maps_against_host_walk(dev):
+    """mvptr_pack_maps: packed positions / source rows / starts / lengths of a one-segment pass (uni-modal stack, padded
+    source, interior padding) and of a two-segment pass built on it (joint sequences = text rows + region rows of two packed
+    outputs, hard negatives through `sel`), each against a plain host loop; > 1024 sequences exercises the chunked scan."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for B, La, Lb, cut in ((7, 9, 8, 3), (1300, 5, 6, 2)):
+        ma = (torch.rand(B, La, generator=g) < 0.6).float()
+        mb = (torch.rand(B, Lb, generator=g) < 0.5).float()
+        ma[:, 0] = 1
+        add_a, add_b = ((1 - ma) * -10000.0).to(dev), ((1 - mb) * -10000.0).to(dev)
+
+        def walk1(m, L):
+            pos, idx, st, ln, r = -np.ones((B, L), np.int64), [], [], [], 0
+            for b in range(B):
+                st.append(r)
+                for l in range(L):
+                    if m[b, l]:
+                        pos[b, l] = r
+                        idx.append(b * L + l)
+                        r += 1
+                ln.append(r - st[-1])
+            return pos, np.array(idx), np.array(st), np.array(ln)
+
+        pa, ia, sa, la, ca = hip.pack_maps([dict(mask=add_a, len=La, src_seq_stride=La)], B)
+        pb, ib, sb, lb, cb = hip.pack_maps([dict(mask=add_b, len=Lb, src_seq_stride=Lb)], B)
+        for (p, i, s_, l_, c), (m, L) in (((pa, ia, sa, la, ca), (ma.numpy(), La)), ((pb, ib, sb, lb, cb), (mb.numpy(), Lb))):
+            rp, ri, rs, rl = walk1(m, L)
+            assert np.array_equal(p.cpu().numpy(), rp) and np.array_equal(s_.cpu().numpy(), rs) and np.array_equal(l_.cpu().numpy(), rl)
+            assert c.tolist() == [len(ri), int(rl.max())] and np.array_equal(i.cpu().numpy()[:len(ri)], ri)
+        ra = int(ca[0])
+        sel_t = torch.randint(0, B, (2 * B,), generator=g)
+        sel_i = torch.randint(0, B, (2 * B,), generator=g)
+        pj, ij, sj, lj, cj = hip.pack_maps([dict(mask=add_a, sel=sel_t.to(dev), len=La, pos=pa),
+                                            dict(mask=add_b, sel=sel_i.to(dev), col0=cut, len=Lb - cut, pos=pb, src_base=ra)], 2 * B)
+        rpa, rpb = pa.cpu().numpy(), pb.cpu().numpy()
+        pos, idx, st, ln, r = -np.ones((2 * B, La + Lb - cut), np.int64), [], [], [], 0
+        for s_ in range(2 * B):
+            t, i = int(sel_t[s_]), int(sel_i[s_])
+            st.append(r)
+            for l in range(La):
+                if ma[t, l]:
+                    pos[s_, l] = r
+                    idx.append(rpa[t, l])
+                    r += 1
+            for l in range(cut, Lb):
+                if mb[i, l]:
+                    pos[s_, La + l - cut] = r
+                    idx.append(ra + rpb[i, l])
+                    r += 1
+            ln.append(r - st[-1])
+        assert np.array_equal(pj.cpu().numpy(), pos) and np.array_equal(sj.cpu().numpy(), np.array(st)) and np.array_equal(lj.cpu().numpy(), np.array(ln))
+        assert cj.tolist() == [r, max(ln)] and np.array_equal(ij.cpu().numpy()[:r], np.array(idx))
