@@ -15,7 +15,9 @@
  *   - return 0 on success, a negative mvptr_status otherwise; mvptr_last_error() returns a
  *     thread-local description of the last failure on the calling thread;
  *   - the library keeps no mutable global state (re-entrant, one process per GPU or several
- *     host threads on several devices).
+ *     host threads on several devices): kernel selection depends on the call's arguments only; the
+ *     environment is not read (the measurement tools use a separate diagnostic build with knobs,
+ *     `make -C mvp_pytorch_amd/csrc diag`).
  */
 #ifndef MVPTR_H
 #define MVPTR_H
@@ -69,13 +71,6 @@ typedef struct {
 
 int mvptr_query(int what, int64_t* out);
 const char* mvptr_last_error(void);
-
-/* Diagnostic knobs (kernel-configuration overrides used by tools/ for A/B measurements):
- * MVPTR_GEMM_CFG, MVPTR_GEMM_TN, MVPTR_NT_EXP, MVPTR_TN_GROUP, MVPTR_LN_GRID, MVPTR_GEMM_DELAY.
- * The environment variables of the same names are read ONCE per process (first kernel launch that
- * looks one up) and every active one is reported on stderr; this call overrides a knob afterwards
- * (value "" = default).  Not part of the reference's surface; not thread-safe against launches. */
-int mvptr_set_knob(const char* name, const char* value);
 
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue; A,B bf16, f32 accumulate (MFMA 16x16x32).
  * Replaces nn.Linear forward (y = x W^T + b): modeling_bert.py:348 (BertSelfOutput.dense),
@@ -351,7 +346,8 @@ int mvptr_clip_ce_bwd(const float* sim, int n, int64_t ld, const float* logit_sc
 
 /* ---- rows between the stacks (rows.hip) ------------------------------------------------------------------
  * Row gather / scatter-add over bf16 [rows, H] buffers: out[i,:] = src[idx[i],:] (idx < 0: zero row) and
- * dst[idx[i],:] += src[i,:] (src bf16, or f32 when src_f32; packed bf16 atomics, so rows may repeat).  With a
+ * dst[idx[i],:] += src[i,:] (src bf16, or f32 when src_f32; rows may repeat: f32 atomics into an f32 destination
+ * when dst_f32 — order-independent to 2^-24, the caller rounds once — else packed bf16 atomics).  With a
  * second buffer (src2 / dst2 != NULL) indices >= split address row idx - split of it: two packed stack outputs
  * used as one source.  Replace the index_select / masked_select / torch.cat chains that move rows between the
  * stacks and into the heads (oscar/modeling/modeling_vlbert.py:519,544-552,586-590,1231-1234,1245;
@@ -360,7 +356,8 @@ int mvptr_clip_ce_bwd(const float* sim, int n, int64_t ld, const float* logit_sc
 int mvptr_gather_rows(const void* src, int64_t ld_src, const void* src2, int64_t ld_src2, int split,
                       const int32_t* idx, void* out, int64_t ld_out, int n, int H, void* stream);
 int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f32, const int32_t* idx, void* dst,
-                           int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int n, int H, void* stream);
+                           int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int dst_f32, int n, int H,
+                           void* stream);
 
 /* Index maps of a row-packed pass, built on the device from additive attention masks (valid slot <=> 0).
  * Output sequence s (0 <= s < n_seq) is the concatenation of nseg (1 or 2) segments; segment k covers the slots
@@ -474,17 +471,6 @@ int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights
                             const void* x, const float* mask_add, const void* saved,
                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
                             int64_t ws_bytes, void* stream);
-
-/* Same, with the layer's two grouped weight-gradient launches issued on `wgrad_stream` (ordered behind the
- * kernels that produce their operands by events; NULL = on `stream`).  The caller owns the other half of
- * the contract: the operands the weight gradients read live in `ws` and `saved`, so `ws` must not be
- * overwritten (next layer's call with the same `ws`) and `g` must not be read before `wgrad_stream` has
- * caught up — mvp_pytorch_amd.engine.EncoderFn alternates two workspaces and joins the streams at the end
- * of a stack's backward pass. */
-int mvptr_encoder_layer_bwd2(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
-                             const void* x, const float* mask_add, const void* saved,
-                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
-                             int64_t ws_bytes, void* stream, void* wgrad_stream);
 
 /* Measurement helper (never on the product path): reads `bytes` (a multiple of 4096) of `src` exactly
  * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,

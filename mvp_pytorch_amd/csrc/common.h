@@ -36,22 +36,25 @@ void mvptr_set_error(const char* fmt, ...);
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// Diagnostic knobs.  The environment is read ONCE, when the first knob is looked up (and every
-// active knob is reported on stderr): a stray variable cannot silently change kernel selection
-// from launch to launch.  Tools that A/B configurations inside one process use mvptr_set_knob().
+// Kernel-configuration knobs.  The PRODUCT library (libmvptr_hip.so) has none: mvptr_knobs() returns a constant
+// table of defaults, nothing reads the environment and nothing can change kernel selection at run time.  The
+// DIAGNOSTIC build (-DMVPTR_DIAG_BUILD, `make diag`: libmvptr_hip_diag.so, loaded by the measurement tools with
+// MVPTR_LIB=diag) reads the environment ONCE, when the first knob is looked up (every active knob is reported on
+// stderr), and exports mvptr_set_knob() for A/B runs inside one process.
 struct MvptrKnobs {
-  char gemm_cfg[16];   // MVPTR_GEMM_CFG   force a gemm_nt tile configuration
-  char gemm_tn[16];    // MVPTR_GEMM_TN    force a gemm_tn configuration
-  int nt_exp;          // MVPTR_NT_EXP     gemm_nt experiment flags
+  char gemm_cfg[16];   // MVPTR_GEMM_CFG   force a gemm_nt tile configuration ("t256k" | "w4" | "s128")
+  char gemm_tn[16];    // MVPTR_GEMM_TN    force a gemm_tn configuration ("32" | "64" | "k2" | "K" | "q")
+  int nt_exp;          // MVPTR_NT_EXP     experiment flags (bit 5: n-major tile order of gemm_tn; bit 9: non-temporal gelu' stores)
   int tn_group;        // MVPTR_TN_GROUP   0: one launch per weight-gradient problem
   int ln_grid;         // MVPTR_LN_GRID    partial rows of the LayerNorm backward pass (0 = default)
   int tn_splits;       // MVPTR_TN_SPLITS  force the M-split count of the weight-gradient launches (0 = planner)
   int nt_group[2];     // MVPTR_NT_GROUP   "gm[,gn]": tile order of gemm_nt (row tiles per group, column tiles per chunk; 0 = default)
-  int tn_slab;         // MVPTR_TN_SLAB    1: per-split f32 slabs + reduce kernel (fixed summation order) instead of f32 atomics
-  int delay[3];        // MVPTR_GEMM_DELAY "cycles[,lo,hi]"
-  unsigned long long stamps;  // MVPTR_GEMM_STAMPS (diagnostic builds)
+  unsigned long long stamps;  // MVPTR_GEMM_STAMPS (stamp / timeline builds)
 };
 const MvptrKnobs& mvptr_knobs();
+#ifdef MVPTR_DIAG_BUILD
+extern "C" int mvptr_set_knob(const char* name, const char* value);
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -74,9 +74,7 @@ struct GemmNtArgs {
   int vec_out_ok;   // 16-byte stores allowed on out0/out1
   int vec_aux_ok;   // 16-byte loads allowed on aux
   int vec_bias_ok;  // 16-byte loads allowed on bias
-  int delay_cycles;  // experiment (MVPTR_GEMM_DELAY): start delay of the second resident workgroups
-  int delay_lo, delay_hi;
-  int exp_flags;  // experiments (MVPTR_NT_EXP): bit 0 = persistent kernel without next-tile prefetch
+  int stash_nt;  // diagnostic build (MVPTR_NT_EXP bit 9): EPI_BIAS_GELU stores gelu'(u) — read only in the backward pass — non-temporally
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
   // fused vocabulary decoder + cross entropy (mvptr_decoder_ce_fwd / _bwd)
   const int64_t* labels;  // [M], < 0 or >= N: row not scored
@@ -131,8 +129,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-      if (p.exp_flags & 256) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(op));  // A/B knob (MVPTR_NT_EXP bit 8)
-      else *reinterpret_cast<bf16x8*>(op) = o;
+      *reinterpret_cast<bf16x8*>(op) = o;
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -275,7 +272,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
         dg[e] = d2.x;
         dg[e + 1] = d2.y;
       }
-      store_bf8(p.out0, m, dg);
+      if (p.stash_nt && nfull && p.vec_out_ok) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(dg[e]);
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>((__bf16*)p.out0 + (int64_t)m * p.ldc + n));
+      } else {
+        store_bf8(p.out0, m, dg);
+      }
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
       if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
@@ -351,25 +355,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
   unsigned long long tl_start, tl_loop, tl_end;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_start)::"memory");
 #endif
-  if (p.delay_cycles > 0) {
-    // experiment: hi >= 0: workgroups lo <= id < hi start `cycles` late; hi < 0: the first `lo`
-    // workgroups start (id / 8 % P) / P * cycles late, P = -hi (phases spread inside each XCD)
-    long long d = 0;
-    if (p.delay_hi >= 0) {
-      if ((int)blockIdx.x >= p.delay_lo && (int)blockIdx.x < p.delay_hi) d = p.delay_cycles;
-    } else if (p.delay_hi == -1000) {
-      // phases spread BETWEEN the 8 XCD groups (blockIdx % 8), equal inside a group: the workgroups that
-      // share an L2 keep sweeping K together while the groups' output bursts come at different times
-      if ((int)blockIdx.x < p.delay_lo) d = (long long)p.delay_cycles * ((int)blockIdx.x & 7) / 8;
-    } else if ((int)blockIdx.x < p.delay_lo) {
-      const int P = -p.delay_hi;
-      d = (long long)p.delay_cycles * (((int)blockIdx.x >> 3) % P) / P;
-    }
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(16);
-  }
-  // MVPTR_NT_EXP bit 14 (A/B knob): no XCD remap — consecutive logical tiles go to consecutive XCDs
-  const int t = (p.exp_flags & 16384) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+  const int t = xcd_remap(blockIdx.x, nwg);
   // order of the logical tiles (an XCD owns a contiguous run of them): column tiles in chunks of
   // group_n; inside a chunk, groups of group_m row tiles x the chunk's columns, row tile fastest.
   // A chunk narrower than the matrix keeps that part of B in the XCD's L2 while its rows stream by.
@@ -450,56 +436,6 @@ void gemm_nt_kernel(GemmNtArgs p) {
 
   const int nk = (p.K + BK - 1) / BK;
   constexpr int LPS = NA + NB;  // loads per stage per thread
-  if constexpr (SCHED == 2) {
-    // Staggered halves: the MFMA pipe of a SIMD is shared by wave i and wave i + NWAVES/2.  If both
-    // run "issue loads, then MFMAs" in lockstep, the pipe idles while every wave issues its LDS-DMA
-    // and fragment reads (~400 cycles per K-step measured with s_memtime) and then serialises both
-    // waves' MFMA bursts.  The second half of the waves therefore runs one burst behind: after each
-    // barrier it first issues the MFMAs of the PREVIOUS K-step (fragments kept in registers across
-    // the barrier) while the first half issues its loads, then swaps roles.
-    static_assert(KS == 1, "stagger schedule is written for BK = 32");
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (s < nk) stage(s, s * BK);
-    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NWAVES / 2;
-    bf16x8 xf[MT], wf[4];
-    auto mma = [&]() {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int younger = min(STAGES - 2, nk - 1 - kt);
-      if (younger >= 3)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * LPS) : "memory");
-      else if (younger == 2)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
-      else if (younger == 1)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const char* la = lds + buf * STAGE_BYTES;
-      const char* lb = la + A_BYTES;
-      if (late && kt > 0) mma();  // K-step kt-1 of the late half, beside the early half's loads
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
-      if (kt + STAGES - 1 < nk) {
-        int nb = buf + STAGES - 1;
-        if (nb >= STAGES) nb -= STAGES;
-        stage(nb, (kt + STAGES - 1) * BK);
-      }
-      if (!late) mma();
-      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
-    }
-    if (late) mma();
-  } else {
   // prologue: STAGES-1 stages in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -585,7 +521,6 @@ void gemm_nt_kernel(GemmNtArgs p) {
     o[4] = (unsigned long long)nk;
   }
 #endif
-  }
 
   // ------------------------------------------------------------------ epilogue
 #ifdef MVPTR_TIMELINE_BUILD
@@ -604,1215 +539,6 @@ void gemm_nt_kernel(GemmNtArgs p) {
     o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
   }
 #endif
-}
-
-// Persistent form of the 256x256 / BK 64 configuration: one workgroup per CU walks over its tiles.
-// The 2 x 64 KiB operand ring and a separate 32-KiB epilogue staging area fill the 160-KiB LDS, so
-// after the last K-step of a tile both ring stages are free: the LDS-DMA loads of the NEXT tile's
-// first two K-steps are issued before the epilogue starts and land while it runs (pipeline-fill
-// latency and the workgroup hand-over gap, ~3 us of a 26-32 us tile at K = 768, leave the critical
-// path).
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(GemmNtArgs p) {
-  using C = Cfg<64, 2, 2, 4, 8>;
-  constexpr int BM = C::BM, BN = C::BN, BK = 64, WN = 4;
-  constexpr int A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, ROW_B = C::ROW_B, CHUNKS = C::CHUNKS;
-  constexpr int RPI = C::ROWS_PER_INSTR, NA = C::NA, NB = C::NB, KS = C::KS;
-  constexpr int NWAVES = C::NWAVES, MT = C::MT, WROWS = C::MT * 16;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = gridDim.x;
-
-  // With 128-byte rows (8 chunks) the swizzle (row >> 1) & 7 of staging instruction i and of
-  // fragment row-block i does not depend on i (their row offsets are multiples of 16), so one
-  // per-lane offset serves every instruction; the per-instruction part is a uniform constant.
-  static_assert(CHUNKS == 8 && RPI == 8, "persistent kernel is written for BK = 64");
-  const int srow = wave * RPI + lane / CHUNKS;                       // staging row of instruction 0
-  const int kc = ((lane % CHUNKS) ^ swz_row(srow, CHUNKS)) * 8;      // first k of this lane's chunk
-  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
-  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
-  const uint32_t stepA = (uint32_t)(NWAVES * RPI) * (uint32_t)p.lda * 2u;  // 64 rows further
-  const uint32_t stepB = (uint32_t)(NWAVES * RPI) * (uint32_t)p.ldb * 2u;
-  const int wm = wave / WN, wn = wave % WN;
-  const int c16 = lane & 15, q4 = lane >> 4;
-  uint32_t fx0[KS], fw0[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int rx = wm * WROWS + c16, rw = wn * 64 + c16;
-    fx0[ks] = rx * ROW_B + (((ks * 4 + q4) ^ swz_row(rx, CHUNKS)) << 4);
-    fw0[ks] = rw * ROW_B + (((ks * 4 + q4) ^ swz_row(rw, CHUNKS)) << 4);
-  }
-  float* st = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * (16 * 64);
-  const int nk = (p.K + BK - 1) / BK;
-
-  // round r: workgroup w takes logical tile r * grid + remap(w) (bijective inside the round, the
-  // workgroups of one XCD get neighbouring tiles), grouped GROUP_M row-tiles x all column tiles
-  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
-    const int base = round * grid;
-    const int left = ntiles - base;
-    if (left <= 0) return false;
-    const int nthis = min(left, grid);
-    if ((int)blockIdx.x >= nthis) return false;
-    const int t = base + xcd_remap(blockIdx.x, nthis);
-    const int gsz = GROUP_M * p.tiles_n;
-    const int grp = t / gsz;
-    const int first_m = grp * GROUP_M;
-    const int gm = min(GROUP_M, p.tiles_m - first_m);
-    const int in_g = t - grp * gsz;
-    m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
-    return true;
-  };
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int buf, int k0) {
-    char* la = lds + buf * STAGE_BYTES;
-    char* lb = la + A_BYTES;
-    const bool in_k = (k0 + kc < p.K);
-    // opaque copies: keeps the compiler from hoisting the eight per-instruction offsets out of the
-    // K loop as loop invariants (they would be spilled; one v_add each is cheaper)
-    uint32_t oa = offA0, ob = offB0;
-    asm volatile("" : "+v"(oa), "+v"(ob));
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const uint32_t va = in_k ? oa + (uint32_t)i * stepA + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const uint32_t vb = in_k ? ob + (uint32_t)i * stepB + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
-    }
-  };
-  auto rsrc_a = [&](int m0) {
-    const int rows_a = min(BM, p.M - m0);
-    return make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
-  };
-  auto rsrc_b = [&](int n0) {
-    const int rows_b = min(BN, p.N - n0);
-    return make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
-  };
-
-  int m0 = 0, n0 = 0;
-  if (!tile_origin(0, m0, n0)) return;
-  __amdgpu_buffer_rsrc_t rsA = rsrc_a(m0), rsB = rsrc_b(n0);
-  bool prefetched = false;
-  for (int round = 0;; ++round) {
-    f32x4 acc[4][MT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!prefetched) stage(rsA, rsB, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-      // double buffer: K-step kt has landed when nothing is outstanding (the epilogue's stores of
-      // the previous tile included); the barrier also frees the other buffer for K-step kt + 1
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      const int buf = kt & 1;
-      const char* la = lds + buf * STAGE_BYTES;
-      const char* lb = la + A_BYTES;
-      bf16x8 xf[MT], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[0] + i * 16 * ROW_B);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[0] + i * 16 * ROW_B);
-      if (kt + 1 < nk && !(prefetched && kt == 0)) stage(rsA, rsB, buf ^ 1, (kt + 1) * BK);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks > 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[ks] + i * 16 * ROW_B);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[ks] + i * 16 * ROW_B);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-    __syncthreads();  // every wave is done with the operand ring
-    int m1 = 0, n1 = 0;
-    const bool more = tile_origin(round + 1, m1, n1);
-    const bool pf = more && !(p.exp_flags & 1);
-    __amdgpu_buffer_rsrc_t rsA1 = rsA, rsB1 = rsB;
-    if (more) {
-      rsA1 = rsrc_a(m1);
-      rsB1 = rsrc_b(n1);
-    }
-    if (pf) {
-      stage(rsA1, rsB1, 0, 0);
-      if (nk > 1) stage(rsA1, rsB1, 1, BK);
-    }
-    // the epilogue's lane-derived constants are recomputed per tile (opaque lane copy) instead of
-    // living in registers across the MFMA loop
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    nt_epilogue<EPI, MT, 16>(p, acc, st, m0, n0, wm, wn, lane_e);
-    if (!more) break;
-    m0 = m1;
-    n0 = n1;
-    rsA = rsA1;
-    rsB = rsB1;
-    prefetched = pf;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// "Q" configuration: 256x256 tile per 256-thread workgroup, FOUR waves as 2(M) x 2(N), each
-// 128x128 = 4x4 v_mfma_f32_32x32x16_bf16 (256 accumulator registers; one wave per SIMD owns the
-// whole 512-register file).  Per MFMA: half a ds_read_b128 (8 fragment reads per 16 MFMAs) and the
-// fewest L2->LDS bytes per FLOP of any tile here.
-//  * 64 k per stage (whole 128-byte lines per row: half-line fetches of a 32-k stage measured 10 %
-//    slower), 64 KiB per stage, double buffer; a row's eight 16-byte chunks XOR-swizzled with
-//    (row >> 1) & 7: the 32x32x16 operand reads (a lane reads chunk 2s+h of row r) are conflict free.
-//  * the LDS-DMA loads are hand-issued (lds_dma16): hipcc drains the builtin form with a vmcnt(0)
-//    in front of the next ds_read, which serialises a ring; here every wait is the counted one in
-//    front of the barrier.
-//  * rotated loop (see gemm_tn_q_kernel): the barrier sits in front of the last of a stage's four
-//    16-k sub-steps; the LDS-DMA issue of the stage after next and the fragment reads of the next
-//    stage run under that sub-step's 16 MFMAs; quarters pinned with sched_barrier(0).
-//  * the weight tile is the MFMA A operand: a lane holds 4 consecutive output columns per register
-//    group; v_permlane32_swap pairs two groups so that each lane owns 8 consecutive columns of one
-//    row and the epilogue finishes straight from registers with 16-byte loads / stores (no LDS
-//    restaging; a row's 128 columns are written by 4 consecutive store instructions).
-template <int EPI>
-__device__ __forceinline__ void ntq_finish8(const GemmNtArgs& p, int m, int n, float (&v)[8]) {
-  // v = 8 consecutive columns n..n+7 of row m of the f32 product; N % 8 == 0 (launch condition)
-  if (m >= p.M || n >= p.N) return;
-  if ((p.exp_flags & 4) && v[0] != 12345.678f) return;  // ablation (MVPTR_NT_EXP bit 2): no loads / math / stores
-  if (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD && p.bias != nullptr) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] += b0[e];
-      v[4 + e] += b1[e];
-    }
-  }
-  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
-  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (kNeedsAux && p.aux != nullptr) {
-    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p.aux + (int64_t)m * p.ld_aux + n);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = bf2f(x[e]);
-  }
-  auto store_bf8 = [&](void* base, const float (&o)[8]) {
-    bf16x8 t;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = f2bf(o[e]);
-    *reinterpret_cast<bf16x8*>((__bf16*)base + (int64_t)m * p.ldc + n) = t;
-  };
-  if (EPI == MVPTR_EPI_BIAS) {
-    store_bf8(p.out0, v);
-  } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-    float g[8], dg[8];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      f32x2 a2, d2;
-      gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-      g[e] = a2.x;
-      g[e + 1] = a2.y;
-      dg[e] = d2.x;
-      dg[e + 1] = d2.y;
-    }
-    store_bf8(p.out0, dg);
-    store_bf8(p.out1, g);
-  } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2)  // N even: (m * N + n + e) even, lanes own whole hash pairs
-      drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += a[e];
-    store_bf8(p.out0, v);
-  } else if (EPI == MVPTR_EPI_GELU_BWD) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= a[e];
-    store_bf8(p.out0, v);
-  } else if (EPI == MVPTR_EPI_ADD) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += a[e];
-    store_bf8(p.out0, v);
-  } else if (EPI == MVPTR_EPI_F32) {
-    float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
-    *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-  } else if (EPI == MVPTR_EPI_BIAS_TANH) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-    store_bf8(p.out0, v);
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_ntq_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int OP_B = 256 * BK * 2;      // one operand tile of a stage (32 KiB)
-  constexpr int STAGE_B = 2 * OP_B;       // activations, then weights
-  constexpr int LPS = 16;                 // LDS-DMA instructions per wave and stage
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nwg);
-  const int gsz = GROUP_M * p.tiles_n;
-  const int grp = t / gsz;
-  const int first_m = grp * GROUP_M;
-  const int gm = min(GROUP_M, p.tiles_m - first_m);
-  const int in_g = t - grp * gsz;
-  const int tm = first_m + in_g % gm;
-  const int tn = in_g / gm;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int rows_a = min(BM, p.M - m0);
-  const int rows_b = min(BN, p.N - n0);
-  const u32x4 rsA = make_rsrc_words(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
-  const u32x4 rsB = make_rsrc_words(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
-  const uint32_t lds0 = lds_addr(lds);
-
-  // staging instruction i (0..7) of this wave fills KiB (i * 4 + wave) of an operand tile: rows
-  // 8 * (i * 4 + wave) .. + 7, whole 128-byte lines; lane -> row + (lane >> 3), 16-byte slot
-  // lane & 7 holds k-chunk slot ^ ((row >> 1) & 7) = slot ^ ((4 * (wave & 1) + (lane >> 4)) & 7)
-  const int srow = wave * 8 + (lane >> 3);
-  const int kc = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
-  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
-  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
-  const uint32_t rstepA = (uint32_t)(32 * p.lda * 2), rstepB = (uint32_t)(32 * p.ldb * 2);
-  auto stage_piece = [&](int buf, int st, int i) {
-    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
-    const bool in_k = (st * BK + kc < p.K);
-    if (i < 8) {
-      const uint32_t va = in_k ? offA0 + (uint32_t)i * rstepA + (uint32_t)(st * BK * 2) : MVPTR_OOB;
-      lds_dma16(rsA, va, la + i * 4096);
-    } else {
-      const uint32_t vb = in_k ? offB0 + (uint32_t)(i - 8) * rstepB + (uint32_t)(st * BK * 2) : MVPTR_OOB;
-      lds_dma16(rsB, vb, la + OP_B + (i - 8) * 4096);
-    }
-  };
-
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r31 = lane & 31, h = lane >> 5;
-  // fragment offsets of the four 16-k sub-steps; row block b adds b * 4096 (an immediate)
-  uint32_t fx[4], fw[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    const uint32_t o = (uint32_t)(r31 * 128 + (((2 * s4 + h) ^ ((r31 >> 1) & 7)) << 4));
-    fx[s4] = (uint32_t)(wm * 128 * 128) + o;
-    fw[s4] = (uint32_t)(OP_B + wn * 128 * 128) + o;
-  }
-
-  f32x16 acc[4][4];  // [nb][mb]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8 wf0[4], xf0[4], wf1[4], xf1[4];
-  // quarter nb multiplies W fragment nb with all four X fragments.  The eight fragment reads of a
-  // sub-step are spread X0 X1 X2 | X3 W0 W1 | W2 W3 | - over the quarters of the previous sub-step:
-  // the last quarter issues none, so they have all landed when the next sub-step's first MFMA waits
-  auto read_frag = [&](const char* base, int s4, int f, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
-    if (f < 4) xf[f] = *reinterpret_cast<const bf16x8*>(base + fx[s4] + f * 4096);
-    else wf[f - 4] = *reinterpret_cast<const bf16x8*>(base + fw[s4] + (f - 4) * 4096);
-  };
-  auto read_quarter = [&](const char* base, int s4, int j, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
-    constexpr int first[5] = {0, 3, 6, 8, 8};
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (f >= first[j] && f < first[j + 1]) read_frag(base, s4, f, wf, xf);
-  };
-  auto mma_row = [&](int nb, const bf16x8(&wf)[4], const bf16x8(&xf)[4]) {
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-      acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-  };
-
-  const int nsteps = (p.K + BK - 1) / BK;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) stage_piece(0, 0, j);
-  if (nsteps > 1) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) stage_piece(1, 1, j);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) read_quarter(lds, 0, j, wf0, xf0);
-  // One 64-k stage = four 16-k sub-steps of 16 MFMAs; sub-step s multiplies the fragments read
-  // during sub-step s-1.  The barrier sits in front of the LAST sub-step: by then this wave has read
-  // all of stage st (lgkmcnt(0)) and the next stage has landed (it is the only one in flight), so the
-  // last sub-step's MFMAs cover the LDS-DMA issue of stage st+2 into the buffer just freed and the
-  // reads of the next stage's first fragments.
-  // MORE / REFILL are compile-time tags (run-time branches around the MFMA quarters make hipcc spill).
-  auto step = [&](int st, auto more_tag, auto refill_tag) {
-    constexpr bool MORE = decltype(more_tag)::value, REFILL = decltype(refill_tag)::value;
-    const char* cur = lds + (st & 1) * STAGE_B;
-    const char* nxt = lds + ((st + 1) & 1) * STAGE_B;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 1, j, wf1, xf1);
-      mma_row(j, wf0, xf0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 2, j, wf0, xf0);
-      mma_row(j, wf1, xf1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 3, j, wf1, xf1);
-      mma_row(j, wf0, xf0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (MORE) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of stage st are done
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (REFILL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage_piece(st & 1, st + 2, 4 * j + i);
-      }
-      if constexpr (MORE) read_quarter(nxt, 0, j, wf0, xf0);
-      mma_row(j, wf1, xf1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  {
-    int st = 0;
-    for (; st + 2 < nsteps; ++st) step(st, std::true_type{}, std::true_type{});
-    if (st + 1 < nsteps) step(st++, std::true_type{}, std::false_type{});
-    step(st, std::false_type{}, std::false_type{});
-  }
-
-  if (p.exp_flags & 2) return;  // ablation (MVPTR_NT_EXP bit 1): no epilogue at all
-  // epilogue straight from the accumulators.  Block (nb, mb): lane (r31, h) holds row m = ..+r31,
-  // columns 8g + 4h + (0..3) in registers 4g..4g+3; swapping group 2q+1 of the low half-wave with
-  // group 2q of the high half-wave leaves columns 16q + 8h + (0..7) in each lane.
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  const int er = lane_e & 31, eh = lane_e >> 5;
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int m = m0 + wm * 128 + mb * 32 + er;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = acc[nb][mb][8 * q2 + e], hi = acc[nb][mb][8 * q2 + 4 + e];
-          // lanes 32-63 of `lo` <-> lanes 0-31 of `hi` (two wait states after a VALU write of either)
-          asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-          v[e] = lo;
-          v[4 + e] = hi;
-        }
-        const int n = n0 + wn * 128 + nb * 32 + 16 * q2 + 8 * eh;
-        ntq_finish8<EPI>(p, m, n, v);
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// "QP": the Q tile as a PERSISTENT kernel with a DEFERRED epilogue.  With K = 768 a 256x256 tile is
-// ~20 us of MFMA work and 128-256 KiB of output; when every CU finishes its tile at the same time
-// the outputs leave as one burst at the chip's write rate (~3 TB/s: 100 us of a 300-us launch,
-// measured with the stores ablated) while no MFMA runs.  Here a workgroup walks over its tiles with
-// one continuous LDS-DMA / MFMA pipeline; at the end of a tile the accumulators (+ bias) are packed
-// to bf16 into 128 "pending" registers, and the epilogue proper (permlane swaps to 8-column runs,
-// GELU, the 16-byte stores) is dripped through the first eight 64-k stages of the NEXT tile, one
-// 32-row x 128-byte group per stage, under that tile's MFMAs.  Output writes are thereby spread
-// evenly over the launch and overlap the matrix pipe chip-wide.
-//  * stage loads run two stages ahead across tile boundaries (issue-side tile state in SGPRs); after
-//    the last tile the descriptors have zero records, so the tail needs no branches.
-//  * the first MFMA of every accumulator block of a tile takes C = 0: no accumulator clearing.
-//  * the bias row of a tile is staged in LDS (one LDS-DMA instruction of wave 0 in the tile's first
-//    stage) and added in f32 before the bf16 rounding: EPI_BIAS results are bit-identical to the
-//    other configurations.
-//  * needs K >= 512 (eight stages to drip into) and the Q conditions; epilogues without an aux operand.
-struct NtqpOut {
-  __amdgpu_buffer_rsrc_t out0, out1;
-};
-// Every call issues the same number of store instructions whatever the lane predicate (rows /
-// columns outside the problem, or no pending tile, take the always-out-of-range offset): the
-// barrier waits of the main loop count them.
-template <int EPI>
-__device__ __forceinline__ void ntqp_finish8(const GemmNtArgs& p, const NtqpOut& o, int m, int n, const u32x4& pk) {
-  // pk = 8 consecutive columns n..n+7 of row m, bf16(acc + bias)
-  const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : MVPTR_OOB;
-  if (EPI == MVPTR_EPI_BIAS) {
-    __builtin_amdgcn_raw_buffer_store_b128(pk, o.out0, off, 0, 0);
-  } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-    u32x4 og, od;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float u0 = __builtin_bit_cast(float, pk[e] << 16);
-      const float u1 = __builtin_bit_cast(float, pk[e] & 0xffff0000u);
-      f32x2 a2, d2;
-      gelu_pair(f32x2{u0, u1}, a2, d2);
-      const bf16x2 ga = {f2bf(a2.x), f2bf(a2.y)};
-      const bf16x2 gd = {f2bf(d2.x), f2bf(d2.y)};
-      og[e] = __builtin_bit_cast(uint32_t, ga);
-      od[e] = __builtin_bit_cast(uint32_t, gd);
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(od, o.out0, off, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(og, o.out1, off, 0, 0);
-  }
-}
-template <int EPI>
-constexpr int ntqp_stores_per_unit() { return EPI == MVPTR_EPI_BIAS_GELU ? 2 : 1; }
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_ntqp_kernel(GemmNtArgs p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int OP_B = 256 * BK * 2;      // one operand tile of a stage (32 KiB)
-  constexpr int STAGE_B = 2 * OP_B;       // activations, then weights
-  constexpr int BIAS_OFF = 2 * STAGE_B;   // two 1-KiB bias rows (tile parity)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = gridDim.x;
-  const int nk = (p.K + BK - 1) / BK;
-  const uint32_t lds0 = lds_addr(lds);
-
-  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
-    const int base = round * grid;
-    const int left = ntiles - base;
-    if (left <= 0) return false;
-    const int nthis = min(left, grid);
-    if ((int)blockIdx.x >= nthis) return false;
-    const int t = base + xcd_remap(blockIdx.x, nthis);
-    const int gsz = GROUP_M * p.tiles_n;
-    const int grp = t / gsz;
-    const int first_m = grp * GROUP_M;
-    const int gm = min(GROUP_M, p.tiles_m - first_m);
-    const int in_g = t - grp * gsz;
-    m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
-    return true;
-  };
-
-  // ---- issue side: the tile whose stages are being loaded (two stages ahead of the MFMAs)
-  int is_round = 0, is_k = 0;
-  u32x4 rsA, rsB;
-  auto issue_tile = [&](int round) {
-    int m0 = 0, n0 = 0;
-    if (tile_origin(round, m0, n0)) {
-      const int rows_a = min(BM, p.M - m0), rows_b = min(BN, p.N - n0);
-      rsA = make_rsrc_words(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
-      rsB = make_rsrc_words(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
-    } else {
-      rsA = make_rsrc_words(p.A, 0u);  // zero records: every load returns zeros without touching memory
-      rsB = make_rsrc_words(p.B, 0u);
-    }
-  };
-  issue_tile(0);
-  const int srow = wave * 8 + (lane >> 3);
-  const int kc = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
-  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
-  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
-  const uint32_t rstepA = (uint32_t)(32 * p.lda * 2), rstepB = (uint32_t)(32 * p.ldb * 2);
-  auto stage_piece = [&](int buf, int i) {
-    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
-    const bool in_k = (is_k * BK + kc < p.K);
-    if (i < 8) {
-      const uint32_t va = in_k ? offA0 + (uint32_t)i * rstepA + (uint32_t)(is_k * BK * 2) : MVPTR_OOB;
-      lds_dma16(rsA, va, la + i * 4096);
-    } else {
-      const uint32_t vb = in_k ? offB0 + (uint32_t)(i - 8) * rstepB + (uint32_t)(is_k * BK * 2) : MVPTR_OOB;
-      lds_dma16(rsB, vb, la + OP_B + (i - 8) * 4096);
-    }
-  };
-  auto issue_advance = [&]() {
-    if (++is_k == nk) {
-      is_k = 0;
-      issue_tile(++is_round);
-    }
-  };
-
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r31 = lane & 31, h = lane >> 5;
-  uint32_t fx[4], fw[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    const uint32_t o = (uint32_t)(r31 * 128 + (((2 * s4 + h) ^ ((r31 >> 1) & 7)) << 4));
-    fx[s4] = (uint32_t)(wm * 128 * 128) + o;
-    fw[s4] = (uint32_t)(OP_B + wn * 128 * 128) + o;
-  }
-
-  f32x16 acc[4][4];    // [nb][mb]
-  uint32_t pend[4][4][8];  // [nb][mb][register pair]: bf16(acc + bias) of the previous tile
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pend[i][j][e] = 0u;
-  int pm0 = 0x40000000, pn0 = 0;  // origin of the pending tile (none yet: no row passes m < M)
-
-  bf16x8 wf0[4], xf0[4], wf1[4], xf1[4];
-  auto read_frag = [&](const char* base, int s4, int f, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
-    if (f < 4) xf[f] = *reinterpret_cast<const bf16x8*>(base + fx[s4] + f * 4096);
-    else wf[f - 4] = *reinterpret_cast<const bf16x8*>(base + fw[s4] + (f - 4) * 4096);
-  };
-  auto read_quarter = [&](const char* base, int s4, int j, bf16x8(&wf)[4], bf16x8(&xf)[4]) {
-    constexpr int first[5] = {0, 3, 6, 8, 8};
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (f >= first[j] && f < first[j + 1]) read_frag(base, s4, f, wf, xf);
-  };
-  auto mma_row = [&](int nb, const bf16x8(&wf)[4], const bf16x8(&xf)[4], auto first_tag) {
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      if constexpr (decltype(first_tag)::value) {
-        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], z, 0, 0, 0);
-      } else {
-        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb], xf[mb], acc[nb][mb], 0, 0, 0);
-      }
-    }
-  };
-  const u32x4 rsBias = make_rsrc_words(p.bias, p.bias != nullptr ? (uint32_t)p.N * 4u : 0u);
-  const uint32_t out_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);  // < 4 GiB (launch condition)
-  NtqpOut outs;
-  outs.out0 = make_rsrc_uniform(p.out0, out_bytes);
-  outs.out1 = make_rsrc_uniform(p.out1 != nullptr ? p.out1 : p.out0, p.out1 != nullptr ? out_bytes : 0u);
-  // one unit of the deferred epilogue: block (nb, mb), register groups 2*q2 / 2*q2+1 -> the lane's
-  // 8-column run at columns 32 nb + 16 q2 + 8 h of row 32 mb + r31
-  auto drip_unit = [&](int nb, int mb, int q2) {
-    u32x4 pk;
-    uint32_t lo0 = pend[nb][mb][4 * q2], lo1 = pend[nb][mb][4 * q2 + 1];
-    uint32_t hi0 = pend[nb][mb][4 * q2 + 2], hi1 = pend[nb][mb][4 * q2 + 3];
-    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo0), "+v"(hi0));
-    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo1), "+v"(hi1));
-    pk[0] = lo0;
-    pk[1] = lo1;
-    pk[2] = hi0;
-    pk[3] = hi1;
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int m = pm0 + wm * 128 + mb * 32 + (lane_e & 31);
-    const int n = pn0 + wn * 128 + nb * 32 + 16 * q2 + 8 * (lane_e >> 5);
-    ntqp_finish8<EPI>(p, outs, m, n, pk);
-  };
-  // group g (0..7) = rows 32 (g >> 1).., columns 64 (g & 1)..: four units = whole 128-byte lines
-  auto drip_group_unit = [&](int g, int u) { drip_unit(2 * (g & 1) + (u >> 1), g >> 1, u & 1); };
-
-
-  int round = 0, m0 = 0, n0 = 0;
-  tile_origin(0, m0, n0);  // grid <= ntiles: always valid
-  // prologue: two stages in flight, the first one landed
-#pragma unroll
-  for (int j = 0; j < 16; ++j) stage_piece(0, j);
-  issue_advance();
-#pragma unroll
-  for (int j = 0; j < 16; ++j) stage_piece(1, j);
-  issue_advance();
-  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-#pragma unroll
-  for (int j = 0; j < 4; ++j) read_quarter(lds, 0, j, wf0, xf0);
-  int bufsel = 0;
-
-  // G: drip group handled in this stage (-1: none); FIRST: the tile's first stage (C = 0 MFMAs and
-  // the bias-row load)
-  auto stage_body = [&](auto g_tag, auto first_tag, auto second_tag) {
-    constexpr int G = decltype(g_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;
-    (void)second_tag;
-    const char* cur = lds + bufsel * STAGE_B;
-    const char* nxt = lds + (bufsel ^ 1) * STAGE_B;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 1, j, wf1, xf1);
-      mma_row(j, wf0, xf0, first_tag);
-      if constexpr (G >= 0) {
-        if (j == 0) drip_group_unit(G, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 2, j, wf0, xf0);
-      mma_row(j, wf1, xf1, std::false_type{});
-      if constexpr (G >= 0) {
-        if (j == 0) drip_group_unit(G, 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      read_quarter(cur, 3, j, wf1, xf1);
-      mma_row(j, wf0, xf0, std::false_type{});
-      if constexpr (G >= 0) {
-        if (j == 0) drip_group_unit(G, 2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the stage are done
-    // the next stage's loads are older than this stage's deferred stores, which may stay in flight
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G >= 0 ? 3 * ntqp_stores_per_unit<EPI>() : 0) : "memory");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) stage_piece(bufsel, 4 * j + i);
-      read_quarter(nxt, 0, j, wf0, xf0);
-      mma_row(j, wf1, xf1, std::false_type{});
-      if constexpr (G >= 0) {
-        // the group's last unit goes out behind the stage's LDS-DMA issue: its stores are OLDER than
-        // nothing the next barrier waits for except themselves (counted there as in-flight-allowed)
-        if (j == 3) drip_group_unit(G, 3);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (FIRST) {
-      // the tile's bias row (256 floats) goes to LDS by one LDS-DMA instruction of wave 0; the next
-      // barrier's vmcnt(0) covers it, the conversion at the end of the tile reads it
-      if (wave == 0)
-        lds_dma16(rsBias, (uint32_t)((n0 + lane * 4) * 4), lds0 + (uint32_t)(BIAS_OFF + (round & 1) * 1024));
-    }
-    issue_advance();
-    bufsel ^= 1;
-  };
-
-  for (;;) {
-    stage_body(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
-    stage_body(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 3>{}, std::false_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 4>{}, std::false_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 5>{}, std::false_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 6>{}, std::false_type{}, std::false_type{});
-    stage_body(std::integral_constant<int, 7>{}, std::false_type{}, std::false_type{});
-    for (int kk = 8; kk < nk; ++kk)
-      stage_body(std::integral_constant<int, -1>{}, std::false_type{}, std::false_type{});
-    // tile end: accumulators + bias -> bf16 pending registers
-    // (speed ablations, wrong results: MVPTR_QP_EXP 1 no bias reads, 2 no accumulator reads, 3 no conversion)
-#if !defined(MVPTR_QP_EXP) || MVPTR_QP_EXP != 3
-    {
-      const char* brow = lds + BIAS_OFF + (round & 1) * 1024 + (wn * 128 + 4 * h) * 4;
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        f32x4 b[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#if defined(MVPTR_QP_EXP) && MVPTR_QP_EXP == 1
-          b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-          (void)brow;
-#else
-          b[g] = *reinterpret_cast<const f32x4*>(brow + (nb * 32 + 8 * g) * 4);
-#endif
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int r = 2 * e;
-#if defined(MVPTR_QP_EXP) && MVPTR_QP_EXP == 2
-            float a0 = __builtin_bit_cast(float, pend[nb][mb][e]), a1 = a0 * 0.5f;
-#else
-            const float a0 = acc[nb][mb][r], a1 = acc[nb][mb][r + 1];
-#endif
-            const bf16x2 t2 = {f2bf(a0 + b[r >> 2][r & 3]), f2bf(a1 + b[r >> 2][(r & 3) + 1])};
-            pend[nb][mb][e] = __builtin_bit_cast(uint32_t, t2);
-          }
-          // one block at a time: hipcc otherwise reads all 256 accumulators first and spills the
-          // loop's address registers to make room
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-#endif
-    pm0 = m0;
-    pn0 = n0;
-    ++round;
-    if (!tile_origin(round, m0, n0)) break;
-  }
-  // the last tile's epilogue
-#pragma unroll
-  for (int g = 0; g < 8; ++g)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) drip_group_unit(g, u);
-}
-
-template <int EPI>
-int launch_qp(GemmNtArgs a, hipStream_t s) {
-  constexpr int LDS_BYTES = 2 * 2 * 256 * 64 * 2 + 2048;  // 128 KiB ring + two bias rows
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 255) / 256;
-  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff ||
-      (int64_t)a.M * a.ldc * 2 >= (int64_t)0x7fffffff)
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntqp_kernel<EPI>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
-    num_cu = prop.multiProcessorCount;
-  }
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = ntiles < num_cu ? ntiles : num_cu;
-  hipLaunchKernelGGL((gemm_ntqp_kernel<EPI>), dim3(grid), dim3(256), LDS_BYTES, s, a);
-  MVPTR_CHECK_LAUNCH("gemm_nt");
-  return MVPTR_OK;
-}
-template <int EPI>
-constexpr bool qp_has_epilogue() { return EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU; }
-
-template <int EPI>
-int launch_q(GemmNtArgs a, hipStream_t s) {
-  constexpr int LDS_BYTES = 2 * 2 * 256 * 64 * 2;  // 128 KiB
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 255) / 256;
-  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff)
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntq_kernel<EPI>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((gemm_ntq_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), LDS_BYTES, s, a);
-  MVPTR_CHECK_LAUNCH("gemm_nt");
-  return MVPTR_OK;
-}
-// what the "Q" kernel's register epilogue needs: whole 8-column runs and 16-byte accesses
-inline bool q_eligible(const GemmNtArgs& a) {
-  if ((a.N & 7) || !a.vec_out_ok || a.vec_out != nullptr) return false;
-  if (a.aux != nullptr && !a.vec_aux_ok) return false;
-  if (a.bias != nullptr && !a.vec_bias_ok) return false;
-  return true;
-}
-
-// ---------------------------------------------------------------------------------------------
-// "pd": persistent kernel with a DEFERRED epilogue and TWO waves per SIMD.
-//
-// What bounds the K = 768 GEMMs: a CU can store ~24 GB/s, so the 128-256 KiB
-// of a tile's outputs take 5-11 us during which the default kernel runs no MFMA; a one-wave-per-SIMD
-// kernel ("qp") can overlap the stores but not the epilogue's VALU work with its own MFMAs.  Here the
-// default kernel's loop (8 waves as 2 x 4, 16x16x32 MFMA, BK 64 double buffer, builtin LDS-DMA) runs
-// persistently over 192 x 256 tiles: a wave owns 96 x 64 = 96 accumulator registers, which leaves room
-// for the previous tile's outputs as 48 "pending" registers (bf16 of acc + bias).  At the end of a
-// tile the next tile's first two K-steps are requested, the accumulators are packed into the pending
-// registers (~200 VALU per wave) and the K-loop of the next tile starts; its first six K-steps each
-// finish one 16-row block of the pending tile — unpack, restage through the wave's 4-KiB LDS area
-// into row-chunk form, bias/GELU/dropout/residual math, 16-byte full-line stores — between their
-// MFMAs, where the SIMD's other wave keeps the matrix pipe busy.
-//  * vmcnt completes in issue order: a block's aux rows are requested BEFORE the K-step's LDS-DMA
-//    issue (waiting for them then does not wait for the loads of the next K-step), its stores come
-//    after it and may stay in flight across the next barrier (counted wait: every wave issues the
-//    same number of store instructions per block, masked lanes take an out-of-range buffer offset).
-//  * EPI_BIAS output is bit-identical to the default kernel (bias added in f32 before the rounding);
-//    epilogues with an aux operand or GELU see one extra bf16 rounding of acc + bias.
-//  * needs K >= 384 (six K-steps to drip into), N % 8 == 0 and 16-byte aligned operands.
-template <int EPI>
-__device__ __forceinline__ void nt_epilogue_aux(const GemmNtArgs& p, int mrow0, int ncol0, int lane, bf16x8 (&auxv)[2]) {
-  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
-  if (!kNeedsAux) return;
-  const int n = ncol0 + (lane & 7) * 8, rsub = lane >> 3;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int mj = mrow0 + it * 8 + rsub;
-    bf16x8 x;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
-    if (p.aux != nullptr && mj < p.M && n < p.N) x = *reinterpret_cast<const bf16x8*>(p.aux + (int64_t)mj * p.ld_aux + n);
-    auxv[it] = x;
-  }
-}
-template <int EPI>
-__device__ __forceinline__ void nt_epilogue_block(const GemmNtArgs& p, const NtqpOut& outs, const f32x4 (&blk)[4], float* st,
-                                                  int mrow0, int ncol0, int lane, float (&cs)[8], const bf16x8 (&auxv)[2]) {
-  // blk[nt] = 4 consecutive columns (16 nt + 4 (lane >> 4) ..) of row lane & 15 of a 16 x 64 block
-  // whose bias has been added already; finished in row-chunk form (lane: row it*8 + lane>>3, 8 columns)
-  const int c16 = lane & 15, q4 = lane >> 4;
-  const int ch = lane & 7, rsub = lane >> 3;
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-    *reinterpret_cast<f32x4*>(st + c16 * 64 + (((nt * 4 + q4) ^ c16) << 2)) = blk[nt];
-  const int n = ncol0 + ch * 8;
-  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int lrow = it * 8 + rsub;
-    const int m = mrow0 + lrow;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch) ^ lrow) << 2));
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + lrow * 64 + (((2 * ch + 1) ^ lrow) << 2));
-    // every lane runs the math and every wave issues the same number of store instructions (masked
-    // lanes take the always-out-of-range offset): the K-loop's counted vmcnt relies on it
-    const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : MVPTR_OOB;
-    float v[8], a[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = v0[e];
-      v[4 + e] = v1[e];
-    }
-    if (kNeedsAux) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it][e]);
-    }
-    auto store_bf8 = [&](const __amdgpu_buffer_rsrc_t& rs, const float (&o)[8]) {
-      bf16x8 t;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t[e] = f2bf(o[e]);
-      // MVPTR_NT_EXP bit 9: sc1 (write-through, line not kept in the XCD's L2) instead of a plain store
-      if (p.exp_flags & 512) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, off, 0, 16);
-      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rs, off, 0, 0);
-    };
-    if (EPI == MVPTR_EPI_BIAS) {
-      store_bf8(outs.out0, v);
-    } else if (EPI == MVPTR_EPI_BIAS_GELU) {
-      float g[8], dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        f32x2 a2, d2;
-        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-        g[e] = a2.x;
-        g[e + 1] = a2.y;
-        dg[e] = d2.x;
-        dg[e + 1] = d2.y;
-      }
-      store_bf8(outs.out0, dg);
-      store_bf8(outs.out1, g);
-    } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-#pragma unroll
-      for (int e = 0; e < 8; e += 2)
-        drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += a[e];
-      store_bf8(outs.out0, v);
-    } else if (EPI == MVPTR_EPI_GELU_BWD) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] *= a[e];
-        if (off != MVPTR_OOB) cs[e] += v[e];
-      }
-      store_bf8(outs.out0, v);
-    } else if (EPI == MVPTR_EPI_ADD) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += a[e];
-      store_bf8(outs.out0, v);
-    } else if (EPI == MVPTR_EPI_BIAS_TANH) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-      store_bf8(outs.out0, v);
-    }
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pd_kernel(GemmNtArgs p) {
-  constexpr int BM = 192, BN = 256, BK = 64, WN = 4, MT = 6, WROWS = 96, NWAVES = 8;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int ROW_B = 128, NA = 3, NB = 4, KS = 2;
-  constexpr int STORES_PER_BLOCK = (EPI == MVPTR_EPI_BIAS_GELU) ? 4 : 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = gridDim.x;
-  const int srow = wave * 8 + (lane >> 3);
-  const int kc = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) * 8;
-  const uint32_t offA0 = (uint32_t)(srow * p.lda * 2 + kc * 2);
-  const uint32_t offB0 = (uint32_t)(srow * p.ldb * 2 + kc * 2);
-  const uint32_t stepA = 64u * (uint32_t)p.lda * 2u, stepB = 64u * (uint32_t)p.ldb * 2u;
-  const int wm = wave / WN, wn = wave % WN;
-  const int c16 = lane & 15, q4 = lane >> 4;
-  uint32_t fx0[KS], fw0[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int sw = (c16 >> 1) & 7;   // (row >> 1) & 7 of every fragment row this lane reads
-    fx0[ks] = (uint32_t)((wm * WROWS + c16) * ROW_B + (((ks * 4 + q4) ^ sw) << 4));
-    fw0[ks] = (uint32_t)((wn * 64 + c16) * ROW_B + (((ks * 4 + q4) ^ sw) << 4));
-  }
-  float* st = reinterpret_cast<float*>(lds + 2 * STAGE_BYTES) + wave * (16 * 64);
-  const int nk = (p.K + BK - 1) / BK;
-
-  auto tile_origin = [&](int round, int& m0, int& n0) -> bool {
-    const int base = round * grid;
-    const int left = ntiles - base;
-    if (left <= 0) return false;
-    const int nthis = min(left, grid);
-    if ((int)blockIdx.x >= nthis) return false;
-    const int t = base + xcd_remap(blockIdx.x, nthis);
-    const int gsz = GROUP_M * p.tiles_n;
-    const int grp = t / gsz;
-    const int first_m = grp * GROUP_M;
-    const int gm = min(GROUP_M, p.tiles_m - first_m);
-    const int in_g = t - grp * gsz;
-    m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
-    return true;
-  };
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int buf, int k0) {
-    char* la = lds + buf * STAGE_BYTES;
-    char* lb = la + A_BYTES;
-    const bool in_k = (k0 + kc < p.K);
-    uint32_t oa = offA0, ob = offB0;
-    asm volatile("" : "+v"(oa), "+v"(ob));
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const uint32_t va = in_k ? oa + (uint32_t)i * stepA + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const uint32_t vb = in_k ? ob + (uint32_t)i * stepB + (uint32_t)k0 * 2 : MVPTR_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
-    }
-  };
-  auto rsrc_a = [&](int m0) {
-    const int rows_a = min(BM, p.M - m0);
-    return make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
-  };
-  auto rsrc_b = [&](int n0) {
-    const int rows_b = min(BN, p.N - n0);
-    return make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
-  };
-
-  int m0 = 0, n0 = 0;
-  if (!tile_origin(0, m0, n0)) return;
-  __amdgpu_buffer_rsrc_t rsA = rsrc_a(m0), rsB = rsrc_b(n0);
-  f32x4 acc[4][MT];
-  uint32_t pend[MT][4][2];   // previous tile: bf16(acc + bias), [16-row block][16-column block][pair]
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pend[i][j][0] = pend[i][j][1] = 0u;
-  int pm0 = 0x40000000, pn0 = 0;  // origin of the pending tile (none yet: every row fails m < M)
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const uint32_t out_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);  // < 4 GiB (launch condition)
-  NtqpOut outs;
-  outs.out0 = make_rsrc_uniform(p.out0, out_bytes);
-  outs.out1 = make_rsrc_uniform(p.out1 != nullptr ? p.out1 : p.out0, p.out1 != nullptr ? out_bytes : 0u);
-
-  // finish 16-row block `mt` of the pending tile: drip_load (aux rows) ahead of the K-step's LDS-DMA
-  // issue, drip (math + stores) between its MFMAs
-  bf16x8 auxv[2];
-  auto drip_load = [&](int mt) {
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    nt_epilogue_aux<EPI>(p, pm0 + wm * WROWS + mt * 16, pn0 + wn * 64, lane_e, auxv);
-  };
-  auto drip = [&](int mt) {
-    if (p.exp_flags & 128) {   // ablation (MVPTR_NT_EXP bit 7): no deferred epilogue work; keeps the store count
-      const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int i = 0; i < STORES_PER_BLOCK; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, outs.out0, MVPTR_OOB, 0, 0);
-      return;
-    }
-    f32x4 blk[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      blk[nt][0] = __builtin_bit_cast(float, pend[mt][nt][0] << 16);
-      blk[nt][1] = __builtin_bit_cast(float, pend[mt][nt][0] & 0xffff0000u);
-      blk[nt][2] = __builtin_bit_cast(float, pend[mt][nt][1] << 16);
-      blk[nt][3] = __builtin_bit_cast(float, pend[mt][nt][1] & 0xffff0000u);
-    }
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));   // epilogue constants re-derived here, not kept across the MFMA loop
-    nt_epilogue_block<EPI>(p, outs, blk, st, pm0 + wm * WROWS + mt * 16, pn0 + wn * 64, lane_e, cs, auxv);
-    if (EPI == MVPTR_EPI_GELU_BWD && mt == MT - 1 && p.vec_out != nullptr) {
-      const int ch = lane_e & 7, rsub = lane_e >> 3;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float sum = cs[e];
-        sum += __shfl_xor(sum, 8);
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const int n = pn0 + wn * 64 + ch * 8 + e;
-        if (rsub == 0 && n < p.N && pm0 < p.M) atomicAdd(p.vec_out + n, sum);
-        cs[e] = 0.f;
-      }
-    }
-  };
-
-  bool prefetched = false;
-  for (int round = 0;; ++round) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!prefetched) stage(rsA, rsB, 0, 0);
-    // DRIP: pending block finished in this K-step (-1: none; -2: none, but the previous K-step's block
-    // stores may still be in flight)
-    auto kstep = [&](int kt, auto drip_tag) {
-      constexpr int DRIP = decltype(drip_tag)::value;
-      // K-step kt has landed once only the deferred stores issued AFTER its loads (the previous
-      // K-step's block: a fixed number of store instructions per wave) remain outstanding; after the
-      // block that ends with the column-sum atomics everything is waited for
-      constexpr bool kCounted = (DRIP >= 1 || DRIP == -2) && !(EPI == MVPTR_EPI_GELU_BWD && (DRIP == -2));
-      if constexpr (kCounted) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(STORES_PER_BLOCK) : "memory");
-      } else if constexpr (DRIP == 0) {
-        // first K-step of a tile: when the previous tile's end requested K-steps 0 AND 1, only K-step 0
-        // has to have landed (the LDS-DMA instructions of K-step 1 may stay in flight)
-        if (prefetched) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NA + NB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      }
-      if constexpr (DRIP >= 0) drip_load(DRIP);
-      const int buf = kt & 1;
-      const char* la = lds + buf * STAGE_BYTES;
-      const char* lb = la + A_BYTES;
-      bf16x8 xf[MT], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[0] + i * 16 * ROW_B);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[0] + i * 16 * ROW_B);
-      if (kt + 1 < nk && !(prefetched && kt == 0)) stage(rsA, rsB, buf ^ 1, (kt + 1) * BK);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks > 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw0[ks] + i * 16 * ROW_B);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx0[ks] + i * 16 * ROW_B);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if constexpr (DRIP >= 0) {
-          if (ks == 0) drip(DRIP);
-        }
-      }
-    };
-    kstep(0, std::integral_constant<int, 0>{});
-    kstep(1, std::integral_constant<int, 1>{});
-    kstep(2, std::integral_constant<int, 2>{});
-    kstep(3, std::integral_constant<int, 3>{});
-    kstep(4, std::integral_constant<int, 4>{});
-    kstep(5, std::integral_constant<int, 5>{});
-    if (nk > 6) kstep(6, std::integral_constant<int, -2>{});
-    for (int kt = 7; kt < nk; ++kt) kstep(kt, std::integral_constant<int, -1>{});
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the operand ring
-    int m1 = 0, n1 = 0;
-    const bool more = tile_origin(round + 1, m1, n1);
-    __amdgpu_buffer_rsrc_t rsA1 = rsA, rsB1 = rsB;
-    // the tile's bias quads first (their wait must not include the next tile's loads), then the next
-    // tile's first two K-steps, then accumulators (+ bias in f32) -> bf16 pending registers
-    f32x4 b4[4];
-    {
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
-      const int nb0 = n0 + wn * 64 + (lane_e >> 4) * 4;
-      constexpr bool kBias = (EPI != MVPTR_EPI_GELU_BWD && EPI != MVPTR_EPI_ADD);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        b4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n = nb0 + nt * 16;
-        if (kBias && p.bias != nullptr && n < p.N) b4[nt] = *reinterpret_cast<const f32x4*>(p.bias + n);  // N % 8 == 0: whole quads
-      }
-      asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));   // landed before the loads below are issued
-    }
-    if (more) {
-      rsA1 = rsrc_a(m1);
-      rsB1 = rsrc_b(n1);
-      stage(rsA1, rsB1, 0, 0);
-      stage(rsA1, rsB1, 1, BK);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x2 lo = {f2bf(acc[nt][mt][0] + b4[nt][0]), f2bf(acc[nt][mt][1] + b4[nt][1])};
-        const bf16x2 hi = {f2bf(acc[nt][mt][2] + b4[nt][2]), f2bf(acc[nt][mt][3] + b4[nt][3])};
-        pend[mt][nt][0] = __builtin_bit_cast(uint32_t, lo);
-        pend[mt][nt][1] = __builtin_bit_cast(uint32_t, hi);
-      }
-    pm0 = m0;
-    pn0 = n0;
-    if (!more) break;
-    m0 = m1;
-    n0 = n1;
-    rsA = rsA1;
-    rsB = rsB1;
-    prefetched = true;
-  }
-  // the last tile's epilogue
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    drip_load(mt);
-    drip(mt);
-  }
-}
-
-template <int EPI>
-int launch_pd(GemmNtArgs a, hipStream_t s) {
-  constexpr int LDS_BYTES = 2 * (192 + 256) * 64 * 2 + 8 * 16 * 64 * 4;  // 112 KiB ring + 32 KiB staging
-  a.tiles_m = (a.M + 191) / 192;
-  a.tiles_n = (a.N + 255) / 256;
-  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff ||
-      (int64_t)a.M * a.ldc * 2 >= (int64_t)0x7fffffff)
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pd_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
-    num_cu = prop.multiProcessorCount;
-  }
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = ntiles < num_cu ? ntiles : num_cu;
-  hipLaunchKernelGGL((gemm_nt_pd_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
-  MVPTR_CHECK_LAUNCH("gemm_nt");
-  return MVPTR_OK;
-}
-template <int EPI>
-constexpr bool pd_has_epilogue() {
-  return EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD ||
-         EPI == MVPTR_EPI_ADD || EPI == MVPTR_EPI_BIAS_TANH;
-}
-// whole 8-column runs, 16-byte accesses, six K-steps to drip into
-inline bool pd_eligible(const GemmNtArgs& a) {
-  if ((a.N & 7) || !a.vec_out_ok || a.K < 384) return false;
-  if (a.aux != nullptr && !a.vec_aux_ok) return false;
-  if (a.bias != nullptr && !a.vec_bias_ok) return false;
-  return true;
-}
-
-template <int EPI>
-int launch_persist(GemmNtArgs a, hipStream_t s) {
-  using C = Cfg<64, 2, 2, 4, 8>;
-  constexpr int LDS_BYTES = C::LDS_BYTES + 8 * 16 * 64 * 4;  // ring + 32 KiB staging = 160 KiB
-  a.tiles_m = (a.M + C::BM - 1) / C::BM;
-  a.tiles_n = (a.N + C::BN - 1) / C::BN;
-  if ((int64_t)C::BM * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)C::BN * a.ldb * 2 >= (int64_t)0x7fffffff)
-    MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: leading dimension too large");
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<EPI>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: no HIP device");
-    num_cu = prop.multiProcessorCount;
-  }
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int grid = ntiles < num_cu ? ntiles : num_cu;
-  hipLaunchKernelGGL((gemm_nt_persist_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
-  MVPTR_CHECK_LAUNCH("gemm_nt");
-  return MVPTR_OK;
 }
 
 template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
@@ -1846,55 +572,30 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
 
 template <int EPI>
 int launch(const GemmNtArgs& a, hipStream_t s) {
-  // Tile configurations (measured on MI355X, round 1, profiles/r01_gemm_configs.txt):
-  //   "t256k" 256x256, BK 64 (whole 128-B lines per row), double buffer, 8 waves of 128x64, one
-  //           workgroup per CU: fewest L2->LDS bytes per FLOP (32 B/clk/CU at full MFMA rate, the
-  //           measured L2->LDS fill rate is ~30-35), loop rate 1.2-1.4 PF/s
-  //   "w4"    256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU: the second
-  //           workgroup's loop runs beside the first one's epilogue, lower loop rate (1.0-1.15 PF/s)
-  //   "t256" (BK 32 ring) / "t256g" (ring + the two wave halves staggered by one MFMA burst) /
-  //           "w4g": tuning knobs, within 5 % of the two above
-  // Rule (sweeps of tools/sweep_gemm_cfg.py at the step's shapes): "t256k" everywhere except the
-  // short-K, narrow GEMMs whose 256x256 tiles would need more than one round of the 256 CUs
-  // (attention-output projection on the big batch), where the epilogue overlap of "w4" wins.
-  // MVPTR_GEMM_CFG overrides the choice.
+  // Tile configurations (measured on MI355X, profiles/r01_gemm_configs.txt, profiles/r02_experiments.txt,
+  // profiles/r03_experiments.txt):
+  //   256x256, BK 64 (whole 128-B lines per row), double buffer, 8 waves of 128x64, one workgroup per CU: fewest
+  //           L2->LDS bytes per FLOP, loop rate 1.2-1.4 PF/s — the default;
+  //   256x128, BK 32, 3-stage ring, 8 waves of 64x64, two workgroups per CU: the second workgroup's loop runs
+  //           beside the first one's epilogue, lower loop rate (1.0-1.15 PF/s) — short-K narrow GEMMs whose 256x256
+  //           tiles would need more than one round of the 256 CUs (attention-output projection on the big batch);
+  //   128x128, BK 32, 4 waves, up to three workgroups per CU — few-row GEMMs (head transforms on the masked rows).
+  // Measured and dropped (kernels removed, numbers in the experiment logs): BK 32 rings of 3 / 4 / 5 stages for the
+  // 256x256 tile, staggered wave halves, persistent workgroups with next-tile prefetch or deferred epilogues,
+  // one-wave-per-SIMD 128x128 wave tiles with a register epilogue.
+#ifdef MVPTR_DIAG_BUILD
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
-    const size_t n = strlen(env);
-    if (env[0] == 'p' && env[1] == 'd') {
-      if constexpr (pd_has_epilogue<EPI>()) {
-        if (!pd_eligible(a)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=pd needs N %% 8 == 0, K >= 384, 16-byte aligned operands");
-        return launch_pd<EPI>(a, s);
-      } else {
-        MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=pd: epilogue not supported");
-      }
-    }
-    if (env[0] == 'q' && env[1] == 'p') {
-      if constexpr (qp_has_epilogue<EPI>()) {
-        if (!q_eligible(a) || a.K < 512) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=qp needs the Q conditions and K >= 512");
-        return launch_qp<EPI>(a, s);
-      } else {
-        MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=qp: epilogue not supported");
-      }
-    }
-    if (env[0] == 'q') {
-      if (!q_eligible(a)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=q needs N %% 8 == 0, 16-byte aligned operands, no vec_out");
-      return launch_q<EPI>(a, s);
-    }
-    if (env[0] == 'p') return launch_persist<EPI>(a, s);  // "p256": persistent 256x256 / BK 64
-    if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128": 128x128, 4 waves
-    if (env[0] == 'h') return launch_bk<EPI, 32, 3, 2, 2, 8, 0>(a, s);  // "h4": 256x128, 4 waves of 128x64, 2 WG/CU
-    if (env[0] == 't' && env[n - 1] == 'k') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
-    if (env[0] == 't' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 2, 4, 8, 2>(a, s);
-    if (env[0] == 't') return launch_bk<EPI, 32, 3, 2, 4, 8, 0>(a, s);
-    if (env[0] == 'w' && env[n - 1] == 'g') return launch_bk<EPI, 32, 3, 4, 2, 4, 2>(a, s);
-    if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
+    if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128"
+    if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);  // "w4"
+    if (env[0] == 't') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);  // "t256k"
     MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
   }
+#endif
   const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
   // few-row GEMMs (head transforms on the masked rows: M ~ 3 k, N = 768) would give a 256x256 tile to
-  // a quarter of the CUs or fewer: 128x128 tiles, 4 waves, up to three workgroups per CU ("s128":
-  // 35 vs 74 us at M = 3000, N = 768, K = 3072; at M = 11 k the big tile still wins, 74 vs 87 us)
+  // a quarter of the CUs or fewer: 128x128 tiles, 4 waves, up to three workgroups per CU
+  // (35 vs 74 us at M = 3000, N = 768, K = 3072; at M = 11 k the big tile still wins, 74 vs 87 us)
   if (tiles256 <= 64 && a.M > 128) return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);
   if (a.N <= 768 && a.K <= 768 && tiles256 > 256) return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
   return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
@@ -1948,8 +649,6 @@ int decoder_args(GemmNtArgs& a, const void* h, int64_t ldh, const void* W, int64
   a.drop = make_dropdev(nullptr);
   a.labels = labels;
   a.vec_bias_ok = (bias && (((uintptr_t)bias & 15) == 0)) ? 1 : 0;
-  a.delay_lo = 256;
-  a.delay_hi = 512;
   return MVPTR_OK;
 }
 }  // namespace
@@ -2026,12 +725,8 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.vec_out = vec_out;
   a.drop = make_dropdev(drop);
   a.stamps = nullptr;
-  a.delay_cycles = 0;
   const MvptrKnobs& kn = mvptr_knobs();
-  a.exp_flags = kn.nt_exp;
-  a.delay_cycles = kn.delay[0];
-  a.delay_lo = kn.delay[1];
-  a.delay_hi = kn.delay[2];
+  a.stash_nt = (kn.nt_exp & 512) ? 1 : 0;
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
   a.stamps = (unsigned long long*)kn.stamps;
 #endif

@@ -12,8 +12,6 @@
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
 #include <stdlib.h>
-#include <map>
-#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -44,9 +42,6 @@ struct GemmTnGroup {
   GemmTnArgs prob[MVPTR_TN_MAX_GROUP];
   int base[MVPTR_TN_MAX_GROUP + 1];
   int count;
-  // "Q" kernel only: per-workgroup 256x256 f32 slabs (workgroup g writes slab g, 256 KiB, in register
-  // order) that tn_reduce_kernel sums over the M-splits; nullptr = f32 atomics straight into dW
-  float* slab;
   int splits;
 };
 
@@ -314,7 +309,7 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 // certifies stage st+1 sits between the two 16-row halves of stage st, and what follows it (issue of
 // stage st+STAGES into the buffer just freed, fragment reads of the next stage's first half) runs
 // under the 16 MFMAs of the second half, whose fragments are already in registers.
-template <int STAGES, bool SLAB>
+template <int STAGES>
 __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   constexpr int TM_ = 32;
   constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
@@ -533,31 +528,6 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, hh = lane_e >> 5;
-  if constexpr (SLAB) {
-    // slab mode: the partial tile goes out as plain 16-byte stores, 1 KiB contiguous per wave
-    // instruction (float index ((((wave*4 + nb)*4 + kb)*4 + i)*64 + lane)*4 + j holds accumulator
-    // register r = 4 i + j).  Plain stores run at the chip's write rate (~6.5 TB/s measured) where
-    // f32 atomics reach ~1.3 TB/s, and the sum over the splits is taken in a fixed order.
-    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 16384 + lane_e * 4;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 v = {acc[nb][kb][4 * i], acc[nb][kb][4 * i + 1], acc[nb][kb][4 * i + 2], acc[nb][kb][4 * i + 3]};
-          *reinterpret_cast<f32x4*>(sl + ((nb * 4 + kb) * 4 + i) * 256) = v;
-        }
-    if (do_bias) {
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) {
-        const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
-        const int n = n0 + wn * 128 + nb * 32 + l31;
-        if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
-      }
-    }
-    return;
-  }
   const int nw = n0 + wn * 128 + 4 * hh, kw = k0 + wk * 128 + l31;
   const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
   float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
@@ -593,307 +563,6 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
 }
 
 
-// "O" configuration (MVPTR_GEMM_TN=o): the "Q" tile (256 x 256 per workgroup, 32 token rows
-// per stage, STAGES-deep LDS-DMA ring) with EIGHT waves (two per SIMD) as 2(n) x 4(k), each 128 x 64 =
-// 8 x 4 blocks of v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  In-loop stamps of the
-// four-wave layouts (tools/clock_tn.py) read ~1 670 cycles per stage against the 1 024 the MFMAs
-// need: a lone wave per SIMD pays for each of its eight LDS-DMA issues (~80 cycles) with an idle
-// matrix pipe; with a partner wave on the SIMD the other's MFMAs run meanwhile (1 528 cycles here).
-// The chip gives most of that back as clock (1.99 -> 1.86 GHz in the loop, DVFS give-back item 3 of
-// MI355X_MICROARCH.md): "Q", a 16x16x32 four-wave build and this one land within 2-5 % of each
-// other in wall time — the loop is bounded by the power the MFMAs + operand traffic draw, not by
-// its issue schedule.  Fragment reads: one set of eight A fragments refreshed in place behind its
-// row, B fragments 0-1 double-buffered, 2-3 refreshed after the last row.
-template <int STAGES, bool SLAB>
-__global__ __launch_bounds__(512, 1) void gemm_tn_o_kernel(GemmTnGroup grp) {
-  constexpr int TM_ = 32;
-  constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
-  constexpr int STAGE_B = 4 * SUB_B;   // A: 2 sub-tiles (256 n), B: 2 sub-tiles (256 k)
-  constexpr int LPS = 4;               // LDS-DMA pieces per wave and stage: 2 for A, 2 for B
-  constexpr int TKW = 256;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gidx = xcd_remap(blockIdx.x, gridDim.x);
-  GemmTnArgs p = grp.prob[0];
-  int pbase = 0;
-#pragma unroll
-  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
-    if (i < grp.count && gidx >= grp.base[i]) {
-      p = grp.prob[i];
-      pbase = grp.base[i];
-    }
-  const int nt = p.tiles_n * p.tiles_k;
-  const int idx = gidx - pbase;
-  const int split = idx / nt;
-  const int t = idx - split * nt;
-  int tn, tk;
-  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
-    tk = t / p.tiles_n;
-    tn = t - tk * p.tiles_n;
-  } else {
-    tn = t / p.tiles_k;
-    tk = t - tn * p.tiles_k;
-  }
-  const int n0 = tn * TN_, k0 = tk * TKW;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
-  const int rows = m_end - m_begin;
-  if (rows <= 0) return;
-  const int ncols = min(TN_, p.N - n0);
-  const int kcols = min(TKW, p.K - k0);
-  const int ncols8 = (int)min((int64_t)((ncols + 7) & ~7), p.lda - n0);
-  const int kcols8 = (int)min((int64_t)((kcols + 7) & ~7), p.ldb - k0);
-  const u32x4 rsA = make_rsrc_words(
-      p.A + (int64_t)m_begin * p.lda + n0, (uint32_t)(((int64_t)(rows - 1) * p.lda + ncols8) * 2));
-  const u32x4 rsB = make_rsrc_words(
-      p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
-  const uint32_t lds0 = lds_addr(lds);
-
-  // staging: wave w fills the 4-row group w of each of the four 32 x 128 sub-tiles (A0 A1 B0 B1)
-  uint32_t offA[2], offB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 4 + (lane >> 4);
-    const int ch = (lane & 15) ^ swz256(row);
-    const int col = i * 128 + ch * 8;
-    offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
-    offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
-  }
-  const uint32_t stepA = (uint32_t)(TM_ * p.lda * 2), stepB = (uint32_t)(TM_ * p.ldb * 2);
-  auto stage_piece = [&](int buf, int st, int i) {   // i: 0,1 = A sub-tiles, 2,3 = B sub-tiles
-#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 4
-    return;
-#endif
-    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + i * SUB_B + wave * 1024);
-    // a lane whose column lies outside the tile holds MVPTR_OOB (2^31): adding a stage offset (the
-    // split's byte span is below 2^31) keeps it past the descriptor's range, no select needed
-    if (i < 2) lds_dma16(rsA, offA[i] + (uint32_t)st * stepA, la);
-    else lds_dma16(rsB, offB[i - 2] + (uint32_t)st * stepB, la);
-  };
-
-  const int wn = wave >> 2, wk = wave & 3;
-  const int g = lane >> 4, i16 = lane & 15;
-  const int q = i16 >> 2, pp = i16 & 3;
-  // offsets of the low read (rows 8g + q) of block 0; block b XORs b into chunk bits 1-3, and the high
-  // read (rows 8g + 4 + q: 1 KiB further, swizzle bit 0 set) is (low ^ 16) + 1024: every fragment
-  // address is one v_xad_u32 from these two registers
-  uint32_t ta0, tb0;
-  {
-    const int row = 8 * g + q;
-    const int sw = swz256(row);
-    ta0 = (uint32_t)wn * SUB_B + row * 256 + (((pp >> 1) ^ sw) << 4) + 8 * (pp & 1);
-    tb0 = (uint32_t)(2 + (wk >> 1)) * SUB_B + row * 256 + ((((wk & 1) * 8 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1);
-  }
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
-  float bsum[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
-
-  // one A fragment set, refreshed in place (fragment j of the next stage is requested right after
-  // row j, its only user, has been issued).  Every row uses all four B fragments: 0-1 have two sets
-  // (the next stage's arrive during rows 0-1), 2-3 are refreshed in place after the last row — the
-  // next stage's first row starts on 0-1 while they land.
-  bf16x8 fa[8], fbl0[2], fbl1[2], fbh[2];
-  auto frag = [&](const char* base, uint32_t t0, int b) {
-    return tr_frag(base, t0 ^ (uint32_t)(b << 5), (t0 ^ (uint32_t)((b << 5) | 16)) + 1024u);
-  };
-  auto mma_row = [&](int nb, const bf16x8(&fbl)[2], auto bias_tag) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const bf16x8& b = (kb < 2) ? fbl[kb] : fbh[kb - 2];
-#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 2
-      asm volatile("" ::"v"(fa[nb]), "v"(b));
-#else
-      acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[nb], b, acc[nb][kb], 0, 0, 0);
-#endif
-    }
-    if constexpr (decltype(bias_tag)::value) {
-      const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
-        bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
-      }
-    }
-  };
-
-  // Uniform pipeline: every stage is issued, landed-checked and read the same way whether it exists
-  // or not.  A stage past the split's rows lies beyond the descriptors' ranges, so its LDS-DMA
-  // pieces fill the buffer with zeros without touching memory: the vmcnt counts are compile-time
-  // constants, the loop body has no run-time branch (one inside the MFMA sequence makes hipcc
-  // spill), and an odd stage count is padded with one all-zero stage.  At a stage's start: this
-  // wave's fragments have landed (lgkmcnt(0)), stage st+1 has landed (counted vmcnt), barrier ->
-  // every wave is done with the stage's buffer, which is refilled with stage st+STAGES.
-  const int nsteps = (rows + TM_ - 1) / TM_;
-#pragma unroll
-  for (int i = 0; i < STAGES; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stage_piece(i, i, j);
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * LPS) : "memory");
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    fbl0[j] = frag(lds, tb0, j);
-    fbh[j] = frag(lds, tb0, 2 + j);
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) fa[j] = frag(lds, ta0, j);
-#ifdef MVPTR_TIMELINE_BUILD
-  const unsigned long long tl_c0 = __builtin_amdgcn_s_memtime(), tl_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  auto main_loop = [&](auto bias_tag) {
-    int buf = 0;
-    auto step = [&](int st, const bf16x8(&fbl)[2], bf16x8(&nbl)[2]) {
-      const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-#if defined(MVPTR_TN_EXP) && MVPTR_TN_EXP == 6
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPS) : "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
-#endif
-      const char* nxt = lds + nbuf * STAGE_B;
-      // opaque per stage: hipcc would otherwise hoist the 24 per-fragment offsets (base ^ block) out of
-      // the loop and spill them; computed in place each is one v_xad_u32 beside the MFMAs
-      asm volatile("" : "+v"(ta0), "+v"(tb0));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if ((j & 1) == 0) stage_piece(buf, st + STAGES, j >> 1);
-        if (j < 2) nbl[j] = frag(nxt, tb0, j);
-        mma_row(j, fbl, bias_tag);
-        fa[j] = frag(nxt, ta0, j);
-        if (j == 7) {
-          fbh[0] = frag(nxt, tb0, 2);
-          fbh[1] = frag(nxt, tb0, 3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      buf = nbuf;
-    };
-    for (int st = 0; st < nsteps; st += 2) {
-      step(st, fbl0, fbl1);
-      step(st + 1, fbl1, fbl0);
-    }
-  };
-  if (do_bias) main_loop(std::true_type{});
-  else main_loop(std::false_type{});
-#ifdef MVPTR_TIMELINE_BUILD
-  {
-    const unsigned long long tl_c1 = __builtin_amdgcn_s_memtime(), tl_r1 = __builtin_amdgcn_s_memrealtime();
-    if (p.stamps != nullptr && tid == 0) {
-      unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
-      o[0] = tl_r0;
-      o[1] = tl_r1;
-      o[2] = tl_c0;
-      o[3] = tl_c1;
-      o[4] = (unsigned long long)nsteps;
-    }
-  }
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  // write-out.  Block (nb, kb), register r of lane (g, i16): dW[n0 + wn*128 + nb*16 + 4g + r][k0 + wk*64 + kb*16 + i16]
-  int lane_e = lane;
-  asm volatile("" : "+v"(lane_e));
-  const int ge = lane_e >> 4, ie = lane_e & 15;
-  if (do_bias) {
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      float tot = bsum[nb] + __shfl_xor(bsum[nb], 16);
-      tot += __shfl_xor(tot, 32);
-      const int n = n0 + wn * 128 + nb * 16 + ie;
-      if (ge == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
-    }
-  }
-  if constexpr (SLAB) {
-    // float index (((wave*8 + nb)*4 + kb)*64 + lane)*4 + r
-    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 8192 + lane_e * 4;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(sl + (nb * 4 + kb) * 256) = acc[nb][kb];
-  } else {
-    const int nw = n0 + wn * 128 + 4 * ge, kw = k0 + wk * 64 + ie;
-    float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = nb * 16 + r;
-        float* rowp = wbase + (int64_t)nn * p.ldw;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-          if (nw + nn < p.N && kw + kb * 16 < p.K) atomicAdd(rowp + kb * 16, acc[nb][kb][r]);
-      }
-  }
-}
-
-// Sum of the M-splits' slabs of gemm_tn_q_kernel / gemm_tn_o_kernel into dW (+=), splits in ascending order: the
-// result does not depend on the order in which workgroups finished (bitwise reproducible, unlike
-// the atomic write-out).  One thread per 16-byte slab position = four rows n..n+3 of one column k;
-// a wave reads 1 KiB contiguous per split and updates 2 x 128-byte row segments per row.
-template <int LAYOUT>   // 0: "Q", 2: "O"
-__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
-  const int splits = grp.splits;
-  const int tile_lin = blockIdx.x >> 6;
-  GemmTnArgs p = grp.prob[0];
-  int pbase = 0;
-#pragma unroll
-  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
-    if (i < grp.count && tile_lin * splits >= grp.base[i]) {
-      p = grp.prob[i];
-      pbase = grp.base[i];
-    }
-  const int nt = p.tiles_n * p.tiles_k;
-  const int t = tile_lin - pbase / splits;
-  int tn, tk;
-  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
-    tk = t / p.tiles_n;
-    tn = t - tk * p.tiles_n;
-  } else {
-    tn = t / p.tiles_k;
-    tk = t - tn * p.tiles_k;
-  }
-  const int e4 = (blockIdx.x & 63) * 256 + threadIdx.x;   // 16-byte position inside the tile's slab
-  const int lane = e4 & 63;
-  const f32x4* src = reinterpret_cast<const f32x4*>(grp.slab) + ((int64_t)(pbase + t) * 16384 + e4);
-  const int64_t sstride = (int64_t)nt * 16384;
-  // rows_per_split covers M with `active` splits (the planner's count may leave trailing ones empty)
-  const int active = min(splits, (p.M + p.rows_per_split - 1) / p.rows_per_split);
-  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-  int sidx = 0;
-  for (; sidx + 4 <= active; sidx += 4) {
-    const f32x4 a = src[(int64_t)sidx * sstride], b = src[(int64_t)(sidx + 1) * sstride];
-    const f32x4 c = src[(int64_t)(sidx + 2) * sstride], d = src[(int64_t)(sidx + 3) * sstride];
-    sum += a;
-    sum += b;
-    sum += c;
-    sum += d;
-  }
-  for (; sidx < active; ++sidx) sum += src[(int64_t)sidx * sstride];
-  int n, k;
-  if constexpr (LAYOUT == 2) {   // gemm_tn_o_kernel: e4 = ((wave*8 + nb)*4 + kb)*64 + lane, eight waves 2(n) x 4(k)
-    const int kb = (e4 >> 6) & 3, nb = (e4 >> 8) & 7, wave = e4 >> 11;
-    n = tn * TN_ + (wave >> 2) * 128 + nb * 16 + 4 * (lane >> 4);
-    k = tk * 256 + (wave & 3) * 64 + kb * 16 + (lane & 15);
-  } else {                   // gemm_tn_q_kernel: e4 = (((wave*4 + nb)*4 + kb)*4 + i)*64 + lane
-    const int i = (e4 >> 6) & 3, kb = (e4 >> 8) & 3, nb = (e4 >> 10) & 3, wave = e4 >> 12;
-    n = tn * TN_ + (wave >> 1) * 128 + nb * 32 + 8 * i + 4 * (lane >> 5);
-    k = tk * 256 + (wave & 1) * 128 + kb * 32 + (lane & 31);
-  }
-  if (k < p.K) {
-    float* o = p.dW + (int64_t)n * p.ldw + k;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (n + j < p.N) o[(int64_t)j * p.ldw] += sum[j];
-  }
-}
-
 __global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float* out,
                               int rows_per_block) {
   // block handles a 64-column strip x rows_per_block rows; 256 threads = 4 row lanes x 64 cols
@@ -927,54 +596,13 @@ int launch_tn(const GemmTnGroup& g, hipStream_t stream) {
   return MVPTR_OK;
 }
 
-// Slab workspace of the "Q" write-out: one buffer per (device, stream), grown on demand and kept
-// for the life of the process.  Launches on one stream are ordered, so the next launch's slabs
-// overwrite the buffer only after the previous reduce kernel has read it; streams that run
-// concurrently (the text / visual stacks) get separate buffers.
-constexpr size_t TN_SLAB_MAX_BYTES = (size_t)1 << 30;
-float* tn_slab_workspace(hipStream_t stream, size_t bytes) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> pool;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  auto& slot = pool[std::make_pair(dev, stream)];
-  if (slot.second >= bytes) return slot.first;
-  if (slot.first != nullptr) {
-    (void)hipFree(slot.first);   // waits for the work that may still read it
-    slot = std::make_pair((float*)nullptr, (size_t)0);
-  }
-  const size_t want = (bytes + ((size_t)32 << 20) - 1) & ~(((size_t)32 << 20) - 1);
-  void* ptr = nullptr;
-  if (hipMalloc(&ptr, want) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;               // caller falls back to the atomic write-out
-  }
-  slot = std::make_pair((float*)ptr, want);
-  return slot.first;
-}
-
-template <int STAGES, int LAYOUT>
+template <int STAGES>
 int launch_tn_q(GemmTnGroup& g, hipStream_t stream) {
   const int lds_b = STAGES * 4 * 32 * 256;
-  const void* k_atomic = LAYOUT == 2 ? (const void*)gemm_tn_o_kernel<STAGES, false> : (const void*)gemm_tn_q_kernel<STAGES, false>;
-  const void* k_slab = LAYOUT == 2 ? (const void*)gemm_tn_o_kernel<STAGES, true> : (const void*)gemm_tn_q_kernel<STAGES, true>;
-  for (const void* fn : {k_atomic, k_slab}) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
-    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
-  }
-  g.slab = nullptr;
-  const size_t slab_bytes = (size_t)g.base[g.count] * 65536 * sizeof(float);
-  if (mvptr_knobs().tn_slab != 0 && g.splits >= 2 && slab_bytes <= TN_SLAB_MAX_BYTES)
-    g.slab = tn_slab_workspace(stream, slab_bytes);
-  void* kargs[] = {(void*)&g};
-  hipError_t le = hipLaunchKernel(g.slab == nullptr ? k_atomic : k_slab, dim3(g.base[g.count]), dim3(LAYOUT == 2 ? 512 : 256), kargs, lds_b, stream);
-  if (le != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: launch: %s", hipGetErrorString(le));
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_q_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
   MVPTR_CHECK_LAUNCH("gemm_tn");
-  if (g.slab != nullptr) {
-    hipLaunchKernelGGL(tn_reduce_kernel<LAYOUT>, dim3((g.base[g.count] / g.splits) * 64), dim3(256), 0, stream, g);
-    MVPTR_CHECK_LAUNCH("gemm_tn reduce");
-  }
   return MVPTR_OK;
 }
 
@@ -986,7 +614,7 @@ struct TnPlan {
 // Estimated time of one configuration for `tiles` output tiles of one launch (all problems of a
 // group share M, so they share the split count): whole rounds of workgroups x steps per split,
 // plus the f32 atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
-TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false, bool slab = false) {
+TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
   // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1; "Q": round 2)
   const double t64 = quad ? 1.5 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
@@ -996,9 +624,8 @@ TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad 
     const double rounds = (double)((tiles * sp + slots - 1) / slots);
     const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
     const double out_b = (double)out_elems * 4.0;
-    // write-out: f32 atomics (~1.3 TB/s chip-wide, partly overlapped), or plain slab stores
-    // (~6.5 TB/s) + the reduce kernel's reads of every slab (mostly L2 / MALL hits) + its launch
-    const double wr = (slab && sp >= 2) ? sp * out_b / 6.5e6 + (sp + 2) * out_b / 5.0e6 + 4.0 : sp * out_b / 1.3e6 * 0.7;
+    // write-out: f32 atomics (~1.3 TB/s chip-wide, partly overlapped)
+    const double wr = sp * out_b / 1.3e6 * 0.7;
     const double cost = rounds * steps * t64 + wr;
     if (cost < best.cost) {
       best.cost = cost;
@@ -1032,20 +659,16 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
       tiles += ((probs[i].N + TN_ - 1) / TN_) * ((probs[i].K + cfg_ks[c] * 128 - 1) / (cfg_ks[c] * 128));
       out_elems += (int64_t)probs[i].N * probs[i].K;
     }
-    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4, c == 4 && mvptr_knobs().tn_slab != 0);
+    plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4);
   }
   // "Q" (256x256 tile, four waves of 128x128) wins from ~6 k token rows up (tools/sweep_tn.py,
   // tools/sweep_tn_group.py: 1.0-1.15 PF/s against 0.7-0.8 at M >= 19 k, +8 % at 11 k, -7 % at 3 k)
   int pick = (plans[1].cost < plans[0].cost) ? 1 : 0;
   if (M >= 6000) pick = 4;
   const char* env = mvptr_knobs().gemm_tn;
-  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q' || env[0] == 'o' || env[0] == 'O') ? 4 : 0;
+  if (env[0] != 0) pick = (env[0] == '6') ? 1 : (env[0] == 'k') ? 2 : (env[0] == 'K') ? 3 : (env[0] == 'q' || env[0] == 'Q') ? 4 : 0;
   TnPlan pl = plans[pick];
   if (mvptr_knobs().tn_splits > 0) pl.splits = min(mvptr_knobs().tn_splits, (M + 255) / 256);
-  // 256 x 256 tiles: "Q" (four waves, 32x32x16) unless MVPTR_GEMM_TN=o asks for "O" (eight waves, 16x16x32;
-  // within 2-5 % of "Q" on isolated launches, no difference on the training step: see its header)
-  const bool oshape = (pick == 4) && (env[0] == 'o' || env[0] == 'O');
-  if (oshape) pl.tm = 64;       // gemm_tn_o_kernel runs its stages in pairs
   int rps = (M + pl.splits - 1) / pl.splits;
   rps = (rps + pl.tm - 1) / pl.tm * pl.tm;
   // keep each split's byte span below 2 GiB (buffer offsets are 32-bit)
@@ -1058,7 +681,6 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
   const int splits = (M + rps - 1) / rps;
   GemmTnGroup g;
   g.count = count;
-  g.slab = nullptr;
   g.splits = splits;
   g.base[0] = 0;
   for (int i = 0; i < count; ++i) {
@@ -1087,7 +709,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
-  if (pick == 4) return oshape ? launch_tn_q<4, 2>(g, stream) : launch_tn_q<4, 0>(g, stream);
+  if (pick == 4) return launch_tn_q<4>(g, stream);
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
   if (pl.tm == 64) return launch_tn<64, 1, 3>(g, stream);

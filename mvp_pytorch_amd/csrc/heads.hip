@@ -30,70 +30,113 @@ __device__ __forceinline__ float ld_elem(const void* base, int64_t idx, int is_b
   return is_bf16 ? bf2f(((const __bf16*)base)[idx]) : ((const float*)base)[idx];
 }
 
-// C[M,N] = act(alpha * op(A) op(B) + bias): 32 x 32 tile per 256-thread workgroup, 4 outputs per thread
-// (rows ty + 8 i of column tx), K swept in slices of 32 through LDS.
-__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs p) {
-  __shared__ float As[32][33];  // [m][k]
-  __shared__ float Bs[32][33];  // [k][n]
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < p.K; k0 += 32) {
+// C[M,N] = act(alpha * op(A) op(B) + bias): one 32 x 32 output tile per 256-thread workgroup.  The four waves
+// each take a quarter of K and multiply with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: an fmaf chain,
+// exact f32 at the vector rate) on operands loaded from global memory STRAIGHT into the MFMA operand layout — no
+// LDS staging and no barrier in the loop, eight 8-deep k-chunks (32 independent loads per lane) in flight: these
+// products are latency-bound (192 workgroups for a 256 x 768 output, one per CU), so what counts is how many
+// loads a wave keeps outstanding.  MFMA step j of a chunk uses k = chunk + 4 h + j on lane half h for BOTH
+// operands (a sum over k may take its terms in any order), so a lane's four k values are contiguous: one 16-byte
+// (f32) or 8-byte (bf16) load where k is the operand's contiguous index, four row-coalesced scalar loads
+// where it is not.  The partial tiles of waves 1-3 are summed through LDS at the end.
+template <bool BF16>
+__device__ __forceinline__ void sg_load4(const void* base, int64_t row_off, int64_t k_stride, int kk, int klimit, bool row_ok,
+                                         float out[4]) {
+  // four values at element offsets row_off + (kk + j) * k_stride, j = 0..3; zeros outside the problem
+  if (k_stride == 1 && row_ok && kk + 3 < klimit && ((row_off + kk) & 3) == 0 && (((uintptr_t)base) & (BF16 ? 7 : 15)) == 0) {
+    if (BF16) {
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>((const __bf16*)base + row_off + kk);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // A slice: element (m, k); fastest-varying index of the load follows the storage order
-      {
-        const int a = ty + 8 * i, b = tx;
-        const int m = p.trans_a ? (m0 + b) : (m0 + a);
-        const int k = p.trans_a ? (k0 + a) : (k0 + b);
-        float v = 0.f;
-        if (m < p.M && k < p.K) {
-          if (p.trans_a) {
-            const int64_t row = p.a_rows ? (int64_t)p.a_rows[k] : (int64_t)k;   // stored [K, M]: gather applies to stored rows
-            v = ld_elem(p.A, row * p.lda + m, p.a_bf16);
-          } else {
-            const int64_t row = p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m;
-            v = ld_elem(p.A, row * p.lda + k, p.a_bf16);
-          }
-        }
-        if (p.trans_a) As[b][a] = v; else As[a][b] = v;
-      }
-      {
-        const int a = ty + 8 * i, b = tx;
-        const int k = p.trans_b ? (k0 + b) : (k0 + a);
-        const int n = p.trans_b ? (n0 + a) : (n0 + b);
-        float v = 0.f;
-        if (k < p.K && n < p.N) {
-          if (p.trans_b) {
-            const int64_t row = p.b_rows ? (int64_t)p.b_rows[n] : (int64_t)n;
-            v = ld_elem(p.B, row * p.ldb + k, p.b_bf16);
-          } else {
-            const int64_t row = p.b_rows ? (int64_t)p.b_rows[k] : (int64_t)k;
-            v = ld_elem(p.B, row * p.ldb + n, p.b_bf16);
-          }
-        }
-        if (p.trans_b) Bs[b][a] = v; else Bs[a][b] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const float bv = Bs[k][tx];
+      for (int j = 0; j < 4; ++j) out[j] = bf2f(v[j]);
+    } else {
+      const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)base + row_off + kk);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = fmaf(As[ty + 8 * i][k], bv, acc[i]);
+      for (int j = 0; j < 4; ++j) out[j] = v[j];
     }
-    __syncthreads();
+    return;
   }
-  const int n = n0 + tx;
-  if (n >= p.N) return;
-  const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty + 8 * i;
-    if (m >= p.M) continue;
-    float v = acc[i] * p.alpha + bv;
+  for (int j = 0; j < 4; ++j) {
+    float v = 0.f;
+    if (row_ok && kk + j < klimit) {
+      const int64_t o = row_off + (int64_t)(kk + j) * k_stride;
+      v = BF16 ? bf2f(((const __bf16*)base)[o]) : ((const float*)base)[o];
+    }
+    out[j] = v;
+  }
+}
+
+template <bool ABF, bool BBF>
+__global__ __launch_bounds__(256) void sgemm_small_kernel(SgemmArgs p) {
+  __shared__ float red[3][16][64];      // partial tiles of waves 1..3
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m = m0 + l31, n = n0 + l31;
+  // this wave's k range: a quarter of K rounded up to whole 8-deep chunks
+  const int kq = ((p.K + 31) / 32) * 8;
+  const int kbeg = wave * kq, kend = min(p.K, kbeg + kq);
+  // A: lane (row m, half h) reads op(A)[m][k]; B: lane (column n, half h) reads op(B)[k][n]
+  const bool a_gather_k = p.trans_a && p.a_rows != nullptr, b_gather_k = !p.trans_b && p.b_rows != nullptr;
+  int64_t a_off = 0, a_ks = 1, b_off = 0, b_ks = 1;
+  const bool a_ok = m < p.M, b_ok = n < p.N;
+  if (p.trans_a) { a_off = m; a_ks = p.lda; }                 // stored [K, M]
+  else { a_off = (a_ok ? (p.a_rows ? (int64_t)p.a_rows[m] : (int64_t)m) : 0) * p.lda; a_ks = 1; }
+  if (p.trans_b) { b_off = (b_ok ? (p.b_rows ? (int64_t)p.b_rows[n] : (int64_t)n) : 0) * p.ldb; b_ks = 1; }   // stored [N, K]
+  else { b_off = n; b_ks = p.ldb; }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int UN = 8;   // chunks in flight
+  for (int kb = kbeg; kb < kend; kb += 8 * UN) {
+    float av[UN][4], bv[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int kk = kb + 8 * u + 4 * hh;
+      if (a_gather_k || b_gather_k) {
+        // the gather indexes stored rows = k: resolve each k on its own
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kk + j;
+          float x = 0.f, y = 0.f;
+          if (k < kend) {
+            if (a_ok) {
+              const int64_t o = p.trans_a ? (a_gather_k ? (int64_t)p.a_rows[k] : (int64_t)k) * p.lda + m : a_off + k;
+              x = ABF ? bf2f(((const __bf16*)p.A)[o]) : ((const float*)p.A)[o];
+            }
+            if (b_ok) {
+              const int64_t o = p.trans_b ? b_off + k : (b_gather_k ? (int64_t)p.b_rows[k] : (int64_t)k) * p.ldb + n;
+              y = BBF ? bf2f(((const __bf16*)p.B)[o]) : ((const float*)p.B)[o];
+            }
+          }
+          av[u][j] = x;
+          bv[u][j] = y;
+        }
+      } else {
+        sg_load4<ABF>(p.A, a_off, a_ks, kk, kend, a_ok, av[u]);
+        sg_load4<BBF>(p.B, b_off, b_ks, kk, kend, b_ok, bv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], bv[u][j], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0 || n >= p.N) return;
+  const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mr = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;   // 32x32 accumulator layout: register r, lane half hh -> row
+    if (mr >= p.M) continue;
+    float v = ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane])) * p.alpha + bias;
     if (p.act == 1) v = tanhf(v);
-    float* c = p.C + (int64_t)m * p.ldc + n;
+    float* c = p.C + (int64_t)mr * p.ldc + n;
     *c = p.accumulate ? (*c + v) : v;
   }
 }
@@ -233,7 +276,11 @@ extern "C" int mvptr_sgemm_small(const void* A, int64_t lda, int a_bf16, int tra
   p.trans_a = trans_a ? 1 : 0; p.trans_b = trans_b ? 1 : 0;
   p.a_bf16 = a_bf16 ? 1 : 0; p.b_bf16 = b_bf16 ? 1 : 0;
   p.act = act; p.accumulate = accumulate ? 1 : 0; p.alpha = alpha;
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((N + 31) / 32, (M + 31) / 32);
+  if (p.a_bf16 && p.b_bf16) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (p.a_bf16) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else if (p.b_bf16) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   MVPTR_CHECK_LAUNCH("sgemm_small");
   return MVPTR_OK;
 }

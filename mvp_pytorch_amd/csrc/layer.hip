@@ -120,36 +120,11 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
   return MVPTR_OK;
 }
 
-namespace {
-// Hand-over from the layer's stream to the weight-gradient stream: an event recorded behind the kernel
-// that produced the last operand, waited for by the other stream.  Events come from a small per-thread
-// ring (a wait captures the record that precedes it, so re-recording an event later is harmless).
-int wgrad_handover(hipStream_t from, hipStream_t to) {
-  constexpr int RING = 32;
-  static thread_local hipEvent_t ring[RING];
-  static thread_local int used = 0, next = 0;
-  if (used < RING) {
-    hipError_t e = hipEventCreateWithFlags(&ring[used], hipEventDisableTiming);
-    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "encoder_layer_bwd: event: %s", hipGetErrorString(e));
-    ++used;
-  }
-  hipEvent_t ev = ring[next];
-  next = (next + 1) % used;
-  hipError_t e = hipEventRecord(ev, from);
-  if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "encoder_layer_bwd: hand-over: %s", hipGetErrorString(e));
-  return MVPTR_OK;
-}
-}  // namespace
-
-extern "C" int mvptr_encoder_layer_bwd2(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
-                                        const void* x, const float* mask_add, const void* saved,
-                                        const void* dy, void* dx, const mvptr_layer_grads* g,
-                                        void* ws, int64_t ws_bytes, void* stream, void* wgrad_stream) {
+extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                       const void* x, const float* mask_add, const void* saved,
+                                       const void* dy, void* dx, const mvptr_layer_grads* g,
+                                       void* ws, int64_t ws_bytes, void* stream) {
   RUN(check_desc("encoder_layer_bwd", d));
-  // weight gradients on their own stream (NULL or == stream: on the layer's stream)
-  void* const wstream = (wgrad_stream != nullptr) ? wgrad_stream : stream;
-  const bool aside = (wstream != stream);
   if (!w || !x || !saved || !dy || !dx || !g || !ws || (!mask_add && d->M == 0))
     MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd: NULL argument");
   if (ws_bytes < mvptr_layer_workspace_bytes(d))
@@ -201,10 +176,7 @@ extern "C" int mvptr_encoder_layer_bwd2(const mvptr_layer_desc* d, const mvptr_l
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache
   if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, nullptr);
-  if (nwg > 0) {
-    if (aside) RUN(wgrad_handover((hipStream_t)stream, (hipStream_t)wstream));   // d2 and dU are complete behind this point
-    RUN(mvptr_gemm_tn_multi(wg, nwg, wstream));
-  }
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
   nwg = 0;
   RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
                     nullptr, nullptr, stream));
@@ -233,16 +205,6 @@ extern "C" int mvptr_encoder_layer_bwd2(const mvptr_layer_desc* d, const mvptr_l
     wg[0] = wg[1];
     wg[1] = t;
   }
-  if (nwg > 0) {
-    if (aside) RUN(wgrad_handover((hipStream_t)stream, (hipStream_t)wstream));   // d1 and dqkv are complete behind this point
-    RUN(mvptr_gemm_tn_multi(wg, nwg, wstream));
-  }
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
   return MVPTR_OK;
-}
-
-extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
-                                       const void* x, const float* mask_add, const void* saved,
-                                       const void* dy, void* dx, const mvptr_layer_grads* g,
-                                       void* ws, int64_t ws_bytes, void* stream) {
-  return mvptr_encoder_layer_bwd2(d, w, x, mask_add, saved, dy, dx, g, ws, ws_bytes, stream, nullptr);
 }

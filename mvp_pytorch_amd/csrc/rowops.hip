@@ -618,7 +618,14 @@ void mvptr_set_error(const char* fmt, ...) {
 extern "C" const char* mvptr_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
-// diagnostic knobs (see common.h)
+// kernel-configuration knobs (see common.h): constants in the product build, environment + mvptr_set_knob in the
+// diagnostic build
+#ifndef MVPTR_DIAG_BUILD
+const MvptrKnobs& mvptr_knobs() {
+  static const MvptrKnobs defaults = {{0}, {0}, 0, 1, 0, 0, {0, 0}, 0ull};
+  return defaults;
+}
+#else
 namespace {
 MvptrKnobs g_knobs;
 bool knob_assign(const char* name, const char* value) {
@@ -629,14 +636,9 @@ bool knob_assign(const char* name, const char* value) {
   else if (!strcmp(name, "MVPTR_TN_GROUP")) g_knobs.tn_group = (v[0] == 0) ? 1 : atoi(v);
   else if (!strcmp(name, "MVPTR_LN_GRID")) g_knobs.ln_grid = atoi(v);
   else if (!strcmp(name, "MVPTR_TN_SPLITS")) g_knobs.tn_splits = atoi(v);
-  else if (!strcmp(name, "MVPTR_TN_SLAB")) g_knobs.tn_slab = atoi(v);
   else if (!strcmp(name, "MVPTR_NT_GROUP")) {
     g_knobs.nt_group[0] = g_knobs.nt_group[1] = 0;
     sscanf(v, "%d,%d", &g_knobs.nt_group[0], &g_knobs.nt_group[1]);
-  }
-  else if (!strcmp(name, "MVPTR_GEMM_DELAY")) {
-    g_knobs.delay[0] = 0; g_knobs.delay[1] = 256; g_knobs.delay[2] = 512;
-    sscanf(v, "%d,%d,%d", &g_knobs.delay[0], &g_knobs.delay[1], &g_knobs.delay[2]);
   } else if (!strcmp(name, "MVPTR_GEMM_STAMPS")) g_knobs.stamps = strtoull(v, nullptr, 0);
   else return false;
   return true;
@@ -644,12 +646,8 @@ bool knob_assign(const char* name, const char* value) {
 bool knobs_from_env() {
   memset(&g_knobs, 0, sizeof(g_knobs));
   g_knobs.tn_group = 1;
-  g_knobs.tn_slab = 0;
-  g_knobs.delay[1] = 256;
-  g_knobs.delay[2] = 512;
   static const char* names[] = {"MVPTR_GEMM_CFG", "MVPTR_GEMM_TN", "MVPTR_NT_EXP", "MVPTR_TN_GROUP",
-                                "MVPTR_LN_GRID", "MVPTR_GEMM_DELAY", "MVPTR_GEMM_STAMPS", "MVPTR_TN_SPLITS",
-                                "MVPTR_TN_SLAB", "MVPTR_NT_GROUP"};
+                                "MVPTR_LN_GRID", "MVPTR_GEMM_STAMPS", "MVPTR_TN_SPLITS", "MVPTR_NT_GROUP"};
   for (const char* n : names) {
     const char* v = getenv(n);
     if (v != nullptr && v[0] != 0) {
@@ -672,6 +670,7 @@ extern "C" int mvptr_set_knob(const char* name, const char* value) {
   if (!knob_assign(name, value)) MVPTR_FAIL(MVPTR_BAD_ARG, "set_knob: unknown knob '%s'", name);
   return MVPTR_OK;
 }
+#endif
 
 extern "C" int mvptr_query(int what, int64_t* out) {
   if (!out) MVPTR_FAIL(MVPTR_BAD_ARG, "query: out is NULL");

@@ -14,15 +14,36 @@ namespace {
 // [col0, col0 + len) of row sel[s] (s when sel == NULL) of its additive mask (valid slot <=> mask == 0) and
 // names the source row of a valid slot: pos[sel * ld_pos + col] (a row of an already packed buffer) or, when
 // pos == NULL, sel * src_seq_stride + col (a row of a padded [*, src_seq_stride, H] buffer), plus src_base.
-// One workgroup: sequences are dealt to threads (count pass), a block-wide exclusive scan gives seq_start,
-// a second pass writes pos_out[s, slot] = packed row (-1: padded slot) and idx_out[packed row] = source row.
-__global__ __launch_bounds__(1024) void pack_maps_kernel(mvptr_pack_seg s0, mvptr_pack_seg s1, int nseg, int n_seq,
-                                                          int32_t* pos_out, int32_t* idx_out, int32_t* seq_start,
-                                                          int32_t* seq_len, int64_t* counts) {
+// Three small launches: (1) one wave per sequence counts its valid slots (64 slots per ballot); (2) one
+// workgroup scans the counts into seq_start and writes the totals; (3) one wave per sequence writes
+// pos_out[s, slot] = packed row (-1: padded slot) and idx_out[packed row] = source row from ballot prefix counts.
+__device__ __forceinline__ const float* seg_mask_row(const mvptr_pack_seg& g, int s, int64_t& r) {
+  r = g.sel ? g.sel[s] : (int64_t)s;
+  return g.mask + r * g.ld_mask + g.col0;
+}
+
+__global__ __launch_bounds__(256) void pack_count_kernel(mvptr_pack_seg s0, mvptr_pack_seg s1, int nseg, int n_seq,
+                                                          int32_t* seq_len) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_seq) return;
+  int cnt = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const mvptr_pack_seg& g = k ? s1 : s0;
+    int64_t r;
+    const float* m = seg_mask_row(g, s, r);
+    for (int l0 = 0; l0 < g.len; l0 += 64) {
+      const bool ok = (l0 + lane < g.len) && (m[l0 + lane] == 0.f);
+      cnt += __popcll(__ballot(ok));
+    }
+  }
+  if (lane == 0) seq_len[s] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t* seq_len, int n_seq, int32_t* seq_start, int64_t* counts) {
   __shared__ int scan[1024];
   __shared__ int carry_s, maxlen_s;
   const int tid = threadIdx.x;
-  const int Ltot = s0.len + (nseg > 1 ? s1.len : 0);
   if (tid == 0) {
     carry_s = 0;
     maxlen_s = 0;
@@ -30,59 +51,19 @@ __global__ __launch_bounds__(1024) void pack_maps_kernel(mvptr_pack_seg s0, mvpt
   __syncthreads();
   for (int base = 0; base < n_seq; base += 1024) {
     const int s = base + tid;
-    int cnt = 0;
-    if (s < n_seq) {
-      {
-        const int64_t r = s0.sel ? s0.sel[s] : (int64_t)s;
-        const float* m = s0.mask + r * s0.ld_mask + s0.col0;
-        for (int l = 0; l < s0.len; ++l) cnt += (m[l] == 0.f);
-      }
-      if (nseg > 1) {
-        const int64_t r = s1.sel ? s1.sel[s] : (int64_t)s;
-        const float* m = s1.mask + r * s1.ld_mask + s1.col0;
-        for (int l = 0; l < s1.len; ++l) cnt += (m[l] == 0.f);
-      }
-    }
-    // inclusive scan of cnt over the 1024 threads (Hillis-Steele in LDS)
+    const int cnt = (s < n_seq) ? seq_len[s] : 0;
     scan[tid] = cnt;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
       const int v = (tid >= o) ? scan[tid - o] : 0;
       __syncthreads();
       scan[tid] += v;
       __syncthreads();
     }
     const int carry = carry_s;
-    int start = carry + scan[tid] - cnt;
     if (s < n_seq) {
-      seq_start[s] = start;
-      seq_len[s] = cnt;
+      seq_start[s] = carry + scan[tid] - cnt;
       atomicMax(&maxlen_s, cnt);
-      int32_t* po = pos_out + (int64_t)s * Ltot;
-      {
-        const int64_t r = s0.sel ? s0.sel[s] : (int64_t)s;
-        const float* m = s0.mask + r * s0.ld_mask + s0.col0;
-        for (int l = 0; l < s0.len; ++l) {
-          const bool ok = (m[l] == 0.f);
-          po[l] = ok ? start : -1;
-          if (ok) {
-            const int64_t src = s0.pos ? (int64_t)s0.pos[r * s0.ld_pos + s0.col0 + l] : r * s0.src_seq_stride + s0.col0 + l;
-            idx_out[start++] = (int32_t)(src + s0.src_base);
-          }
-        }
-      }
-      if (nseg > 1) {
-        const int64_t r = s1.sel ? s1.sel[s] : (int64_t)s;
-        const float* m = s1.mask + r * s1.ld_mask + s1.col0;
-        for (int l = 0; l < s1.len; ++l) {
-          const bool ok = (m[l] == 0.f);
-          po[s0.len + l] = ok ? start : -1;
-          if (ok) {
-            const int64_t src = s1.pos ? (int64_t)s1.pos[r * s1.ld_pos + s1.col0 + l] : r * s1.src_seq_stride + s1.col0 + l;
-            idx_out[start++] = (int32_t)(src + s1.src_base);
-          }
-        }
-      }
     }
     __syncthreads();
     if (tid == 1023) carry_s = carry + scan[1023];
@@ -91,6 +72,37 @@ __global__ __launch_bounds__(1024) void pack_maps_kernel(mvptr_pack_seg s0, mvpt
   if (tid == 0) {
     counts[0] = carry_s;
     counts[1] = maxlen_s;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_fill_kernel(mvptr_pack_seg s0, mvptr_pack_seg s1, int nseg, int n_seq,
+                                                         const int32_t* seq_start, int32_t* pos_out, int32_t* idx_out) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_seq) return;
+  const int Ltot = s0.len + (nseg > 1 ? s1.len : 0);
+  int32_t* po = pos_out + (int64_t)s * Ltot;
+  int run = seq_start[s];
+  int slot0 = 0;
+  const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));   // lanes below this one
+  for (int k = 0; k < nseg; ++k) {
+    const mvptr_pack_seg& g = k ? s1 : s0;
+    int64_t r;
+    const float* m = seg_mask_row(g, s, r);
+    for (int l0 = 0; l0 < g.len; l0 += 64) {
+      const int l = l0 + lane;
+      const bool in = l < g.len;
+      const bool ok = in && (m[l] == 0.f);
+      const uint64_t bal = __ballot(ok);
+      const int dest = run + __popcll(bal & lt);
+      if (in) po[slot0 + l] = ok ? dest : -1;
+      if (ok) {
+        const int64_t src = g.pos ? (int64_t)g.pos[r * g.ld_pos + g.col0 + l] : r * g.src_seq_stride + g.col0 + l;
+        idx_out[dest] = (int32_t)(src + g.src_base);
+      }
+      run += __popcll(bal);
+    }
+    slot0 += g.len;
   }
 }
 
@@ -111,26 +123,41 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const __bf16* src, int
     *reinterpret_cast<u32x4*>(out + (int64_t)r * ld_out + c * 8) = v;
   }
 }
-// dst[idx[i], :] += src[i, :] (bf16 destination, packed-pair atomics: rows may repeat and several calls may hit
-// one row); src is bf16, or f32 (gradient of an f32 head, rounded to bf16 on the way) when src_f32
+// dst[idx[i], :] += src[i, :]: rows may repeat and several calls may hit one row, so the adds are atomics — f32
+// atomics into an f32 destination (dst_f32: sums exact to 2^-24 whatever the arrival order; the caller rounds to
+// bf16 once) or packed-pair bf16 atomics into a bf16 destination (every add rounds: order-dependent at 2^-9).
+// src is bf16, or f32 (gradient of an f32 head) when src_f32.
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const void* src, int64_t ld_src, int src_f32, const int32_t* idx,
-                                                                __bf16* dst, int64_t ld_dst, __bf16* dst2, int64_t ld_dst2, int split,
-                                                                int n, int pairs) {
+                                                                void* dst_, int64_t ld_dst, void* dst2_, int64_t ld_dst2, int split,
+                                                                int n, int pairs, int dst_f32) {
   const int64_t total = (int64_t)n * pairs;
   for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int r = (int)(e / pairs), c = (int)(e - (int64_t)r * pairs);
     const int d = idx[r];
     if (d < 0) continue;
-    bf16x2 v;
+    float f0, f1;
     if (src_f32) {
       const float* sp = (const float*)src + (int64_t)r * ld_src + c * 2;
-      v[0] = f2bf(sp[0]);
-      v[1] = f2bf(sp[1]);
+      f0 = sp[0];
+      f1 = sp[1];
     } else {
-      v = *reinterpret_cast<const bf16x2*>((const __bf16*)src + (int64_t)r * ld_src + c * 2);
+      const bf16x2 sv = *reinterpret_cast<const bf16x2*>((const __bf16*)src + (int64_t)r * ld_src + c * 2);
+      f0 = bf2f(sv[0]);
+      f1 = bf2f(sv[1]);
     }
-    __bf16* dp = (dst2 != nullptr && d >= split) ? dst2 + (int64_t)(d - split) * ld_dst2 + c * 2 : dst + (int64_t)d * ld_dst + c * 2;
-    asm volatile("global_atomic_pk_add_bf16 %0, %1, off" : : "v"(dp), "v"(v) : "memory");
+    const bool second = (dst2_ != nullptr && d >= split);
+    const int64_t off = second ? (int64_t)(d - split) * ld_dst2 + c * 2 : (int64_t)d * ld_dst + c * 2;
+    if (dst_f32) {
+      float* dp = (float*)(second ? dst2_ : dst_) + off;
+      atomicAdd(dp, f0);
+      atomicAdd(dp + 1, f1);
+    } else {
+      __bf16* dp = (__bf16*)(second ? dst2_ : dst_) + off;
+      bf16x2 v;
+      v[0] = f2bf(f0);
+      v[1] = f2bf(f1);
+      asm volatile("global_atomic_pk_add_bf16 %0, %1, off" : : "v"(dp), "v"(v) : "memory");
+    }
   }
 }
 
@@ -143,8 +170,10 @@ extern "C" int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, 
   for (int k = 0; k < nseg; ++k)
     if (!segs[k].mask || segs[k].len <= 0 || segs[k].col0 < 0) MVPTR_FAIL(MVPTR_BAD_ARG, "pack_maps: bad segment %d", k);
   mvptr_pack_seg s1 = segs[nseg > 1 ? 1 : 0];
-  hipLaunchKernelGGL(pack_maps_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, segs[0], s1, nseg, n_seq, pos_out, idx_out,
-                     seq_start, seq_len, counts);
+  const dim3 grid((n_seq + 3) / 4);
+  hipLaunchKernelGGL(pack_count_kernel, grid, dim3(256), 0, (hipStream_t)stream, segs[0], s1, nseg, n_seq, seq_len);
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seq_len, n_seq, seq_start, counts);
+  hipLaunchKernelGGL(pack_fill_kernel, grid, dim3(256), 0, (hipStream_t)stream, segs[0], s1, nseg, n_seq, seq_start, pos_out, idx_out);
   MVPTR_CHECK_LAUNCH("pack_maps");
   return MVPTR_OK;
 }
@@ -165,7 +194,8 @@ extern "C" int mvptr_gather_rows(const void* src, int64_t ld_src, const void* sr
 }
 
 extern "C" int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f32, const int32_t* idx, void* dst,
-                                      int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int n, int H, void* stream) {
+                                      int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int dst_f32, int n, int H,
+                                      void* stream) {
   if (n <= 0 || H <= 0 || (H & 1) || (ld_src & 1) || (ld_dst & 1) || (dst2 && (ld_dst2 & 1)))
     MVPTR_FAIL(MVPTR_BAD_SHAPE, "scatter_add_rows: H and the leading dimensions must be positive and even");
   if (!src || !idx || !dst || ((uintptr_t)src & 3) || ((uintptr_t)dst & 3) || ((uintptr_t)dst2 & 3))
@@ -174,7 +204,7 @@ extern "C" int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f
   int grid = (int)((total + 255) / 256);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, src_f32 ? 1 : 0, idx,
-                     (__bf16*)dst, ld_dst, (__bf16*)dst2, ld_dst2, split, n, H / 2);
+                     dst, ld_dst, dst2, ld_dst2, split, n, H / 2, dst_f32 ? 1 : 0);
   MVPTR_CHECK_LAUNCH("scatter_add_rows");
   return MVPTR_OK;
 }

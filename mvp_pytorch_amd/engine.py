@@ -889,8 +889,8 @@ class MultiTapFn(torch.autograd.Function):
     read src2), idx_k int32 (negative index = zero row).  ALL the rows that later stages read from one stack
     output go through ONE call — the packed joint input gathered from the packed text and visual outputs, [CLS]
     states, masked-LM rows, phrase / region rows of the word-region alignment — so the backward pass builds each
-    buffer's gradient with one zero fill and one scatter-add per consumer (rows may repeat: packed bf16 atomics)
-    instead of a full-size zero-filled tensor + add per consumer.  Incoming gradients may be bf16 or f32."""
+    buffer's gradient with one zero fill and one scatter-add per consumer (rows may repeat: f32 atomics, rounded to
+    bf16 once) instead of a full-size zero-filled tensor + add per consumer.  Incoming gradients may be bf16 or f32."""
 
     @staticmethod
     def forward(ctx, src, src2, *idxs):
@@ -903,8 +903,9 @@ class MultiTapFn(torch.autograd.Function):
     def backward(ctx, *gs):
         s1, s2 = ctx.shapes
         dev = ctx.idxs[0].device
-        d = torch.zeros(s1, device=dev, dtype=torch.bfloat16)
-        d2 = torch.zeros(s2, device=dev, dtype=torch.bfloat16) if s2 is not None else None
+        # f32 accumulation (order-independent to 2^-24), one rounding to bf16 at the end
+        d = torch.zeros(s1, device=dev, dtype=torch.float32)
+        d2 = torch.zeros(s2, device=dev, dtype=torch.float32) if s2 is not None else None
         for g, i in zip(gs, ctx.idxs):
             if g is None:
                 continue
@@ -912,7 +913,7 @@ class MultiTapFn(torch.autograd.Function):
             if g.dtype not in (torch.bfloat16, torch.float32):
                 g = g.float()
             hip.scatter_add_rows(g, i, d, d2)
-        return (d, d2) + (None,) * len(ctx.idxs)
+        return (d.to(torch.bfloat16), d2.to(torch.bfloat16) if d2 is not None else None) + (None,) * len(ctx.idxs)
 
 
 def tap_rows(src, idx, src2=None):

@@ -14,19 +14,20 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip.so")
+# MVPTR_LIB=diag (measurement tools only): the diagnostic build with kernel-configuration knobs (`make diag`)
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip_diag.so" if os.environ.get("MVPTR_LIB") == "diag" else "libmvptr_hip.so")
 
 # epilogue codes (mvptr_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIAS_TANH = range(7)
 
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "mvptr_query", "mvptr_last_error", "mvptr_set_knob", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
+    "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
-    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe", "mvptr_encoder_layer_bwd2",
+    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe",
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps",
@@ -86,7 +87,8 @@ def load():
     lib.mvptr_layer_workspace_bytes.argtypes = [POINTER(LayerDesc)]
     P, I64, I, F = c_void_p, c_int64, c_int, c_float
     lib.mvptr_query.argtypes = [I, POINTER(c_int64)]
-    lib.mvptr_set_knob.argtypes = [c_char_p, c_char_p]
+    if hasattr(lib, "mvptr_set_knob"):      # diagnostic build only
+        lib.mvptr_set_knob.argtypes = [c_char_p, c_char_p]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
@@ -120,7 +122,7 @@ def load():
     lib.mvptr_clip_ce_fwd.argtypes = [P, I, I64, P, P, P, P, P]
     lib.mvptr_clip_ce_bwd.argtypes = [P, I, I64, P, P, P, P, P, P, P]
     lib.mvptr_gather_rows.argtypes = [P, I64, P, I64, I, P, P, I64, I, I, P]
-    lib.mvptr_scatter_add_rows.argtypes = [P, I64, I, P, P, I64, P, I64, I, I, I, P]
+    lib.mvptr_scatter_add_rows.argtypes = [P, I64, I, P, P, I64, P, I64, I, I, I, I, P]
     lib.mvptr_pack_maps.argtypes = [POINTER(PackSeg), I, I, P, P, P, P, P, P]
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
     lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
@@ -130,7 +132,6 @@ def load():
     lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
-    lib.mvptr_encoder_layer_bwd2.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P, P]
     _lib = lib
     return lib
 
@@ -539,12 +540,13 @@ def gather_rows(src, idx, out=None, src2=None):
 
 
 def scatter_add_rows(src, idx, dst, dst2=None):
-    """dst[idx[i]] += src[i] (dst bf16 rows, src bf16 or f32; packed bf16 atomics, rows may repeat); with dst2,
+    """dst[idx[i]] += src[i] (dst f32 or bf16 rows, src bf16 or f32; atomics, rows may repeat); with dst2,
     idx >= dst.shape[0] adds into dst2[idx - dst.shape[0]]."""
     n, H = idx.numel(), dst.shape[1]
     if n:
         _check(load().mvptr_scatter_add_rows(_p(src), src.stride(0), int(src.dtype == torch.float32), _p(idx), _p(dst), dst.stride(0),
-                                             _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0], n, H, _stream()))
+                                             _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0],
+                                             int(dst.dtype == torch.float32), n, H, _stream()))
     return dst
 
 

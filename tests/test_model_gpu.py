@@ -348,9 +348,11 @@ def test_unpadded_equals_padded_execution(dev):
     print("losses unpadded", res[True].tolist(), "padded", res[False].tolist())
     assert torch.allclose(res[True], res[False], rtol=2e-4, atol=1e-5)
     assert grads[True].keys() == grads[False].keys()
-    worst = max((_rel(grads[True][n], grads[False][n]), n) for n in grads[True] if grads[False][n].norm() > 1e-6)
+    # key.bias has a mathematically zero gradient (softmax is invariant to a per-query shift): pure rounding noise
+    worst = max((_rel(grads[True][n], grads[False][n]), n) for n in grads[True]
+                if grads[False][n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
     print("worst gradient difference", worst)
-    assert worst[0] < 2e-3
+    assert worst[0] < 6e-3      # one bf16 rounding (2^-8) of differently ordered sums: padded rows are added as zeros on one side only
     va = b["input_mask_a"].bool()
     vb = b["input_mask_b"].bool()
     (seq_u, txt_u, vis_u, sim_u), (seq_p, txt_p, vis_p, sim_p) = outs[True], outs[False]
@@ -998,6 +1000,7 @@ def test_packed_pipeline_equals_general_path(dev, streams):
     assert np.abs(la - lb).max() / np.abs(la).max() < 5e-4
     ga, gb = res[False][1], res[True][1]
     assert set(ga) == set(gb)
-    worst = max((_rel(gb[n], ga[n]), n) for n in ga)
+    # key.bias has a mathematically zero gradient (softmax is invariant to a per-query shift): pure rounding noise
+    worst = max((_rel(gb[n], ga[n]), n) for n in ga if ga[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
     print("worst gradient rel L2", worst)
     assert worst[0] < 1e-2, worst

@@ -20,7 +20,10 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (200, 2304, 768), (160, 768, 3072), (37, 100, 64), (130, 3129, 768), (500, 768, 2056)])
+# shapes chosen to reach every tile configuration of the product's shape rule (gemm_nt.hip launch()):
+# 128x128 tiles (few tiles), 256x256 / BK 64 (default), 256x128 two workgroups per CU (narrow short-K with many tiles)
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (200, 2304, 768), (160, 768, 3072), (37, 100, 64), (130, 3129, 768), (500, 768, 2056),
+                                   (4200, 2304, 768), (5000, 3072, 136), (70000, 768, 768), (66000, 512, 520)])
 def test_gemm_nt_bias(dev, M, N, K):
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -28,138 +31,12 @@ def test_gemm_nt_bias(dev, M, N, K):
     b = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     ref = a.float() @ b.float().t() + bias
-    for cfg in ("p256", "s128", "t256k", "t256", "t256g", "w4", "w4g", None):  # every tile configuration + the default choice
-        if cfg is None:
-            hip.set_knob("MVPTR_GEMM_CFG", "")
-        else:
-            hip.set_knob("MVPTR_GEMM_CFG", cfg)
-        out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
-        err = _rel(out, ref)
-        print("gemm_nt bias", cfg, M, N, K, err)
-        assert err < 4e-3
-        out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
-        assert _rel(out32, ref) < 1e-5
-    hip.set_knob("MVPTR_GEMM_CFG", "")
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (300, 2304, 768), (777, 768, 3072), (37, 104, 64), (515, 1000, 136), (500, 768, 2056), (1030, 520, 40)])
-def test_gemm_nt_q_config(dev, M, N, K):
-    """The 256x256 / four-wave "Q" tile configuration: every epilogue, ragged M, N and K edges."""
-    from mvp_pytorch_amd import hip
-    g = torch.Generator(device="cpu").manual_seed(11)
-    a = _bf(torch.randn(M, K, generator=g)).to(dev)
-    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    aux = _bf(torch.randn(M, N, generator=g)).to(dev)
-    base = a.float() @ b.float().t()
-    hip.set_knob("MVPTR_GEMM_CFG", "q")
-    try:
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_F32, bias=bias), base + bias) < 1e-5
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias), base + bias) < 4e-3
-        dact, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
-        uref = (base + bias).requires_grad_(True)
-        aref = torch.nn.functional.gelu(uref)
-        aref.sum().backward()
-        assert _rel(act, aref.detach()) < 4e-3
-        assert _rel(dact, uref.grad) < 4e-3
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux), base + bias + aux.float()) < 4e-3
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_BIAS_TANH, bias=bias), torch.tanh(base + bias)) < 4e-3
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux), base + aux.float()) < 4e-3
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_ADD), base) < 4e-3
-        assert _rel(hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=aux), base * aux.float()) < 4e-3
-        drop = hip.make_dropout(0.1, 0x1234567890)
-        z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux, drop=drop)
-        keep = hip.dropout_mask(drop, M * N, dev).reshape(M, N).float()
-        scale = 65536.0 / (65536.0 - drop.thresh16)
-        assert _rel(z, (base + bias) * keep * scale + aux.float()) < 4e-3
-    finally:
-        hip.set_knob("MVPTR_GEMM_CFG", "")
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (300, 2304, 768), (777, 768, 3072), (500, 768, 2056), (70000, 512, 512), (1030, 520, 1000)])
-def test_gemm_nt_qp_config(dev, M, N, K):
-    """The persistent Q kernel with the deferred epilogue: same results as the default configuration
-    (bit-identical for EPI_BIAS), several tiles per workgroup (M = 70000: 548 tiles on 256 CUs)."""
-    from mvp_pytorch_amd import hip
-    g = torch.Generator(device="cpu").manual_seed(12)
-    a = _bf(torch.randn(M, K, generator=g)).to(dev)
-    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    ref = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
-    dref, aref = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
-    ref0 = hip.gemm_nt(a, b, hip.EPI_BIAS)
-    hip.set_knob("MVPTR_GEMM_CFG", "qp")
-    try:
-        out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
-        out0 = hip.gemm_nt(a, b, hip.EPI_BIAS)
-        dact, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
-    finally:
-        hip.set_knob("MVPTR_GEMM_CFG", "")
-    assert torch.equal(out, ref)
-    assert torch.equal(out0, ref0)
-    base = a[:2048].float() @ b.float().t() + bias
-    assert _rel(out[:2048], base) < 4e-3
-    # gelu of the bf16-rounded pre-activation: within bf16 rounding of the f32 path
-    assert _rel(act, aref) < 4e-3 and _rel(dact, dref) < 4e-3
-    assert _rel(act[:2048], torch.nn.functional.gelu(base)) < 6e-3
-
-
-@pytest.mark.parametrize("M,N,K", [(192, 768, 768), (300, 2304, 768), (777, 768, 3072), (500, 768, 2056), (70000, 512, 512), (1030, 520, 1000), (50, 3072, 768)])
-def test_gemm_nt_pd_config(dev, M, N, K):
-    """The persistent 8-wave kernel with the deferred epilogue ("pd"): EPI_BIAS bit-identical to the
-    default configuration, the other epilogues within bf16 rounding of it and of the f32 reference;
-    several tiles per workgroup (M = 70000), ragged M / N / K edges, dropout, column sums."""
-    from mvp_pytorch_amd import hip
-    g = torch.Generator(device="cpu").manual_seed(13)
-    a = _bf(torch.randn(M, K, generator=g)).to(dev)
-    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    aux = _bf(torch.randn(M, N, generator=g)).to(dev)
-    drop = hip.make_dropout(0.1, 0x1234567890)
-
-    def run_all():
-        vec = torch.zeros(N, device=dev)
-        r = dict(bias=hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias), nobias=hip.gemm_nt(a, b, hip.EPI_BIAS),
-                 gelu=hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias),
-                 resid=hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux),
-                 rdrop=hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux, drop=drop),
-                 tanh=hip.gemm_nt(a, b, hip.EPI_BIAS_TANH, bias=bias), add=hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux),
-                 add0=hip.gemm_nt(a, b, hip.EPI_ADD), gbwd=hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=aux, vec_out=vec))
-        r["vec"] = vec
-        return r
-
-    ref = run_all()
-    hip.set_knob("MVPTR_GEMM_CFG", "pd")
-    try:
-        out = run_all()
-    finally:
-        hip.set_knob("MVPTR_GEMM_CFG", "")
-    assert torch.equal(out["bias"], ref["bias"]) and torch.equal(out["nobias"], ref["nobias"])
-    assert torch.equal(out["add0"], ref["add0"])
-    for k in ("resid", "rdrop", "tanh", "add", "gbwd"):
-        assert _rel(out[k], ref[k]) < 4e-3, k
-    assert _rel(out["gelu"][0], ref["gelu"][0]) < 4e-3 and _rel(out["gelu"][1], ref["gelu"][1]) < 4e-3
-    assert _rel(out["vec"], ref["vec"]) < 2e-3
-    n_rows = min(M, 1024)
-    base = a[:n_rows].float() @ b.float().t()
-    assert _rel(out["resid"][:n_rows], base + bias + aux[:n_rows].float()) < 5e-3
-    assert _rel(out["gbwd"][:n_rows], base * aux[:n_rows].float()) < 5e-3
-    keep = hip.dropout_mask(drop, M * N, dev).reshape(M, N).float()[:n_rows]
-    scale = 65536.0 / (65536.0 - drop.thresh16)
-    assert _rel(out["rdrop"][:n_rows], (base + bias) * keep * scale + aux[:n_rows].float()) < 5e-3
-
-
-def test_gemm_nt_q_identity_layout(dev):
-    from mvp_pytorch_amd import hip
-    K = 128
-    a = torch.eye(K, dtype=torch.bfloat16, device=dev)
-    b = (torch.arange(192 * K, device=dev, dtype=torch.float32).reshape(192, K) % 251 - 125).to(torch.bfloat16)
-    hip.set_knob("MVPTR_GEMM_CFG", "q")
-    try:
-        out = hip.gemm_nt(a, b, hip.EPI_F32)
-    finally:
-        hip.set_knob("MVPTR_GEMM_CFG", "")
-    assert torch.equal(out, b.float().t().contiguous())
+    out = hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias)
+    err = _rel(out, ref)
+    print("gemm_nt bias", M, N, K, err)
+    assert err < 4e-3
+    out32 = hip.gemm_nt(a, b, hip.EPI_F32, bias=bias)
+    assert _rel(out32, ref) < 1e-5
 
 
 def test_gemm_nt_identity_layout(dev):
@@ -221,8 +98,10 @@ def test_gemm_nt_dropout_matches_mask(dev):
     assert abs(frac - 0.1) < 0.01
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 256, 3072), (333, 2304, 768), (64, 128, 128), (515, 1000, 136)])
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 256, 3072), (333, 2304, 768), (64, 128, 128), (515, 1000, 136),
+                                   (6400, 2304, 768), (7000, 1000, 136), (20000, 768, 3072)])
 def test_gemm_tn(dev, M, N, K):
+    """Below 6 000 token rows the planner picks a 256x128-tile configuration, from there on the 256x256 "Q" kernel."""
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(4)
     ldn = (N + 7) // 8 * 8
@@ -230,30 +109,24 @@ def test_gemm_tn(dev, M, N, K):
     dy[:, :N] = _bf(torch.randn(M, N, generator=g))
     dy = dy.to(dev)
     x = _bf(torch.randn(M, K, generator=g)).to(dev)
-    for cfg in ("32", "64", "k2", "K", "q", "o", None):  # every tile configuration + the planner's own choice
-        if cfg is None:
-            hip.set_knob("MVPTR_GEMM_TN", "")
-        else:
-            hip.set_knob("MVPTR_GEMM_TN", cfg)
-        dw = torch.zeros(N, K, device=dev)
-        cs = torch.zeros(N, device=dev)
-        hip.gemm_tn(dy, x, dw, n=N, colsum=cs)
-        ref = dy[:, :N].float().t() @ x.float()
-        err = _rel(dw, ref)
-        print("gemm_tn", cfg, M, N, K, err)
-        assert err < 1e-5
-        assert _rel(cs, dy[:, :N].float().sum(0)) < 1e-5
-        hip.gemm_tn(dy, x, dw, n=N)  # accumulates
-        assert _rel(dw, 2 * ref) < 1e-5
-    hip.set_knob("MVPTR_GEMM_TN", "")
+    dw = torch.zeros(N, K, device=dev)
+    cs = torch.zeros(N, device=dev)
+    hip.gemm_tn(dy, x, dw, n=N, colsum=cs)
+    ref = dy[:, :N].float().t() @ x.float()
+    err = _rel(dw, ref)
+    print("gemm_tn", M, N, K, err)
+    assert err < 1e-5
+    assert _rel(cs, dy[:, :N].float().sum(0)) < 1e-5
+    hip.gemm_tn(dy, x, dw, n=N)  # accumulates
+    assert _rel(dw, 2 * ref) < 1e-5
 
 
-def test_gemm_tn_multi(dev):
+@pytest.mark.parametrize("M", [700, 6400])
+def test_gemm_tn_multi(dev, M):
     """Grouped launch: four problems sharing M (an encoder layer's weight gradients) and one with a
     different M (split into its own launch) give the same results as separate calls."""
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(14)
-    M = 700
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
     probs, refs = [], []
     for N, K in shapes:
@@ -268,59 +141,11 @@ def test_gemm_tn_multi(dev):
     dw5 = torch.zeros(104, 72, device=dev)
     probs.append((dy5, x5, dw5, None))
     refs.append(dy5.float().t() @ x5.float())
-    for cfg in ("32", "K", "q", "o", None):
-        if cfg is None:
-            hip.set_knob("MVPTR_GEMM_TN", "")
-        else:
-            hip.set_knob("MVPTR_GEMM_TN", cfg)
-        for _, _, dw, cs in probs:
-            dw.zero_()
-            if cs is not None:
-                cs.zero_()
-        hip.gemm_tn_multi(probs)
-        for (dy, x, dw, cs), ref in zip(probs, refs):
-            assert _rel(dw, ref) < 1e-5
-            if cs is not None:
-                assert _rel(cs, dy.float().sum(0)) < 1e-5
-    hip.set_knob("MVPTR_GEMM_TN", "")
-
-
-def test_gemm_tn_slab_reduce(dev):
-    """'Q' write-out through per-split slabs + the reduce kernel: accumulates onto what dW holds, equals
-    the atomic write-out up to summation order, and is bitwise reproducible (fixed split order)."""
-    from mvp_pytorch_amd import hip
-    g = torch.Generator(device="cpu").manual_seed(41)
-    M = 6400
-    shapes = [(2304, 768), (1000, 136), (768, 3072)]      # whole tiles, ragged edges, wide K
-    probs = []
-    for N, K in shapes:
-        probs.append((_bf(torch.randn(M, N, generator=g)).to(dev), _bf(torch.randn(M, K, generator=g)).to(dev), N, K))
-
-    def run(slab):
-        hip.set_knob("MVPTR_TN_SLAB", slab)
-        outs = []
-        try:
-            dws = [torch.full((N, K), 0.5, device=dev) for _, _, N, K in probs]
-            css = [torch.zeros(N, device=dev) for _, _, N, K in probs]
-            hip.gemm_tn_multi([(dy, x, dw, cs) for (dy, x, N, K), dw, cs in zip(probs, dws, css)])
-            outs = dws + css
-        finally:
-            hip.set_knob("MVPTR_TN_SLAB", "0")
-        return outs
-
-    for cfg in ("q", "o"):
-        hip.set_knob("MVPTR_GEMM_TN", cfg)
-        try:
-            a1, a2, b = run("1"), run("1"), run("0")
-        finally:
-            hip.set_knob("MVPTR_GEMM_TN", "")
-        for (dy, x, N, K), s1, s2, at in zip(probs, a1[:3], a2[:3], b[:3]):
-            ref = 0.5 + dy.float().t() @ x.float()
-            assert torch.equal(s1, s2)
-            assert _rel(s1, ref) < 1e-4 and _rel(at, ref) < 1e-4
-            assert (s1 - at).abs().max() < 1e-3 * ref.abs().max()
-        for (dy, x, N, K), c1 in zip(probs, a1[3:]):
-            assert _rel(c1, dy.float().sum(0)) < 1e-4
+    hip.gemm_tn_multi(probs)
+    for (dy, x, dw, cs), ref in zip(probs, refs):
+        assert _rel(dw, ref) < 1e-5
+        if cs is not None:
+            assert _rel(cs, dy.float().sum(0)) < 1e-5
 
 
 def test_gemm_tn_layout_exact(dev):
@@ -782,6 +607,10 @@ def test_gather_and_scatter_add_rows(dev):
         if d >= 0:
             want[d] += 2 * upd[i]
     assert torch.equal(dst.float(), want)
+    dst32 = torch.zeros(50, 128, device=dev)
+    hip.scatter_add_rows(upd.to(torch.bfloat16), idx, dst32)
+    hip.scatter_add_rows(upd, idx, dst32)
+    assert torch.equal(dst32, want)
 
 
 def test_pack_maps_against_host_walk(dev):

@@ -4,6 +4,7 @@ library: s_memtime / s_memrealtime around the loop, after >= 2 s of back-to-back
 data; MI355X_MICROARCH.md DVFS give-back item 6).  One stage = 64 v_mfma_f32_16x16x32_bf16 per wave =
 1024 MFMA cycles."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 import time
 

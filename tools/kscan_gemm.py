@@ -2,6 +2,7 @@
 """gemm_nt time as a function of K at fixed M, N: the intercept of the linear fit is the per-launch
 cost that does not scale with the MFMA loop (pipeline fill + epilogue), the slope the loop rate."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import numpy as np

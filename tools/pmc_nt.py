@@ -2,6 +2,7 @@
 """One launch per gemm_nt configuration and shape for rocprofv3 --pmc passes (L2 hit rate, traffic):
     rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d DIR -- python3 tools/pmc_nt.py [cfgs]"""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

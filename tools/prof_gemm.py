@@ -2,6 +2,7 @@
 """A few launches of each GEMM shape of the step, for rocprofv3 --pmc runs (counter collection
 replays kernels, so keep it short)."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

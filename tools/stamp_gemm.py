@@ -4,6 +4,7 @@
 build fences overlaps the real kernel has: read its SHARES, not its run time."""
 import ctypes
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

@@ -2,6 +2,7 @@
 """Time every gemm_nt tile configuration (MVPTR_GEMM_CFG) at the shapes of a configs[1] step and
 check each against the default configuration's output.  Run on the GPU box."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch
@@ -13,7 +14,23 @@ dev = torch.device("cuda:0")
 CFGS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["w4", "w4g", "t256", "t256g", "t256k"]
 
 
+COLD = os.environ.get("SWEEP_COLD") == "1"   # every timed launch behind a 768-MB write: operands come from HBM as inside the training step
+_flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev) if COLD else None
+
+
 def timeit(fn, reps=20):
+    if COLD:
+        tot = 0.0
+        for i in range(8):
+            _flush.fill_(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                tot += e0.elapsed_time(e1)
+        return tot / 6 * 1e3
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

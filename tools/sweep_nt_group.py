@@ -3,6 +3,7 @@
 encoder step; under rocprofv3 --pmc FETCH_SIZE the same launches give the bytes fetched beyond L2:
     sweep_nt_group.py [M] [gm,gn;gm,gn;...]"""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

@@ -2,6 +2,7 @@
 """Time the gemm_tn configurations (MVPTR_GEMM_TN) at the weight-gradient shapes of a step and check
 each against an f32 reference."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

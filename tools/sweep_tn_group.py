@@ -2,6 +2,7 @@
 """Grouped weight-gradient launches (FFN pair, attention pair of an encoder layer) per gemm_tn
 configuration and forced M-split count: tools/sweep_tn_group.py [cfgs] [splits]."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import torch

@@ -3,6 +3,7 @@
 after the staging barrier, when the last wave is done): where a (sequence, head) workgroup spends its time, by
 sequence length, for the row-packed joint pass of the timed batch."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import numpy as np

@@ -5,6 +5,7 @@ Prints, per 2-us bin, how many workgroups are in their loop and how many in thei
 per-workgroup phase durations.  Answers: do the workgroups run their epilogues (HBM bursts) in
 lockstep?"""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import numpy as np

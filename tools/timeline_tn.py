@@ -2,6 +2,7 @@
 """Diagnostic: wall-clock timeline of the gemm_tn workgroups (loop vs atomic write-out), from the
 -DMVPTR_TIMELINE_BUILD library."""
 import os
+os.environ.setdefault("MVPTR_LIB", "diag")   # kernel-configuration knobs live in the diagnostic build only (make -C mvp_pytorch_amd/csrc diag)
 import sys
 
 import numpy as np
