@@ -105,7 +105,9 @@ def _best_threads(which, seconds_budget):
     timeout): a candidate that does not finish is reported, not waited for."""
     import subprocess
     total = os.cpu_count() or 1
-    cands = [total] + ([32] if total > 32 else [])
+    # a B=4 fp32 step stops scaling far below the core count of a GPU host (256 threads: > 90 s per step, timed out in
+    # round 2 and cost 4 of the driver's 5 minutes): candidates are capped at 64 threads, host_cores is reported beside
+    cands = sorted({min(total, 64), min(total, 32)}, reverse=True)
     best, notes = None, []
     for c in cands:
         budget = seconds_budget / len(cands)
@@ -238,15 +240,12 @@ class DominantMix:
         self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.bfloat16),
                     torch.empty(M, I, device=dev, dtype=torch.bfloat16), 2.0 * M * I * H) for M in self.Ms]
 
-    def run_tn(self):
-        for probs, _ in self.tn:
-            self.hip.gemm_tn_multi(probs)
-        return len(self.tn), sum(f for _, f in self.tn)
+    def tn_launches(self):
+        return [((lambda probs=probs: self.hip.gemm_tn_multi(probs)), f) for probs, f in self.tn]
 
-    def run_nt(self):
-        for x, u, a, _ in self.nt:
-            self.hip.gemm_nt(x, self.w, self.hip.EPI_BIAS_GELU, bias=self.bias, out=u, out1=a)
-        return len(self.nt), sum(f for _, _, _, f in self.nt)
+    def nt_launches(self):
+        return [((lambda x=x, u=u, a=a: self.hip.gemm_nt(x, self.w, self.hip.EPI_BIAS_GELU, bias=self.bias, out=u, out1=a)), f)
+                for x, u, a, f in self.nt]
 
     # algorithmic HBM bytes per launch (mean over the mix): operands read once, output written /
     # accumulated once
@@ -263,27 +262,48 @@ class DominantMix:
         return sum(2.0 * M * H + 2.0 * I * H + 2 * 2.0 * M * I for M in self.Ms) / len(self.Ms)
 
 
-def _time_launches(fn, reps):
-    fn()
+def _time_launches(launches, reps, cold):
+    """Mean duration and FLOPs per launch of a launch mix, HIP events on the launch stream.  cold: every launch runs
+    behind a 768-MB write (its operands come from HBM, as inside the training step where they were produced several
+    kernels earlier — the same launch repeated back to back re-reads them from the 256-MB Infinity Cache and runs
+    15-30 % faster, profiles/r02_experiments.txt); the events bracket the launch alone."""
+    flush = torch.empty(768 << 20, dtype=torch.uint8, device="cuda") if cold else None
+    for fn, _ in launches:
+        fn()
     torch.cuda.synchronize()
+    ms, n, flops = 0.0, 0, 0.0
+    if cold:
+        for r in range(reps):
+            for fn, f in launches:
+                flush.fill_(r)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms += e0.elapsed_time(e1)
+                n += 1
+                flops += f
+        return ms / n, flops / n
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n, flops = 0, 0.0
     e0.record()  # the kernels are launched on torch's current stream: the events see them
     for _ in range(reps):
-        k, f = fn()
-        n += k
-        flops += f
+        for fn, f in launches:
+            fn()
+            n += 1
+            flops += f
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    return ms / n, flops / n
+    return e0.elapsed_time(e1) / n, flops / n
 
 
 def _pmc_traffic(kernel, packed=True):
     """HBM bytes per launch from the committed PMC passes (profiles/r02_dominant_traffic.json, made
     by tools/runs/r02_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
     WRITE_SIZE, FETCH_SIZE calibrated on a known 1-GiB stream by tools/calib_fetch.py), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_dominant_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
@@ -297,8 +317,10 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     counts of the timed batch), timed with HIP events on the launch stream; the FFN1 forward GEMM
     (second by time) rides along."""
     mix = DominantMix(dev, dims, cfg, batch, single)
-    tn_ms, tn_flops = _time_launches(mix.run_tn, 4)
-    nt_ms, nt_flops = _time_launches(mix.run_nt, 4)
+    tn_ms, tn_flops = _time_launches(mix.tn_launches(), 3, cold=True)       # as inside the step: operands from HBM
+    nt_ms, nt_flops = _time_launches(mix.nt_launches(), 3, cold=True)
+    tn_hot_ms, _ = _time_launches(mix.tn_launches(), 4, cold=False)          # repeated back to back: Infinity-Cache resident
+    nt_hot_ms, _ = _time_launches(mix.nt_launches(), 4, cold=False)
     tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
     nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
     t_tn, t_nt = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_q_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>"))
@@ -306,14 +328,17 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                                      "attention pair per layer; 256x256 tiles, four waves of 128x128; M = %s rows)" % " / ".join(str(m) for m in mix.Ms),
                 achieved=round(tn_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
-                flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
+                timing="each launch behind a 768-MB write (operands from HBM, as inside the step); back to back (Infinity-Cache "
+                       "resident operands): avg_launch_us_back_to_back",
+                avg_launch_us_back_to_back=round(tn_hot_ms * 1e3, 1), flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
                 traffic=(t_tn or {}).get("bytes_per_launch"),
-                traffic_source="profiles/r02_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                traffic_source="profiles/r03_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
                                "tools/prof_dominant.py; FETCH_SIZE divided by the factor measured on a known 1-GiB LDS-DMA stream, "
                                "tools/calib_fetch.py)",
                 second_kernel=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu and gelu')",
                                    achieved=round(nt_ach, 1), frac=round(nt_ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                                   avg_launch_us=round(nt_ms * 1e3, 1), algorithmic_bytes_per_launch=round(mix.nt_bytes()),
+                                   avg_launch_us=round(nt_ms * 1e3, 1), avg_launch_us_back_to_back=round(nt_hot_ms * 1e3, 1),
+                                   algorithmic_bytes_per_launch=round(mix.nt_bytes()),
                                    traffic=(t_nt or {}).get("bytes_per_launch")))
 
 
@@ -407,6 +432,9 @@ def main():
     ap.add_argument("--fixed-length", action="store_true", help="every token/region slot valid is the timed workload")
     ap.add_argument("--no-extras", action="store_true",
                     help="timed steps only (no all-slots-valid leg, kernel replay or CPU baseline): the command profiles/ are made from")
+    ap.add_argument("--with-input-pipeline", action="store_true",
+                    help="extra leg: every step's batch comes from pinned host memory through input_pipeline.PretrainBatchStager "
+                         "(double-buffered H2D on a copy stream, bf16 K-padded features): the PCIe-inclusive rate")
     ap.add_argument("--model", choices=["bi", "single"], default="bi",
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
     ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
@@ -523,6 +551,35 @@ def main():
                 "step_achieved": round(full_tf, 1), "step_frac": round(full_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                 "note": "every one of the 70+5 / 20 / 50 slots valid: nothing to skip; same fences and step count as the headline"}
 
+    # PCIe-inclusive rate (never `value`): the same batch staged from pinned host tensors every step, as a
+    # DataLoader(pin_memory=True) would hand it over; the stager's copy stream overlaps the copy of batch i+1 with step i
+    piped = None
+    if args.with_input_pipeline and not single:
+        from mvp_pytorch_amd.input_pipeline import PretrainBatchStager, INT_FIELDS
+        host = {k: v.cpu().pin_memory() for k, v in batch.items() if k in INT_FIELDS or k == "img_feats"}
+        stager = PretrainBatchStager(dev, args.batch, dims, cfg["img_feature_dim"], depth=2, features="both")
+
+        def piped_steps(n):
+            stager.put_collated(host)
+            for i in range(n):
+                b = stager.get()
+                b = {k: v for k, v in b.items() if k != "img_feats"}      # the model takes the bf16 operand
+                train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+                stager.release()
+                if i + 1 < n:
+                    stager.put_collated(host)
+
+        piped_steps(2)
+        fence()
+        t0 = time.perf_counter()
+        piped_steps(args.steps)
+        fence()
+        pms = (time.perf_counter() - t0) / args.steps * 1e3
+        piped = {"ms_per_step": round(pms, 2), "value": round(world * args.batch / (pms * 1e-3), 1), "steps": args.steps,
+                 "h2d_bytes_per_step": int(sum(v.numel() * v.element_size() for v in host.values())),
+                 "note": "batch staged from pinned host memory each step (f32 features, H2D on a copy stream overlapped with the "
+                         "previous step, f32 -> K-padded bf16 on the copy stream); PCIe-inclusive, not the headline"}
+
     if rank == 0:
         fwd, fb = flops_per_pair(dims, cfg, n_text / args.batch, n_tag / args.batch, single)
         if args.fixed_length:
@@ -553,7 +610,7 @@ def main():
                        "lengths": "fixed (all slots valid)" if args.fixed_length else
                                   "variable (SURVEY 8d: tokens U{8..68}, phrases U{0..5}, tags U{3..18}, regions U{10..50})",
                        "valid_slot_fraction": valid, "padded_slots_computed": False,
-                       "all_slots_valid": full},
+                       "all_slots_valid": full, "with_input_pipeline": piped},
             "roofline": roof,
         }
         if world == 1 and not args.no_extras and not single:

@@ -44,7 +44,7 @@ void mvptr_set_error(const char* fmt, ...);
 struct MvptrKnobs {
   char gemm_cfg[16];   // MVPTR_GEMM_CFG   force a gemm_nt tile configuration ("t256k" | "w4" | "s128")
   char gemm_tn[16];    // MVPTR_GEMM_TN    force a gemm_tn configuration ("32" | "64" | "k2" | "K" | "q")
-  int nt_exp;          // MVPTR_NT_EXP     experiment flags (bit 5: n-major tile order of gemm_tn; bit 9: non-temporal gelu' stores)
+  int nt_exp;          // MVPTR_NT_EXP     experiment flags (bit 5: n-major tile order of gemm_tn; bit 9: plain instead of non-temporal gelu' stores)
   int tn_group;        // MVPTR_TN_GROUP   0: one launch per weight-gradient problem
   int ln_grid;         // MVPTR_LN_GRID    partial rows of the LayerNorm backward pass (0 = default)
   int tn_splits;       // MVPTR_TN_SPLITS  force the M-split count of the weight-gradient launches (0 = planner)

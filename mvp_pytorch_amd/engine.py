@@ -644,13 +644,19 @@ class InputEmbedFn(GradAwareFunction):
         ctx.txt = (idf, tyf, pof, z, mean, rstd, lnw, drop_t)
         ctx.img = None
         if R > 0:
-            D = img_feats.shape[2]
+            D = img_w.shape[1]
             Dp = pad8(D)
-            feats = img_feats.reshape(B * R, D)
-            if feats.dtype != torch.float32:
-                feats = feats.float()
-            fb = torch.empty((B * R, Dp), device=dev, dtype=torch.bfloat16)
-            hip.cast_pack(feats.contiguous(), dst=fb)
+            if img_feats.dtype == torch.bfloat16 and img_feats.shape[2] == Dp and Dp != D and img_feats.is_contiguous():
+                # already the K-padded bf16 GEMM operand (input_pipeline.PretrainBatchStager, features="bf16"): no cast pass
+                fb = img_feats.view(B * R, Dp)
+            else:
+                if img_feats.shape[2] != D:
+                    raise RuntimeError("img_feats has %d columns, img_embedding expects %d" % (img_feats.shape[2], D))
+                feats = img_feats.reshape(B * R, D)
+                if feats.dtype != torch.float32:
+                    feats = feats.float()
+                fb = torch.empty((B * R, Dp), device=dev, dtype=torch.bfloat16)
+                hip.cast_pack(feats.contiguous(), dst=fb)
             cache = meta["cache"]
             cache = cache.for_device(img_w.device)
             w_img, _ = cache.weight_copies(img_w, want_t=False)

@@ -165,6 +165,28 @@ class PretrainBatchStager:
             s.ready.record(self.copy_stream)
         s.decoded, s.staged = False, True
 
+    def put_collated(self, batch):
+        """batch: dict of COLLATED host tensors as `DataLoader(collate_fn=default, pin_memory=True)` yields them —
+        img_feats f32 [B, R, D] and the integer fields [B, width] — the reference's own loader output
+        (run_pretrain_ml.py:474-513 moves each with .to(device)).  The copies are issued straight from the given
+        (pinned) tensors on the copy stream; with features "bf16" / "both" the K-padded bf16 operand of the
+        region-embedding GEMM is produced there too (mvptr_cast_pack), off the step's critical path, and the model
+        takes it instead of casting the f32 features itself."""
+        s = self._slot_for_put()
+        if s.feat_d is None:
+            s.feat_d = torch.empty(self.B, self.R, self.D, dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(self.copy_stream):
+            self._begin_device_work(s)
+            s.feat_d.copy_(batch["img_feats"], non_blocking=True)
+            for k in INT_FIELDS:
+                if k in batch:
+                    o, w = self.int_off[k], self.widths[k]
+                    s.ints_d[:, o:o + w].copy_(batch[k].reshape(self.B, w), non_blocking=True)
+            if s.bf16_d is not None:
+                hip.cast_pack(s.feat_d.view(self.B * self.R, self.D), dst=s.bf16_d)
+            s.ready.record(self.copy_stream)
+        s.decoded, s.staged, s.have_bf16 = False, True, s.bf16_d is not None
+
     # ------------------------------------------------------------------ device side
     def get(self, check=False):
         """The oldest staged batch as the dict `train.model_inputs` takes.  The current stream waits
@@ -188,7 +210,7 @@ class PretrainBatchStager:
             batch[k] = v.reshape(-1) if k in ("is_next", "is_img_match") else v
         if s.feat_d is not None:
             batch["img_feats"] = s.feat_d
-        if s.bf16_d is not None and s.decoded:
+        if s.bf16_d is not None and (s.decoded or getattr(s, "have_bf16", False)):
             batch["img_feats_bf16"] = s.bf16_d
         s.in_use = True
         self._pending = s

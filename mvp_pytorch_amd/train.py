@@ -21,12 +21,17 @@ def model_inputs(batch, max_tag_length):
     """batch (13 tensors of OscarTSVDataset_C, oscar_tsv4.py:363-377) -> model kwargs
     (run_pretrain_ml.py:528-531); a single-stream batch (input_ids / input_mask / ...) maps to
     BertImgForPreTraining's arguments (run_pretrain_ml.py:533 positional order)."""
+    feats = batch.get("img_feats")
+    if "img_feats_bf16" in batch:
+        # K-padded bf16 operand produced by the input pipeline (input_pipeline.PretrainBatchStager): the model skips its cast
+        fb = batch["img_feats_bf16"]
+        feats = fb.view(batch["input_ids_b" if "input_ids_b" in batch else "input_ids"].shape[0], -1, fb.shape[-1])
     if "input_ids" in batch:
         return dict(input_ids=batch["input_ids"], token_type_ids=batch["segment_ids"], attention_mask=batch["input_mask"],
-                    masked_lm_labels=batch["lm_label_ids"], next_sentence_label=batch["is_next"], img_feats=batch["img_feats"])
+                    masked_lm_labels=batch["lm_label_ids"], next_sentence_label=batch["is_next"], img_feats=feats)
     return dict(input_ids_a=batch["input_ids_a"], token_type_ids_a=batch["segment_ids_a"],
                 attention_mask_a=batch["input_mask_a"], masked_lm_labels_a=batch["lm_label_ids_a"],
-                input_ids_b=batch["input_ids_b"], img_feats=batch["img_feats"],
+                input_ids_b=batch["input_ids_b"], img_feats=feats,
                 token_type_ids_b=batch["segment_ids_b"], attention_mask_b=batch["input_mask_b"],
                 masked_lm_labels_b=batch["lm_label_ids_b"], phrase_index=batch.get("phrase_index"),
                 img_index=batch.get("image_index"), max_tag_length=max_tag_length)

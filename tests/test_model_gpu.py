@@ -31,6 +31,23 @@ LOSS_RTOL = 1e-3
 CLIP_BRANCH = ("bert.txt_proj", "bert.vis_proj", "logit_scale")
 SMALL_ROWS_RTOL = 3e-3  # retrieval / ITM losses at B=4 (see module docstring)
 
+# Per-element quantities (logits, gradient norms) cannot meet 1e-3 in bf16 (every rounding of a GEMM operand adds ~1.1e-3
+# relative error, a 12-layer stack has ~60 of them): each is bounded by TWICE the value measured on MI355X in round 3
+# (gpurun_out/r03f/parity_values.txt, r03g), not by a blanket tolerance.  relative L2 unless stated.
+MEASURED = {
+    "tiny_single_pretrain:prediction_scores": 0.0083, "tiny_single_pretrain:seq_relationship": 0.0241,
+    "cfg1_single_pretrain:prediction_scores": 0.0118, "cfg1_single_pretrain:seq_relationship": 0.0079,
+    "tiny_bi_pretrain:gnorm": 0.0272, "cfg1_bi_pretrain:gnorm": 0.0229, "tiny_bi_hn:gnorm": 0.0366,
+    "tiny_bi_pretrain:grad": 0.0191, "cfg1_bi_pretrain:grad": 0.0191,
+}
+
+
+def check_measured(tag, value, fallback):
+    """value < 2 x the round-3 measurement of `tag` (fallback bound for a tag measured for the first time)."""
+    bound = 2.0 * MEASURED[tag] if tag in MEASURED else fallback
+    print("PARITY %s %.5f (bound %.5f)" % (tag, value, bound))
+    assert value < bound, (tag, value, bound)
+
 
 class Replay:
     """Feed recorded reference draws to the product's torch.randperm / torch.randint / random.choice."""
@@ -122,19 +139,22 @@ def test_bi_pretrain_parity(dev, name):
     same_t = np.array_equal(hard[0].cpu().numpy(), d["hard_txt_index"])
     same_i = np.array_equal(hard[1].cpu().numpy(), d["hard_img_index"])
     print(name, "hard indices equal:", same_t, same_i)
-    if name == "tiny_bi_hn":
-        # the hard-negative fixture: every f32 top-2 margin is >= 10x the bf16 error of sim_mat, so the
-        # integer outputs of vl:531-566 must be bit-exact, unconditionally
+    free_running = name in ("tiny_bi_hn", "cfg1_bi_pretrain")
+    if free_running:
+        # the hard-negative fixture and the BERT-base fixture (input batch chosen among 950 seeds for its margin,
+        # tools/gen_golden.py): every f32 top-2 margin is >= 10x the bf16 error of sim_mat, so the integer outputs
+        # of vl:531-566 must be bit-exact, unconditionally
         assert float(d["argmax_margin"]) > 10 * sim_err, (float(d["argmax_margin"]), sim_err)
         assert same_t and same_i
     elif float(d["argmax_margin"]) > 4 * sim_err:
         assert same_t and same_i
     # 2) losses + gradients with the reference's captured draws; the hard batch is the reference's
-    #    (free-running on the hard-negative fixture: nothing injected there)
+    #    (free-running — nothing injected — on the hard-negative fixture and on the BERT-base fixture: the model mines
+    #    its own hard negatives from its own bf16 sim_mat and must land on the reference's losses)
     n = sim_ref.shape[0]
     masked = sim_ref - 2 * torch.eye(n)
     import contextlib
-    inject = contextlib.nullcontext() if name == "tiny_bi_hn" else gu.InjectHard(model.bert, masked.max(1)[1], masked.max(0)[1])
+    inject = contextlib.nullcontext() if free_running else gu.InjectHard(model.bert, masked.max(1)[1], masked.max(0)[1])
     with Replay(d, dev), inject:
         res = model(masked_lm_labels_a=t("lm_label_ids_a"), masked_lm_labels_b=t("lm_label_ids_b"),
                     max_tag_length=dims["G"], img_index=t("image_index"), phrase_index=t("phrase_index"), **kw)
@@ -169,7 +189,7 @@ def test_bi_pretrain_parity(dev, name):
             if pname in CLIP_BRANCH and name.startswith("tiny"):
                 print("   (ill-conditioned, reported only) grad-norm", pname, e)
             else:
-                assert e < (1e-1 if pname in CLIP_BRANCH else 5e-2), (pname, gn, rn)
+                assert e < (1e-1 if pname in CLIP_BRANCH else 2.0 * MEASURED.get(name + ":gnorm", 2.5e-2)), (pname, gn, rn)
         else:
             # analytically zero gradient (key bias: softmax is invariant to it); the reference holds
             # f32 rounding noise there, the bf16 path bf16 rounding noise: absolute bound only
@@ -182,7 +202,7 @@ def test_bi_pretrain_parity(dev, name):
             e = _rel(p.grad, torch.from_numpy(d[full]))
             print("   grad", pname, "rel L2", e)
             if not (pname in CLIP_BRANCH and name.startswith("tiny")):
-                assert e < (1e-1 if pname in CLIP_BRANCH else 3e-2) or pname == "logit_scale", (pname, e)
+                assert e < (1e-1 if pname in CLIP_BRANCH else 2.0 * MEASURED.get(name + ":grad", 1.5e-2)) or pname == "logit_scale", (pname, e)
     print(name, "worst grad-norm error", worst)
 
 
@@ -203,13 +223,15 @@ def test_single_pretrain_parity(dev, name):
     e = _rel(out[1][..., :64], torch.from_numpy(d["prediction_scores_head"]))
     e2 = _rel(out[2], torch.from_numpy(d["seq_relationship_score"]))
     print(name, "prediction_scores rel L2", e, "seq_relationship rel L2", e2)
-    assert e < 2e-2 and e2 < 5e-2  # 4x2 ITM logits of small magnitude
+    check_measured(name + ":prediction_scores", e, 2e-2)
+    check_measured(name + ":seq_relationship", e2, 5e-2)      # 4x2 ITM logits of small magnitude
     out[0].backward()
+    worst = 0.0
     for pname, p in model.named_parameters():
         key = "gnorm:" + pname
         if key in d and float(d[key]) > 1e-6 and p.grad is not None:
-            err = abs(p.grad.double().norm().item() - float(d[key])) / float(d[key])
-            assert err < 5e-2, (pname, err)
+            worst = max(worst, abs(p.grad.double().norm().item() - float(d[key])) / float(d[key]))
+    check_measured(name + ":gnorm", worst, 5e-2)
 
 
 @pytest.mark.parametrize("name", ["tiny_single_pretrain", "cfg1_single_pretrain"])
@@ -231,11 +253,12 @@ def test_single_pretrain_loss_only_path(dev, name):
     assert rel.max() < LOSS_RTOL
     assert out[1].shape[0] == 0
     out[0].backward()
+    worst = 0.0
     for pname, p in model.named_parameters():
         key = "gnorm:" + pname
         if key in d and float(d[key]) > 1e-6 and p.grad is not None:
-            err = abs(p.grad.double().norm().item() - float(d[key])) / float(d[key])
-            assert err < 5e-2, (pname, err)
+            worst = max(worst, abs(p.grad.double().norm().item() - float(d[key])) / float(d[key]))
+    check_measured(name + ":gnorm_loss_only", worst, 5e-2)
 
 
 def test_finetune_parity(dev):
@@ -252,7 +275,7 @@ def test_finetune_parity(dev):
     model.forward_mod = "fine"
     with torch.no_grad():
         fine = model(max_tag_length=dims["G"], **kw)
-    assert _rel(fine, torch.from_numpy(d["ret_fine_logits"])) < 2e-2
+    check_measured("tiny_finetune:ret_fine_logits", _rel(fine, torch.from_numpy(d["ret_fine_logits"])), 2e-2)
     sim_ref = torch.from_numpy(d["ret_global_txt"]) @ torch.from_numpy(d["ret_global_img"]).t()
     masked = sim_ref - 2 * torch.eye(sim_ref.shape[0])
     model.forward_mod = "train"
@@ -268,14 +291,14 @@ def test_finetune_parity(dev):
     model, _ = _build("BiImageBertForVQA", cv, seed + 2, dev)
     o = model(labels=torch.from_numpy(d["vqa_labels"]).to(dev), **kw)
     assert abs(o[0].item() - float(d["vqa_loss"])) / float(d["vqa_loss"]) < LOSS_RTOL
-    assert _rel(o[1], torch.from_numpy(d["vqa_logits"])) < 2e-2
+    check_measured("tiny_finetune:vqa_logits", _rel(o[1], torch.from_numpy(d["vqa_logits"])), 2e-2)
     o[0].backward()
     # VE
     ce_ = dict(cfg, loss_type="ce", num_labels=3, classifier="linear")
     model, _ = _build("BiImageBertForSequenceClassification", ce_, seed + 3, dev)
     o = model(labels=torch.from_numpy(d["ve_labels"]).to(dev), **kw)
     assert abs(o[0].item() - float(d["ve_loss"])) / float(d["ve_loss"]) < LOSS_RTOL
-    assert _rel(o[1], torch.from_numpy(d["ve_logits"])) < 2e-2
+    check_measured("tiny_finetune:ve_logits", _rel(o[1], torch.from_numpy(d["ve_logits"])), 2e-2)
 
 
 def test_data_parallel_replicas_match_single_module(dev):

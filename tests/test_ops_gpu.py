@@ -377,6 +377,15 @@ def test_cast_pack(dev):
     assert torch.equal(dst_t[:, 100:170], src.to(torch.bfloat16).t())
     assert torch.all(dst_t[:, :100] == 0) and torch.all(dst_t[:, 170:] == 0)
     assert torch.equal(hip.cast_f32(dst, cols=2054), src.to(torch.bfloat16).float())
+    # row-major only (the region features): vectorised row cast, pad columns zeroed, odd column counts, unaligned rows
+    for cols in (2054, 2053, 2049):
+        d2 = torch.full((70, 2056), 7.0, dtype=torch.bfloat16, device=dev)
+        hip.cast_pack(src[:, :cols], dst=d2)
+        assert torch.equal(d2[:, :cols], src[:, :cols].to(torch.bfloat16)) and torch.all(d2[:, cols:] == 0)
+    odd = torch.randn(33, 2055, generator=g).to(dev)          # 4-byte-aligned rows only
+    d3 = torch.full((33, 2056), 7.0, dtype=torch.bfloat16, device=dev)
+    hip.cast_pack(odd, dst=d3)
+    assert torch.equal(d3[:, :2055], odd.to(torch.bfloat16)) and torch.all(d3[:, 2055:] == 0)
 
 
 def test_cross_entropy(dev):

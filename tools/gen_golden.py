@@ -490,7 +490,10 @@ if __name__ == "__main__":
     if want("tiny_finetune"):
         gen_finetune("tiny_finetune", gu.TINY_CFG, gu.TINY_FT_DIMS, 1236)
     if want("cfg1_bi_pretrain"):
-        s2 = pick_seed(gu.BASE_CFG, gu.CFG1_DIMS, list(range(4321, 4321 + 10)))
+        # input seed 9810 = the largest f32 top-2 margin of sim_mat (0.0118) among 950 candidate batches (seeds 4321-4330 and
+        # 9000-9819, searched once with pick_seed): >= 10x the bf16 error of the kernels' sim_mat, so the BERT-base
+        # hard-negative indices (vl:531-566) are asserted bit-exact, unconditionally
+        s2 = pick_seed(gu.BASE_CFG, gu.CFG1_DIMS, [9810])
         gen_bi_pretrain("cfg1_bi_pretrain", gu.BASE_CFG, gu.CFG1_DIMS, 4321, s2, full_grads=False)
     if want("cfg1_single_pretrain"):
         gen_single_pretrain("cfg1_single_pretrain", dict(gu.BASE_CFG, vocab_size=30522), gu.CFG1_DIMS, 4322)

@@ -20,8 +20,12 @@ full = len(sys.argv) > 2 and sys.argv[2] == "full"
 batch = None if full else synthetic_batch(dims, bench.BASE_CFG, 1234, device=dev)
 mix = bench.DominantMix(dev, dims, bench.BASE_CFG, batch)
 print("rows per launch group:", mix.Ms)
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
-    mix.run_tn()
-    mix.run_nt()
+cold = os.environ.get("PROF_COLD") == "1"      # every launch behind a 768-MB write, as bench.py times them
+flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev) if cold else None
+for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
+    for fn, _ in mix.tn_launches() + mix.nt_launches():
+        if cold:
+            flush.fill_(r)
+        fn()
 torch.cuda.synchronize()
 print("done")

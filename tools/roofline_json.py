@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""profiles/r02_roofline.json: the dominant kernel's roofline numbers recomputed from the rocprofv3
+"""profiles/rNN_roofline.json: the dominant kernel's roofline numbers recomputed from the rocprofv3
 kernel summaries of tools/prof_dominant.py (launch mix of one step) and the PMC traffic file:
-    roofline_json.py OUT.json MIX_PACKED_STATS.csv MIX_FULL_STATS.csv TRAFFIC.json"""
+    roofline_json.py OUT.json MIX_PACKED_STATS.csv MIX_FULL_STATS.csv TRAFFIC.json [BENCH_PACKED_STATS.csv BENCH_FIXED_STATS.csv]
+With the two optional kernel summaries of bench.py's timed region the IN-STEP figures (same kernel between the
+step's other kernels, operands from HBM) are reported beside the replay figures."""
 import csv
 import json
 import sys
@@ -9,6 +11,7 @@ import sys
 H, I = 768, 3072
 PEAK = 2500.0
 out, packed_csv, full_csv, traffic = sys.argv[1:5]
+bench_csv = {"row_packed_batch": sys.argv[5] if len(sys.argv) > 5 else None, "all_slots_valid": sys.argv[6] if len(sys.argv) > 6 else None}
 tr = json.load(open(traffic))
 
 
@@ -46,5 +49,11 @@ for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots
                 "achieved_tflops": flop / us / 1e6 if us else None, "frac_of_peak": flop / us / 1e6 / PEAK if us else None,
                 "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
                 "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
+    if bench_csv[key]:
+        us_in, calls_in = avg_us(bench_csv[key], "gemm_tn_q_kernel")
+        if us_in:
+            res[key]["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
+                                   "frac_of_peak": flop / us_in / 1e6 / PEAK,
+                                   "source": "rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3 --no-extras (timed region + warm-up)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
