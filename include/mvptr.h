@@ -86,6 +86,13 @@ int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M,
                   void* out1, int64_t ldc, float* vec_out, const mvptr_dropout* drop,
                   void* stream);
 
+/* Split-K form of mvptr_gemm_nt for few-row, long-K products (the data gradient of the vocabulary decoder,
+ * transformers/pytorch_transformers/modeling_bert.py:513-516 backward: [~3 k scored rows, 30 528] x [30 528, 768]):
+ * the reduction index is cut into `splits` slices; slab z (f32 [M, ldc], at slabs + z * M * ldc) receives the partial
+ * product of slice z with plain stores — the caller adds the slabs in index order (deterministic, no atomics). */
+int mvptr_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int splits,
+                         float* slabs, int64_t ldc, void* stream);
+
 /* dW[N,K] (+)= A[M,N]^T * B[M,K] ; A = dY (bf16), B = X (bf16), dW f32 (MFMA 32x32x16,
  * transposed LDS reads, split over M with f32 atomics when accumulate != 0 or splits > 1).
  * Replaces the weight gradient of nn.Linear computed by autograd (addmm backward) for every

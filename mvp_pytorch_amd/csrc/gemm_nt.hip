@@ -74,6 +74,10 @@ struct GemmNtArgs {
   int vec_out_ok;   // 16-byte stores allowed on out0/out1
   int vec_aux_ok;   // 16-byte loads allowed on aux
   int vec_bias_ok;  // 16-byte loads allowed on bias
+  int splits;          // gridDim.y (1 unless split-K)
+  int k_split_len;     // split-K launches (mvptr_gemm_nt_splitk): workgroups with blockIdx.y = z reduce over k in [z * k_split_len, +k_split_len)
+  int64_t slab_stride; //   and write their f32 partial tile into slab z = out0 + z * slab_stride elements; 0 = whole K, no slabs
+  int no_epi;          // diagnostic build (MVPTR_NT_EXP bit 10): skip the epilogue (loop-only timing; outputs are not written)
   int stash_temporal;  // diagnostic build (MVPTR_NT_EXP bit 9): EPI_BIAS_GELU stores gelu'(u) with plain instead of non-temporal stores (A/B)
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
   // fused vocabulary decoder + cross entropy (mvptr_decoder_ce_fwd / _bwd)
@@ -140,11 +144,35 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
   constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
   const bool has_aux = kNeedsAux && p.aux != nullptr;
 
+  // residual / pre-activation rows (aux): the four rows of a 32-row chunk are requested together, ONE CHUNK AHEAD of the
+  // chunk being finished — issued in front of that chunk's stores, so they are older in the wave's in-order vmcnt queue
+  // and their latency (HBM: the operand was written kernels ago) runs under the chunk's LDS round trip, math and stores
+  bf16x8 auxv[2][4];
+  auto load_aux = [&](int it0, bf16x8 (&dstv)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int mj = m0 + wm * WROWS + (it0 + j) * 8 + rsub;
+      bf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
+      if (has_aux && mj < p.M && n < p.N) {
+        const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
+        if (nfull && p.vec_aux_ok) {
+          x = *reinterpret_cast<const bf16x8*>(ap);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < p.N) x[e] = ap[e];
+        }
+      }
+      dstv[j] = x;
+    }
+  };
+  if (kNeedsAux) load_aux(0, auxv[0]);
+
 #pragma unroll
   for (int it = 0; it < MT * 2; ++it) {
-    // 32-row chunk ck = it >> 2 of the wave's block goes through the staging area; its residual /
-    // pre-activation rows are requested together so the chunk pays one memory latency, not four
-    bf16x8 auxv[4];
+    // 32-row chunk ck = it >> 2 of the wave's block goes through the staging area
     if constexpr (CHUNK == 32) {
       if ((it & 3) == 0) {
         const int ck = it >> 2;
@@ -164,26 +192,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
           *reinterpret_cast<f32x4*>(st + c16 * 64 + (((nt * 4 + q4) ^ c16) << 2)) = acc[nt][ck];
       }
     }
-    if (kNeedsAux && (it & 3) == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int mj = m0 + wm * WROWS + (it + j) * 8 + rsub;
-        bf16x8 x;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
-        if (has_aux && mj < p.M && n < p.N) {
-          const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
-          if (nfull && p.vec_aux_ok) {
-            x = *reinterpret_cast<const bf16x8*>(ap);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (n + e < p.N) x[e] = ap[e];
-          }
-        }
-        auxv[j] = x;
-      }
-    }
+    if (kNeedsAux && (it & 3) == 0 && it + 4 < MT * 2) load_aux(it + 4, auxv[((it >> 2) + 1) & 1]);
     const int row = it * 8 + rsub;
     const int lrow = row & (CHUNK - 1);
     const int m = m0 + wm * WROWS + row;
@@ -257,7 +266,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
     }
     if (kNeedsAux) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[it & 3][e]);
+      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[(it >> 2) & 1][it & 3][e]);
     }
     if (EPI == MVPTR_EPI_BIAS) {
       store_bf8(p.out0, m, v);
@@ -310,7 +319,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       for (int e = 0; e < 8; ++e) v[e] += a[e];
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_F32) {
-      float* op = (float*)p.out0 + (int64_t)m * p.ldc + n;
+      float* op = (float*)p.out0 + (int64_t)blockIdx.y * p.slab_stride + (int64_t)m * p.ldc + n;   // split-K: slab blockIdx.y
       if (nfull && p.vec_out_ok) {
         *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -382,6 +391,9 @@ void gemm_nt_kernel(GemmNtArgs p) {
   const __amdgpu_buffer_rsrc_t rsB =
       make_rsrc(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
 
+  // split-K launches: this workgroup's slice of the reduction index (whole K otherwise)
+  const int k_begin = (p.k_split_len > 0) ? (int)blockIdx.y * p.k_split_len : 0;
+  const int k_end = (p.k_split_len > 0) ? min(p.K, k_begin + p.k_split_len) : p.K;
   // staging: a wave instruction fills RPI LDS rows (1 KiB, lane-linear); NA per wave for A, NB for B
   uint32_t offA[NA], offB[NB];
   int kcA[NA], kcB[NB];
@@ -404,12 +416,12 @@ void gemm_nt_kernel(GemmNtArgs p) {
     char* lb = la + A_BYTES;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const uint32_t va = (k0 + kcA[i] < p.K) ? offA[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
+      const uint32_t va = (k0 + kcA[i] < k_end) ? offA[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + (i * NWAVES + wave) * 1024), 16, va, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const uint32_t vb = (k0 + kcB[i] < p.K) ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
+      const uint32_t vb = (k0 + kcB[i] < k_end) ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
     }
   };
@@ -436,12 +448,12 @@ void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = (k_end - k_begin + BK - 1) / BK;
   constexpr int LPS = NA + NB;  // loads per stage per thread
   // prologue: STAGES-1 stages in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) stage(s, s * BK);
+    if (s < nk) stage(s, k_begin + s * BK);
   int buf = 0;
 #ifdef MVPTR_STAMP_BUILD
   unsigned long long t_wait = 0, t_issue = 0, t_lds = 0, t_mfma = 0, ts0, ts1;
@@ -478,7 +490,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
     if (kt + STAGES - 1 < nk) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
-      stage(nb, (kt + STAGES - 1) * BK);
+      stage(nb, k_begin + (kt + STAGES - 1) * BK);
     }
 #ifdef MVPTR_STAMP_BUILD
     __builtin_amdgcn_sched_barrier(0);
@@ -528,6 +540,15 @@ void gemm_nt_kernel(GemmNtArgs p) {
 #ifdef MVPTR_TIMELINE_BUILD
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop)::"memory");
 #endif
+#ifdef MVPTR_DIAG_BUILD
+  if (p.no_epi) {   // loop-only timing: keep the accumulators alive, write nothing
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+#endif
   __syncthreads();  // every wave is done with the operand ring
   nt_epilogue<EPI, MT, 32>(p, acc, reinterpret_cast<float*>(lds) + wave * (32 * ST_LD), m0, n0, wm, wn, lane);
 #ifdef MVPTR_TIMELINE_BUILD
@@ -542,6 +563,126 @@ void gemm_nt_kernel(GemmNtArgs p) {
   }
 #endif
 }
+
+#ifdef MVPTR_DIAG_BUILD
+// EXPERIMENT (diagnostic build only, MVPTR_GEMM_CFG=n768): the row-owning tile a LayerNorm-in-the-epilogue GEMM would
+// need (north_star "fused LayerNorm"): 128 rows x ALL 768 output columns per workgroup, eight waves of
+// 128 x 96 (8 x 6 blocks of v_mfma_f32_16x16x32_bf16 = 192 accumulator registers), BK 32, double-buffered
+// (128 + 768) x 64 B = 56 KiB stages (a BK 64 stage would be 112 KiB: the second buffer does not fit).  Epilogue: bias +
+// residual straight from the accumulators (8-byte stores; no LayerNorm): the point is the MAIN LOOP of this tile
+// shape against the default 256 x 256 tile, measured by tools/exp_rowtile.py with and without epilogues.
+__global__ __launch_bounds__(512, 2) void gemm_nt_rowtile_kernel(GemmNtArgs p) {
+  constexpr int BM = 128, BN = 768, BK = 32, ROW_B = 64, CHUNKS = 4, RPI = 16, NWAVES = 8, MT = 8, NT = 6;
+  constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2, NB = BN / RPI / NWAVES;   // 6 B pieces + 1 A piece per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const int rows_a = min(BM, p.M - m0), rows_b = min(BN, p.N);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, (uint32_t)(((int64_t)(rows_b - 1) * p.ldb + p.K) * 2));
+  uint32_t offA, offB[NB];
+  int kcA, kcB[NB];
+  {
+    const int row = wave * RPI + lane / CHUNKS;
+    const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
+    kcA = c * 8;
+    offA = (uint32_t)(row * p.lda * 2 + c * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = (i * NWAVES + wave) * RPI + lane / CHUNKS;
+    const int c = (lane % CHUNKS) ^ swz_row(row, CHUNKS);
+    kcB[i] = c * 8;
+    offB[i] = (uint32_t)(row * p.ldb * 2 + c * 16);
+  }
+  auto stage = [&](int buf, int k0) {
+    char* la = lds + buf * STAGE_BYTES;
+    char* lb = la + A_BYTES;
+    const uint32_t va = (k0 + kcA < p.K) ? offA + (uint32_t)k0 * 2 : MVPTR_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(la + wave * 1024), 16, va, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const uint32_t vb = (k0 + kcB[i] < p.K) ? offB[i] + (uint32_t)k0 * 2 : MVPTR_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(lb + (i * NWAVES + wave) * 1024), 16, vb, 0, 0, 0);
+    }
+  };
+  const int c16 = lane & 15, q4 = lane >> 4;
+  uint32_t fx[MT], fw[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int rx = i * 16 + c16;
+    fx[i] = rx * ROW_B + ((q4 ^ swz_row(rx, CHUNKS)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int rw = wave * 96 + i * 16 + c16;
+    fw[i] = rw * ROW_B + ((q4 ^ swz_row(rw, CHUNKS)) << 4);
+  }
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = (p.K + BK - 1) / BK;
+  stage(0, 0);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const char* la = lds + buf * STAGE_BYTES;
+    const char* lb = la + A_BYTES;
+    bf16x8 xf[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i]);
+    if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lb + fw[nt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mt], acc[nt][mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    buf ^= 1;
+  }
+  if (p.no_epi) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  // bias + residual, straight from the accumulators: a lane holds 4 consecutive columns of one row per 16x16 block
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = wave * 96 + nt * 16 + q4 * 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && n + 3 < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + c16;
+      if (m >= p.M || n + 3 >= p.N) continue;
+      f32x4 v = acc[nt][mt] + b4;
+      if (p.aux != nullptr) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.aux + (int64_t)m * p.ld_aux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+      }
+      bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *reinterpret_cast<bf16x4*>((__bf16*)p.out0 + (int64_t)m * p.ldc + n) = o;
+    }
+  }
+}
+
+int launch_rowtile(GemmNtArgs a, hipStream_t s) {
+  if (a.N != 768 || (a.K & 31)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=n768 needs N = 768 and K %% 32 == 0");
+  constexpr int LDS_BYTES = 2 * (128 + 768) * 32 * 2;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_rowtile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(gemm_nt_rowtile_kernel, dim3((a.M + 127) / 128), dim3(512), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
+}
+#endif
 
 template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
 int launch_bk(GemmNtArgs a, hipStream_t s) {
@@ -567,7 +708,8 @@ int launch_bk(GemmNtArgs a, hipStream_t s) {
   if (mvptr_knobs().nt_group[0] > 0) a.group_m = mvptr_knobs().nt_group[0];
   if (mvptr_knobs().nt_group[1] > 0) a.group_n = min(mvptr_knobs().nt_group[1], a.tiles_n);
   if (mvptr_knobs().nt_group[0] > 0 && mvptr_knobs().nt_group[1] <= 0) a.group_n = a.tiles_n;   // "gm" or "gm,0": whole width
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, SCHED>), dim3(nwg), dim3(WM * WN * 64), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, BK, STAGES, WM, WN, MT_, SCHED>), dim3(nwg, a.splits > 1 ? a.splits : 1), dim3(WM * WN * 64),
+                     LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
 }
@@ -588,6 +730,10 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
 #ifdef MVPTR_DIAG_BUILD
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
+    if (env[0] == 'n') {                                                  // "n768": row-owning tile experiment
+      if constexpr (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_ADD) return launch_rowtile(a, s);
+      else MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=n768 supports the bias / residual / add epilogues only");
+    }
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128"
     if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);  // "w4"
     if (env[0] == 't') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);  // "t256k"
@@ -727,8 +873,16 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.vec_out = vec_out;
   a.drop = make_dropdev(drop);
   a.stamps = nullptr;
+  a.splits = 1;
+  a.k_split_len = 0;
+  a.slab_stride = 0;
+  a.labels = nullptr;
+  a.lse = a.scale = nullptr;
+  a.part = a.lab_logit = nullptr;
+  a.part_ld = a.n_store = 0;
   const MvptrKnobs& kn = mvptr_knobs();
   a.stash_temporal = (kn.nt_exp & 512) ? 1 : 0;
+  a.no_epi = (kn.nt_exp & 1024) ? 1 : 0;
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
   a.stamps = (unsigned long long*)kn.stamps;
 #endif
@@ -762,4 +916,34 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
     default:
       MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown epilogue %d", epilogue);
   }
+}
+
+
+// Split-K form for few-row, long-K products (the data gradient of the vocabulary decoder: dh[M, 768] = dlogits[M, 30528] W,
+// M = the ~3 k scored rows of a step): 138 tiles of 128 x 128 cannot fill 256 CUs and each would loop over 954 K-steps.
+// The reduction index is cut into `splits` slices; workgroup (tile, z) multiplies slice z and writes its f32 partial tile
+// into slab z (plain stores, no atomics: the caller adds the slabs in order, deterministically).
+extern "C" int mvptr_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int splits,
+                                    float* slabs, int64_t ldc, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || splits > 64) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt_splitk: M,N,K > 0, 1 <= splits <= 64");
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt_splitk: K, lda, ldb must be multiples of 8 and >= K");
+  if (!A || !B || !slabs || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt_splitk: NULL or unaligned pointer");
+  if (ldc < N) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt_splitk: ldc < N");
+  GemmNtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const __bf16*)A;
+  a.B = (const __bf16*)B;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.out0 = slabs;
+  a.ldc = ldc;
+  a.drop = make_dropdev(nullptr);
+  a.vec_out_ok = ((ldc % 4 == 0) && (((uintptr_t)slabs & 15) == 0) && ((((int64_t)M * ldc) & 3) == 0)) ? 1 : 0;
+  a.splits = splits;
+  a.k_split_len = ((K + splits - 1) / splits + 63) / 64 * 64;      // whole K-steps of every tile configuration
+  a.slab_stride = (int64_t)M * ldc;
+  return launch<MVPTR_EPI_F32>(a, (hipStream_t)stream);
 }

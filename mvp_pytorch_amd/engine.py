@@ -872,7 +872,17 @@ class DecoderCEFn(GradAwareFunction):
         else:
             d = hip.ce_bwd(logits, labels, lse, scale, V, Vp)
         H = h.shape[1]
-        dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H) if ctx.needs[0] else None
+        dh = None
+        if ctx.needs[0]:
+            M = d.shape[0]
+            tiles = ((M + 127) // 128) * ((H + 127) // 128)
+            if Vp >= 8192 and tiles < 256 and M > 128:
+                # few scored rows x the whole vocabulary: 128 x 128 tiles cannot fill the chip and each loops over Vp / 32
+                # K-steps -> cut the reduction into slices (one workgroup per tile and slice), add the f32 slabs in order
+                splits = max(2, min(8, 768 // tiles))
+                dh = hip.gemm_nt_splitk(d, cache.t["wt"], splits, n=H).sum(0).to(torch.bfloat16)
+            else:
+                dh = hip.gemm_nt(d, cache.t["wt"], hip.EPI_ADD, n=H)
         weight, bias = ctx.ps
         dw = db = None
         dw_d = db_d = False

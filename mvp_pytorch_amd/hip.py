@@ -14,8 +14,9 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MVPTR_LIB=diag (measurement tools only): the diagnostic build with kernel-configuration knobs (`make diag`)
-LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip_diag.so" if os.environ.get("MVPTR_LIB") == "diag" else "libmvptr_hip.so")
+# MVPTR_LIB=<tag> (measurement tools only): libmvptr_hip_<tag>.so instead of the product library — "diag" = the
+# diagnostic build with kernel-configuration knobs (`make diag`); A/B runs load a second build of the library this way
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip_%s.so" % os.environ["MVPTR_LIB"] if os.environ.get("MVPTR_LIB") else "libmvptr_hip.so")
 
 # epilogue codes (mvptr_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIAS_TANH = range(7)
@@ -30,7 +31,7 @@ SYMBOLS = [
     "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe",
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
-    "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps",
+    "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
 ]
 
 
@@ -90,6 +91,7 @@ def load():
     if hasattr(lib, "mvptr_set_knob"):      # diagnostic build only
         lib.mvptr_set_knob.argtypes = [c_char_p, c_char_p]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
+    lib.mvptr_gemm_nt_splitk.argtypes = [P, I64, P, I64, I, I, I, I, P, I64, P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
     lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
@@ -196,6 +198,16 @@ def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, v
                                 _p(aux), aux.stride(0) if aux is not None else 0, _p(out), _p(out1),
                                 out.stride(0), _p(vec_out), _dp(drop), _stream()))
     return (out, out1) if epilogue == EPI_BIAS_GELU else out
+
+
+def gemm_nt_splitk(a, b, splits, n=None):
+    """f32 slabs [splits, M, N] with slab z = A[:, Kz] B[:, Kz]^T over the z-th slice of the reduction index
+    (mvptr_gemm_nt_splitk); the caller sums them."""
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    slabs = torch.empty((splits, M, N), device=a.device, dtype=torch.float32)
+    _check(load().mvptr_gemm_nt_splitk(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, splits, _p(slabs), N, _stream()))
+    return slabs
 
 
 def gemm_tn(dy, x, dw, n=None, k=None, colsum=None):

@@ -39,6 +39,9 @@ MEASURED = {
     "cfg1_single_pretrain:prediction_scores": 0.0118, "cfg1_single_pretrain:seq_relationship": 0.0079,
     "tiny_bi_pretrain:gnorm": 0.0272, "cfg1_bi_pretrain:gnorm": 0.0229, "tiny_bi_hn:gnorm": 0.0366,
     "tiny_bi_pretrain:grad": 0.0191, "cfg1_bi_pretrain:grad": 0.0191,
+    "tiny_single_pretrain:gnorm": 0.0050, "tiny_single_pretrain:gnorm_loss_only": 0.0050,
+    "cfg1_single_pretrain:gnorm": 0.0246, "cfg1_single_pretrain:gnorm_loss_only": 0.0246,
+    "tiny_finetune:ret_fine_logits": 0.0041, "tiny_finetune:ve_logits": 0.0052, "tiny_finetune:vqa_logits": 0.0062,
 }
 
 

@@ -675,3 +675,22 @@ def test_pack_maps_against_host_walk(dev):
             ln.append(r - st[-1])
         assert np.array_equal(pj.cpu().numpy(), pos) and np.array_equal(sj.cpu().numpy(), np.array(st)) and np.array_equal(lj.cpu().numpy(), np.array(ln))
         assert cj.tolist() == [r, max(ln)] and np.array_equal(ij.cpu().numpy()[:r], np.array(idx))
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(2828, 768, 30528, 5), (800, 768, 30528, 8), (300, 520, 1000, 3), (129, 768, 4096, 2)])
+def test_gemm_nt_splitk(dev, M, N, K, splits):
+    """mvptr_gemm_nt_splitk: the f32 slabs of the K slices add up to the full product (the decoder's data gradient)."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = _bf(torch.randn(M, K, generator=g) * 0.1).to(dev)
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    slabs = hip.gemm_nt_splitk(a, b, splits)
+    assert slabs.shape == (splits, M, N)
+    ref = a.float() @ b.float().t()
+    assert _rel(slabs.sum(0), ref) < 1e-5
+    # every slab is the product over its own slice: the slices partition K
+    klen = ((K + splits - 1) // splits + 63) // 64 * 64
+    for z in range(splits):
+        lo, hi = z * klen, min(K, (z + 1) * klen)
+        part = a[:, lo:hi].float() @ b[:, lo:hi].float().t() if lo < hi else torch.zeros(M, N, device=dev)
+        assert (slabs[z] - part).abs().max() < 1e-4 * max(1.0, float(part.abs().max()))
