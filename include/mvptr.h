@@ -389,6 +389,29 @@ typedef struct {
 int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, int32_t* pos_out, int32_t* idx_out,
                     int32_t* seq_start, int32_t* seq_len, int64_t* counts, void* stream);
 
+/* Word-region alignment loss (phrase_mod == 'sample'), replaces oscar/modeling/modeling_vlbert.py:1285-1300 with
+ * get_pos_neg_sims :1553-1596 and t2i_sim :1543-1550 on rows already gathered from the joint output:
+ * txt bf16 [n, Pw, H] (row k of sample i = its k-th phrase row, rows beyond phrase_index[i,1] - phrase_index[i,0] are
+ * ignored), reg bf16 [n, Rw, H] (region rows, img_index[i,1] - img_index[i,0] of them valid).  pos_pick / neg_pick
+ * int64 [n, Pw] in 0..2 are the reference's randint(0, 3) draws (which of the three most similar regions a phrase
+ * takes, vl:1547-1549), neg_img int64 [n] the other image each sample is compared with (vl:1572-1573).
+ * loss f32 [1] = mean over the samples with phrases of max(neg - pos + 0.2, 0).  The remaining outputs are what the
+ * backward pass reads: hinge f32 [n], coef f32 [n], cnt int32 [n, 2], sel int32 [n, Pw, 2], sval f32 [n, Pw, 2],
+ * inv_p f32 [n, Pw], inv_r f32 [n, Rw].  mvptr_wra_bwd: gout = d/d loss (one f32 in device memory) ->
+ * d_txt bf16 [n, Pw, H], d_reg bf16 [n, Rw, H] (every row written; zero where nothing flows).
+ * mvptr_wra_rows builds the row vectors the gathers use from the packed-row map `pos` int32 [>= n, Lj] of
+ * mvptr_pack_maps: rows_p int32 [n, Pw], rows_r int32 [n, Rw], -1 beyond a sample's counts.
+ * H even and <= 1024; Pw <= 512; Pw * H * 2 + 8 * Pw * Rw bytes of LDS must fit (150 KB). */
+int mvptr_wra_rows(const int32_t* pos, int Lj, const int64_t* phrase_index, const int64_t* img_index, int n, int Pw,
+                   int Rw, int32_t* rows_p, int32_t* rows_r, void* stream);
+int mvptr_wra_fwd(const void* txt, const void* reg, const int64_t* phrase_index, const int64_t* img_index,
+                  const int64_t* pos_pick, const int64_t* neg_pick, const int64_t* neg_img, int n, int Pw, int Rw, int H,
+                  float* loss, float* hinge, float* coef, int32_t* cnt, int32_t* sel, float* sval, float* inv_p,
+                  float* inv_r, void* stream);
+int mvptr_wra_bwd(const void* txt, const void* reg, const int64_t* neg_img, int n, int Pw, int Rw, int H,
+                  const int32_t* cnt, const int32_t* sel, const float* sval, const float* inv_p, const float* inv_r,
+                  const float* coef, const float* gout, void* d_txt, void* d_reg, void* stream);
+
 /* Input pipeline: region features of n_samples TSV rows, still base64 text, ->
  * out_f32 [n_samples, R, D] and/or out_bf16 [n_samples * R, ld_bf16] (columns D..ld_bf16-1 zero: the
  * K-padded operand of the region-embedding GEMM).  Replaces get_img_feature

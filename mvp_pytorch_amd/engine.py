@@ -1034,6 +1034,28 @@ class ContrastiveLossFn(GradAwareFunction):
         return (dsim if ctx.needs[0] else None), (grad_result(p, dls, dls_d) if ctx.needs[1] else None)
 
 
+class WraLossFn(torch.autograd.Function):
+    """Word-region alignment loss on gathered rows (vl:1285-1300 + get_pos_neg_sims vl:1553-1596 + t2i_sim vl:1543-1550):
+    txt bf16 [n, Pw, H] phrase rows, reg bf16 [n, Rw, H] region rows, the reference's draws -> the mean hinge, f32 [] —
+    two launches forward, one backward (csrc/wra.hip)."""
+
+    @staticmethod
+    def forward(ctx, txt, reg, phrase_index, img_index, pos_pick, neg_pick, neg_img):
+        txt, reg = txt.contiguous(), reg.contiguous()
+        neg_img = neg_img.contiguous()
+        loss, saved = hip.wra_fwd(txt, reg, phrase_index.contiguous(), img_index.contiguous(), pos_pick.contiguous(),
+                                  neg_pick.contiguous(), neg_img)
+        ctx.save = (txt, reg, neg_img, saved)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        txt, reg, neg_img, saved = ctx.save
+        ctx.save = None
+        d_txt, d_reg = hip.wra_bwd(txt, reg, neg_img, saved, gloss)
+        return d_txt, d_reg, None, None, None, None, None
+
+
 class CeMeanFn(torch.autograd.Function):
     """CrossEntropyLoss(ignore_index=-1) over a few classes (the 2-way ITM loss vl:1247-1251): one launch computes the
     mean loss and d loss / d logits."""

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
+    "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd",
 ]
 
 
@@ -126,6 +127,9 @@ def load():
     lib.mvptr_gather_rows.argtypes = [P, I64, P, I64, I, P, P, I64, I, I, P]
     lib.mvptr_scatter_add_rows.argtypes = [P, I64, I, P, P, I64, P, I64, I, I, I, I, P]
     lib.mvptr_pack_maps.argtypes = [POINTER(PackSeg), I, I, P, P, P, P, P, P]
+    lib.mvptr_wra_rows.argtypes = [P, I, P, P, I, I, I, P, P, P]
+    lib.mvptr_wra_fwd.argtypes = [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]
+    lib.mvptr_wra_bwd.argtypes = [P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P]
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
     lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
     lib.mvptr_diag_store_probe.argtypes = [P, I64, I, I64, I, I64, P]
@@ -587,3 +591,47 @@ def pack_maps(segs, n_seq):
     counts = torch.empty(2, device=dev, dtype=torch.int64)
     _check(load().mvptr_pack_maps(arr, len(segs), n_seq, _p(pos_out), _p(idx_out), _p(seq_start), _p(seq_len), _p(counts), _stream()))
     return pos_out, idx_out, seq_start, seq_len, counts
+
+
+def wra_rows(pos, phrase_index, img_index, n, Pw, Rw):
+    """pos int32 [>= n, Lj] (packed row of every slot, hip.pack_maps) -> rows_p int32 [n, Pw], rows_r int32 [n, Rw]:
+    the packed rows of each sample's phrase / region slots, -1 beyond its counts (mvptr_wra_rows)."""
+    assert pos.dtype == torch.int32 and pos.is_contiguous() and pos.shape[0] >= n
+    phrase_index, img_index = phrase_index.contiguous(), img_index.contiguous()
+    assert phrase_index.dtype == torch.int64 and img_index.dtype == torch.int64
+    rows_p = torch.empty((n, Pw), device=pos.device, dtype=torch.int32)
+    rows_r = torch.empty((n, Rw), device=pos.device, dtype=torch.int32)
+    _check(load().mvptr_wra_rows(_p(pos), pos.shape[1], _p(phrase_index), _p(img_index), n, Pw, Rw, _p(rows_p), _p(rows_r), _stream()))
+    return rows_p, rows_r
+
+
+def wra_fwd(txt, reg, phrase_index, img_index, pos_pick, neg_pick, neg_img):
+    """txt bf16 [n, Pw, H], reg bf16 [n, Rw, H], draws int64 -> (loss f32 [1], saved tuple for wra_bwd) — mvptr_wra_fwd."""
+    n, Pw, H = txt.shape
+    Rw = reg.shape[1]
+    dev = txt.device
+    for t in (txt, reg, phrase_index, img_index, pos_pick, neg_pick, neg_img):
+        assert t.is_contiguous()
+    assert txt.dtype == torch.bfloat16 and reg.dtype == torch.bfloat16 and reg.shape[0] == n and reg.shape[2] == H
+    assert all(t.dtype == torch.int64 for t in (phrase_index, img_index, pos_pick, neg_pick, neg_img))
+    assert pos_pick.shape == (n, Pw) and neg_pick.shape == (n, Pw) and neg_img.shape == (n,)
+    f32 = torch.empty(1 + 2 * n + 3 * n * Pw + n * Rw, device=dev, dtype=torch.float32)
+    i32 = torch.empty(2 * n + 2 * n * Pw, device=dev, dtype=torch.int32)
+    loss, hinge, coef, sval, inv_p, inv_r = f32.split([1, n, n, 2 * n * Pw, n * Pw, n * Rw])
+    cnt, sel = i32.split([2 * n, 2 * n * Pw])
+    _check(load().mvptr_wra_fwd(_p(txt), _p(reg), _p(phrase_index), _p(img_index), _p(pos_pick), _p(neg_pick), _p(neg_img),
+                                n, Pw, Rw, H, _p(loss), _p(hinge), _p(coef), _p(cnt), _p(sel), _p(sval), _p(inv_p), _p(inv_r),
+                                _stream()))
+    return loss, (cnt, sel, sval, inv_p, inv_r, coef, hinge)
+
+
+def wra_bwd(txt, reg, neg_img, saved, gout):
+    """-> d_txt bf16 like txt, d_reg bf16 like reg; gout: f32 tensor with one element on the device (mvptr_wra_bwd)."""
+    n, Pw, H = txt.shape
+    Rw = reg.shape[1]
+    cnt, sel, sval, inv_p, inv_r, coef, _ = saved
+    gout = gout.reshape(1).to(torch.float32)
+    d_txt, d_reg = torch.empty_like(txt), torch.empty_like(reg)
+    _check(load().mvptr_wra_bwd(_p(txt), _p(reg), _p(neg_img), n, Pw, Rw, H, _p(cnt), _p(sel), _p(sval), _p(inv_p), _p(inv_r),
+                                _p(coef), _p(gout), _p(d_txt), _p(d_reg), _stream()))
+    return d_txt, d_reg

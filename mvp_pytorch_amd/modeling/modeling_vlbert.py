@@ -932,17 +932,12 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         if wra:
             Pw = int(getattr(self.config, "max_phrases", None) or La)
             Rw = Lj - La
-            p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
             if getattr(self.config, "max_phrases", None):
-                torch._assert_async(((p1 - p0) <= Pw).all(), "a sample has more phrases than config.max_phrases")
-            ar_p, ar_r = torch.arange(Pw, device=dev), torch.arange(Rw, device=dev)
-            valid_p = ar_p[None, :] < (p1 - p0)[:, None]
-            valid_r = ar_r[None, :] < (i1 - i0)[:, None]
-            pj = pos_j[:n]
-            minus1 = torch.full((), -1, dtype=torch.int32, device=dev)
-            rows_p = torch.where(valid_p, pj.gather(1, (p0[:, None] + ar_p[None, :]).clamp(max=Lj - 1)), minus1)
-            rows_r = torch.where(valid_r, pj.gather(1, (i0[:, None] + ar_r[None, :]).clamp(max=Lj - 1)), minus1)
-            idxs += [rows_p.reshape(-1), rows_r.reshape(-1)]
+                torch._assert_async(((phrase_index[:, 1] - phrase_index[:, 0]) <= Pw).all(),
+                                    "a sample has more phrases than config.max_phrases")
+            from .. import hip
+            rows_p, rows_r = hip.wra_rows(pos_j, phrase_index, img_index, n, Pw, Rw)
+            idxs += [rows_p.view(-1), rows_r.view(-1)]
         taps = engine.MultiTapFn.apply(both, None, *idxs)
         late = {}
 
@@ -955,12 +950,13 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 late["qa"] = CrossEntropyLoss(ignore_index=-1)(self.qa_head(pooled[:n]), qa_ans)
             if wra:
                 H = both.shape[1]
-                txt_n = F.normalize(taps[2].view(n, Pw, H).float(), p=2, dim=-1)
-                reg_n = F.normalize(taps[3].view(n, Rw, H).float(), p=2, dim=-1)
-                pos_sims, neg_sims = _wra_from_rows(txt_n, reg_n, valid_p, valid_r)
-                valid = (p1 - p0) > 0
-                hinge = torch.clamp(neg_sims + 0.2 - pos_sims, min=0)
-                late["wra"] = torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype)
+                # the reference's draws (vl:1547-1549 one of the top-3 regions per phrase, vl:1572-1573 one other image
+                # per sample) from the device generator, in wra_sample_on_device's order
+                pos_pick = torch.randint(0, 3, (n, Pw), device=dev)
+                neg_pick = torch.randint(0, 3, (n, Pw), device=dev)
+                neg_img = (torch.arange(n, device=dev) + 1 + torch.randint(0, max(n - 1, 1), (n,), device=dev)) % n
+                late["wra"] = engine.WraLossFn.apply(taps[2].view(n, Pw, H), taps[3].view(n, Rw, H), phrase_index, img_index,
+                                                     pos_pick, neg_pick, neg_img)
 
         use_side = self.heads_beside >= 2 and two_streams
         if use_side:

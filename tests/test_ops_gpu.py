@@ -694,3 +694,83 @@ def test_gemm_nt_splitk(dev, M, N, K, splits):
         lo, hi = z * klen, min(K, (z + 1) * klen)
         part = a[:, lo:hi].float() @ b[:, lo:hi].float().t() if lo < hi else torch.zeros(M, N, device=dev)
         assert (slabs[z] - part).abs().max() < 1e-4 * max(1.0, float(part.abs().max()))
+
+
+@pytest.mark.parametrize("n,Pw,Rw,H", [(16, 5, 12, 768), (9, 20, 7, 128), (64, 70, 50, 768)])
+def test_wra_loss_kernel_against_torch_and_oracle(dev, n, Pw, Rw, H):
+    """csrc/wra.hip (forward + gradient) against the torch restatement of vl:1285-1300 / 1553-1596 on the same rows and
+    draws, and against the oracle's per-sample walk; samples without phrases and with few regions included."""
+    from mvp_pytorch_amd import engine, hip
+    from mvp_pytorch_amd.modeling import modeling_vlbert as mv
+    from oracle import mvptr_oracle as orc
+    g = torch.Generator(device="cpu").manual_seed(n + Pw)
+    La = Pw + 3
+    np_ = torch.randint(0, Pw + 1, (n,), generator=g)
+    np_[0], np_[1] = 0, Pw
+    nr_ = torch.randint(3, Rw + 1, (n,), generator=g)
+    p0 = torch.randint(1, 3, (n,), generator=g)
+    phrase_index = torch.stack([p0, p0 + np_], 1)
+    img_index = torch.stack([torch.full((n,), La), La + nr_], 1)
+    txt = _bf(torch.randn(n, Pw, H, generator=g)).to(dev)
+    reg = _bf(torch.randn(n, Rw, H, generator=g) + 0.3 * torch.randn(n, 1, H, generator=g)).to(dev)
+    pos_pick = torch.randint(0, 3, (n, Pw), generator=g).to(dev)
+    neg_pick = torch.randint(0, 3, (n, Pw), generator=g).to(dev)
+    neg_img = ((torch.arange(n) + 1 + torch.randint(0, n - 1, (n,), generator=g)) % n).to(dev)
+    pi, ii = phrase_index.to(dev), img_index.to(dev)
+    valid_p = torch.arange(Pw, device=dev)[None, :] < (pi[:, 1] - pi[:, 0])[:, None]
+    valid_r = torch.arange(Rw, device=dev)[None, :] < (ii[:, 1] - ii[:, 0])[:, None]
+
+    def torch_loss(t, r):
+        tz = torch.where(valid_p[:, :, None], t.float(), torch.zeros((), device=dev))   # the gathers deliver zero rows there
+        tn = torch.nn.functional.normalize(tz, p=2, dim=-1)
+        rn = torch.nn.functional.normalize(r.float(), p=2, dim=-1)
+        pos, neg = mv._wra_from_rows(tn, rn, valid_p, valid_r, draws=(pos_pick, neg_pick, neg_img))
+        valid = (pi[:, 1] - pi[:, 0]) > 0
+        hinge = torch.clamp(neg + 0.2 - pos, min=0)
+        return torch.where(valid, hinge, torch.zeros_like(hinge)).sum() / valid.sum().to(hinge.dtype), pos, neg
+
+    t1, r1 = txt.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    loss = engine.WraLossFn.apply(t1, r1, pi, ii, pos_pick, neg_pick, neg_img)
+    loss.backward()
+    t2, r2 = txt.clone().float().requires_grad_(True), reg.clone().float().requires_grad_(True)
+    ref, pos_ref, neg_ref = torch_loss(t2, r2)
+    ref.backward()
+    print("wra", n, Pw, Rw, H, float(loss.detach()), float(ref.detach()))
+    assert abs(float(loss) - float(ref)) < 2e-6 + 1e-5 * abs(float(ref))
+    # rows beyond a sample's counts receive exactly zero; the rest agree to bf16 rounding of the gradient rows
+    assert float(t1.grad.float()[~valid_p].abs().max()) == 0.0
+    assert float(r1.grad.float()[~valid_r].abs().max()) == 0.0
+    assert _rel(t1.grad, t2.grad) < 4e-3 and _rel(r1.grad, r2.grad) < 4e-3
+    # run-to-run identical (fixed summation order)
+    t3, r3 = txt.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+    engine.WraLossFn.apply(t3, r3, pi, ii, pos_pick, neg_pick, neg_img).backward()
+    assert torch.equal(t3.grad, t1.grad) and torch.equal(r3.grad, r1.grad)
+    # the oracle's walk over samples (vl:1553-1596) on the joint layout these rows come from
+    Lj = La + Rw
+    seq = torch.zeros(n, Lj, H)
+    for i in range(n):
+        seq[i, int(p0[i]):int(p0[i]) + int(np_[i])] = txt[i, :int(np_[i])].float().cpu()
+        seq[i, La:La + int(nr_[i])] = reg[i, :int(nr_[i])].float().cpu()
+    picks = []
+    for i in range(n):      # the oracle draws per sample: ranks for the own image, the other image, ranks for it
+        if int(np_[i]):
+            picks += [pos_pick[i, :int(np_[i])].tolist(), neg_pick[i, :int(np_[i])].tolist()]
+    loss_o = orc.wra_loss_sample(seq, phrase_index, img_index, orc.Draws(randint3=picks, choice=neg_img.tolist()))
+    assert abs(float(loss) - float(loss_o)) < 1e-5
+
+
+def test_wra_rows_against_torch(dev):
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, Lj, Pw, Rw = 11, 40, 6, 9
+    pos = torch.randint(-1, 1000, (2 * n, Lj), generator=g, dtype=torch.int32).to(dev)
+    p0 = torch.randint(0, 5, (n,), generator=g)
+    i0 = torch.randint(20, 30, (n,), generator=g)
+    phrase_index = torch.stack([p0, p0 + torch.randint(0, Pw + 1, (n,), generator=g)], 1).to(dev)
+    img_index = torch.stack([i0, i0 + torch.randint(0, Rw + 1, (n,), generator=g)], 1).to(dev)
+    rows_p, rows_r = hip.wra_rows(pos, phrase_index, img_index, n, Pw, Rw)
+    for rows, index, W in ((rows_p, phrase_index, Pw), (rows_r, img_index, Rw)):
+        ar = torch.arange(W, device=dev)
+        valid = ar[None, :] < (index[:, 1] - index[:, 0])[:, None]
+        want = torch.where(valid, pos[:n].gather(1, (index[:, :1] + ar[None, :]).clamp(max=Lj - 1)), torch.full((), -1, dtype=torch.int32, device=dev))
+        assert torch.equal(rows, want)

@@ -34,6 +34,40 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 print("%s: wall %.2f ms/step, host time inside pretrain_step %.2f ms/step (includes waiting at the step's host syncs)"
       % ("fixed" if fixed else "packed", wall / n * 1e3, host / n * 1e3))
+# where the host waits: the row-count read-backs (engine.AsyncCounts.get)
+from mvp_pytorch_amd import engine  # noqa: E402
+waits = []
+_get = engine.AsyncCounts.get
+
+
+def timed_get(self):
+    t = time.perf_counter()
+    r = _get(self)
+    waits.append(time.perf_counter() - t)
+    return r
+
+
+engine.AsyncCounts.get = timed_get
+for _ in range(5):
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])
+torch.cuda.synchronize()
+per = len(waits) // 5
+print("count read-backs per step: %d; host wait in each (us, mean of 5 steps): %s"
+      % (per, [round(sum(waits[i::per]) / 5 * 1e6) for i in range(per)]))
+engine.AsyncCounts.get = _get
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(5):
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr, stream=sys.stdout)
+print("cProfile, 5 steps, by own time:")
+st.sort_stats("tottime").print_stats(45)
+print("cProfile, 5 steps, by cumulative time:")
+st.sort_stats("cumulative").print_stats(60)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU]) as prof:
     train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"])

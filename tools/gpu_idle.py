@@ -40,3 +40,24 @@ big = max(range(len(seg) - 1), key=lambda i: seg[i + 1][0] - max(e for _, e, _ i
 ref = seg[big][1]
 for s, e, name in seg[max(0, big - 10):big + 14]:
     print("  start %+9.1f us  dur %7.1f us  %s" % ((s - ref) / 1e3, (e - s) / 1e3, name[:110]))
+
+# where in the step the idle time sits: 40 equal windows over the mean step, idle us per step in each and the
+# kernel that runs longest in the window
+W = 40
+step_bounds = [rows[steps[k]][0] for k in range(-6, 0)]
+idle = [0.0] * W
+names = [dict() for _ in range(W)]
+for k in range(5):
+    a, b = step_bounds[k], step_bounds[k + 1]
+    ks = [r for r in rows if a <= r[0] < b]
+    cur = a
+    for s_, e_, n_ in ks:
+        w = min(W - 1, int((s_ - a) * W / (b - a)))
+        if s_ > cur:
+            idle[w] += (s_ - cur) / 5e3
+        cur = max(cur, e_)
+        names[w][n_[:70]] = names[w].get(n_[:70], 0) + (e_ - s_)
+print("idle time along the step (window = 1/%d of the step; us of idle per step in the window; busiest kernel):" % W)
+for w in range(W):
+    top = max(names[w].items(), key=lambda kv: kv[1])[0] if names[w] else "-"
+    print("  %2d  idle %7.1f us   %s" % (w, idle[w], top))
