@@ -98,7 +98,17 @@ class CaptionBertEncoder(nn.Module):
         # the losses is consumed; True = always; False = never (the reference's padded execution)
         self.unpad = getattr(config, "unpad", "train")
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_flat_cache", None)      # .to() / .half() may replace Parameter objects
+        return super()._apply(fn, *args, **kwargs)
+
     def _flat_params(self):
+        """The stack's parameters, sixteen per layer in LayerPack.NAMES order.  Walking the module tree costs ~130 us of
+        host time per call (six calls per training step), so the list is kept until a parameter object is replaced."""
+        cached = self.__dict__.get("_flat_cache")
+        if cached is not None and cached[0] is self.layer[0].attention.self.query.weight and \
+                cached[-1] is self.layer[-1].output.LayerNorm.bias:
+            return cached
         out = []
         for layer in self.layer:
             a = layer.attention
@@ -107,6 +117,7 @@ class CaptionBertEncoder(nn.Module):
                     a.output.LayerNorm.weight, a.output.LayerNorm.bias, layer.intermediate.dense.weight,
                     layer.intermediate.dense.bias, layer.output.dense.weight, layer.output.dense.bias,
                     layer.output.LayerNorm.weight, layer.output.LayerNorm.bias]
+        self.__dict__["_flat_cache"] = out
         return out
 
     def grad_arena_units(self):
