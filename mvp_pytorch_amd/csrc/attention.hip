@@ -435,6 +435,238 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------- backward, sequences of <= 128 rows
+// One pass instead of two: wave w owns key block w (key on lane) and computes P and dS once per (query block, key
+// block) pair — dV^T += dO^T·P and dK^T += Q^T·dS stay in its registers, and its dS blocks (bf16, the B operand it
+// has just fed to the dK product) are kept until every wave is done with V and dO; they then go into LDS over those
+// two tiles as dS[key][query] in the tiles' own row format, and wave w, now owner of QUERY block w, reads them
+// back transposed (ds_read_b64_tr_b16) as the B operand of dQ^T += K^T·dS^T.  Against the two-pass kernel above
+// (which recomputes S, dP, the exponentials and the dropout hashes with the query on the lane to get dS^T in
+// registers) a block pair costs 20 MFMAs, 16 exponentials and 8 hashes instead of 28 / 32 / 16.
+// Needs all of a sequence's blocks resident at once: Lp <= 128 (four waves, one key block each).
+// OCC workgroups per CU: 3 where the LDS footprint allows it (Lp <= 96: the text and visual stacks, whose workgroups
+// are short and latency-bound: -15 % on their launches), 2 for Lp = 128 (the register budget of 3 costs spills there).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.x;
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
+  if (L <= 0) return;
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int64_t row0 = (p.seq_start != nullptr) ? (int64_t)p.seq_start[b] : (int64_t)b * LT;
+  const int Lp = (L + 31) & ~31;
+  const int64_t ldq = 3 * (int64_t)H;
+  char* tQ = smem;
+  char* tK = tQ + LpT * 128;
+  char* tV = tK + LpT * 128;
+  char* tD = tV + LpT * 128;  // dO
+  float* maskv = reinterpret_cast<float*>(tD + LpT * 128);
+  float* lsev = maskv + LpT;
+  float* deltav = lsev + LpT;
+
+  const __bf16* base = p.qkv + row0 * ldq + hd * 64;
+  const __bf16* dob = p.dctx + row0 * H + hd * 64;
+  const __bf16* ob = p.ctx + row0 * H + hd * 64;
+  stage_tile(tQ, base, ldq, L, Lp, wave, lane);
+  stage_tile(tK, base + H, ldq, L, Lp, wave, lane);
+  stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
+  stage_tile(tD, dob, H, L, Lp, wave, lane);
+  for (int i = tid; i < Lp; i += 256) {
+    float mk = -INFINITY, ls = 0.f, dl = 0.f;
+    if (i < L) {
+      mk = (p.mask != nullptr) ? p.mask[row0 + i] : 0.f;
+      ls = p.lse[(int64_t)bh * LT + i];
+      const bf16x8* a = reinterpret_cast<const bf16x8*>(dob + (int64_t)i * H);
+      const bf16x8* c = reinterpret_cast<const bf16x8*>(ob + (int64_t)i * H);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16x8 x = a[j], y = c[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
+      }
+    }
+    maskv[i] = mk;
+    lsev[i] = ls;
+    deltav[i] = dl;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int nb = Lp >> 5;  // <= 4
+  const LaneOffs lo_ = make_lane_offs(lane);
+  __bf16* dq_base = p.dqkv + row0 * ldq + hd * 64;
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const bool owner = wave < nb;
+  const int key = 32 * wave + l31;
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  bf16x8 ds_keep[4][2];
+  if (owner) {
+    // ---------------- phase 1: key block `wave`; key on lane, queries in registers
+    const int kb = wave;
+    const float mk = maskv[key];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      if (qb < nb) {
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tQ, lo_, qb, ks), row_frag_o(tK, lo_, kb, ks), s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_o(tD, lo_, qb, ks), row_frag_o(tV, lo_, kb, ks), dp, 0, 0, 0);
+        }
+        // dropout keep bits: see attn_bwd_kernel pass A
+        uint32_t keepbits = 0xffffu;
+        if (p.drop.thresh16 != 0) {
+          keepbits = 0;
+          const int par = key & 1;
+#pragma unroll
+          for (int r0 = 0; r0 < 16; r0 += 2) {
+            const int rm = r0 + par;
+            const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
+            const uint64_t idx = ((uint64_t)bh * LT + qm) * (uint64_t)LpT + (key & ~1);
+            const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
+            const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+            const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
+            const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
+            keepbits |= (um >= p.drop.thresh16 ? 1u : 0u) << rm;
+            keepbits |= (uo >= p.drop.thresh16 ? 1u : 0u) << (rm ^ 1);
+          }
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lsev + 32 * qb + 8 * t4 + 4 * hh);
+          const f32x4 dl4 = *reinterpret_cast<const f32x4*>(deltav + 32 * qb + 8 * t4 + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * t4 + e;
+            const float pr = __expf(s[r] * 0.125f + mk - ls4[e]);
+            float pd = pr, dpp = dp[r];
+            if (p.drop.thresh16 != 0) {
+              const bool keep = (keepbits >> r) & 1u;
+              pd = keep ? pr * p.drop.scale : 0.f;
+              dpp = keep ? dpp * p.drop.scale : 0.f;
+            }
+            s[r] = pd;                    // dropped-out probabilities (for dV)
+            dp[r] = pr * (dpp - dl4[e]);  // dS
+          }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 pb = pack8(s, st), dsb = pack8(dp, st);
+          ds_keep[qb][st] = dsb;
+          const int blk16 = 2 * qb + st;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tD, lo_, blk16, db), pb, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tQ, lo_, blk16, db), dsb, dk[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#ifdef MVPTR_TIMELINE_BUILD
+  const unsigned long long tl_p1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  __syncthreads();  // nobody reads V / dO any more
+  if (owner) {
+    // dS[key][query] over the V (queries 0..63) and dO (queries 64..127) tiles: row = key, 128-B rows, same chunk swizzle;
+    // register e of pack8(., st) is query 32 qb + 16 st + 8 (e >> 2) + 4 hh + (e & 3)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+      if (qb < nb) {
+        char* ts = (qb >> 1) ? tD : tV;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x4 lo4 = {ds_keep[qb][st][0], ds_keep[qb][st][1], ds_keep[qb][st][2], ds_keep[qb][st][3]};
+          const bf16x4 hi4 = {ds_keep[qb][st][4], ds_keep[qb][st][5], ds_keep[qb][st][6], ds_keep[qb][st][7]};
+          const int ch = 4 * (qb & 1) + 2 * st;
+          *reinterpret_cast<bf16x4*>(ts + tile_off(key, ch) + 8 * hh) = lo4;
+          *reinterpret_cast<bf16x4*>(ts + tile_off(key, ch + 1) + 8 * hh) = hi4;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (owner) {
+    if (key < L) {
+      __bf16* dK = dq_base + (int64_t)key * ldq + H;
+      __bf16* dV = dq_base + (int64_t)key * ldq + 2 * H;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int d = 32 * db + 8 * t4 + 4 * hh;
+          bf16x4 a = {f2bf(dk[db][4 * t4] * 0.125f), f2bf(dk[db][4 * t4 + 1] * 0.125f),
+                      f2bf(dk[db][4 * t4 + 2] * 0.125f), f2bf(dk[db][4 * t4 + 3] * 0.125f)};
+          bf16x4 c = {f2bf(dv[db][4 * t4]), f2bf(dv[db][4 * t4 + 1]), f2bf(dv[db][4 * t4 + 2]), f2bf(dv[db][4 * t4 + 3])};
+          *reinterpret_cast<bf16x4*>(dK + d) = a;
+          *reinterpret_cast<bf16x4*>(dV + d) = c;
+        }
+    }
+    // ---------------- phase 2: query block `wave`; query on lane: dQ^T += K^T · dS^T over all key blocks
+    const int qb = wave, q = key;
+    const char* ts = (qb >> 1) ? tD : tV;
+    f32x16 dq[2] = {zero16(), zero16()};
+    for (int kb = 0; kb < nb; ++kb) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 dsb = tr_frag_o(ts, lo_, 2 * kb + st, qb & 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tK, lo_, 2 * kb + st, db), dsb, dq[db], 0, 0, 0);
+      }
+    }
+    if (q < L) {
+      __bf16* dQ = dq_base + (int64_t)q * ldq;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          bf16x4 a = {f2bf(dq[db][4 * t4] * 0.125f), f2bf(dq[db][4 * t4 + 1] * 0.125f),
+                      f2bf(dq[db][4 * t4 + 2] * 0.125f), f2bf(dq[db][4 * t4 + 3] * 0.125f)};
+          *reinterpret_cast<bf16x4*>(dQ + 32 * db + 8 * t4 + 4 * hh) = a;
+        }
+    }
+  }
+#ifdef MVPTR_TIMELINE_BUILD
+  {
+    // 100-MHz ticks: entry / staging barrier passed / this wave's phase 1 done (slowest by atomicMax) / wave done
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps != nullptr && lane == 0) {
+      unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+      if (wave == 0) {
+        o[0] = tl0;
+        o[1] = tl1;
+        o[3] = (unsigned long long)L;
+      }
+      atomicMax(o + 2, tl2);
+      atomicMax(o + 4, tl_p1);
+    }
+  }
+#endif
+}
+
+// diagnostic build only: MVPTR_ATTN_TWO_PASS=1 keeps the two-pass kernel for every length (A/B measurements)
+bool two_pass_forced() {
+#ifdef MVPTR_DIAG_BUILD
+  static const bool v = [] {
+    const char* e = getenv("MVPTR_ATTN_TWO_PASS");
+    return e && e[0] == '1';
+  }();
+  return v;
+#else
+  return false;
+#endif
+}
+
 int check_common(const char* who, const void* qkv, int B, int L, int heads) {
   if (B <= 0 || L <= 0 || heads <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: B, L, heads must be > 0", who);
   if (L > 256) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: L=%d > 256 not supported", who, L);
@@ -508,9 +740,19 @@ extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add
   a.stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
   const size_t lds = (size_t)a.Lp * 128 * 4 + (size_t)a.Lp * 12;
-  hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // sequences of <= 128 rows (every stack of the pre-training step): the one-pass kernel; longer ones: two passes
+  const bool fused = a.Lp <= 128 && !two_pass_forced();
+  const bool occ3 = fused && a.Lp <= 96;
+  const void* fn = !fused ? (const void*)attn_bwd_kernel
+                          : (occ3 ? (const void*)attn_bwd_fused_kernel<3> : (const void*)attn_bwd_fused_kernel<2>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_bwd: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  if (!fused)
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  else if (occ3)
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<3>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
   MVPTR_CHECK_LAUNCH("attention_bwd");
   return MVPTR_OK;
 }

@@ -36,6 +36,10 @@ for M in (37748, 10917):
     t_fd = timeit(lambda: hip.layernorm_fwd(z, g, b, 1e-12, drop=drop))
     t_b = timeit(lambda: hip.layernorm_bwd(dy, z, mean, rstd, g, dg, db, dbias))
     t_bd = timeit(lambda: hip.layernorm_bwd(dy, z, mean, rstd, g, dg, db, dbias, dense_drop=drop))
+    drop2 = hip.make_dropout(0.1, 99)
+    t_b2 = timeit(lambda: hip.layernorm_bwd(dy, z, mean, rstd, g, dg, db, dbias, y_drop=drop2, dense_drop=drop))
     by = M * H * 2
+    print("M=%5d  bwd with both dropouts (output dropout of the layer above re-applied to dy + dense dropout output) %6.1f us (%.2f TB/s)"
+          % (M, t_b2, 4 * by / t_b2 / 1e6), flush=True)
     print("M=%5d  fwd %6.1f us (%.2f TB/s) | fwd+dropout %6.1f us (%.2f TB/s) | bwd %6.1f us (%.2f TB/s) | bwd+dense-dropout output %6.1f us (%.2f TB/s)"
           % (M, t_f, 2 * by / t_f / 1e6, t_fd, 2 * by / t_fd / 1e6, t_b, 3 * by / t_b / 1e6, t_bd, 4 * by / t_bd / 1e6), flush=True)

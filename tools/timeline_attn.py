@@ -58,5 +58,11 @@ for lo, hi in ((1, 32), (33, 64), (65, 96), (97, 128)):
     m = (L >= lo) & (L <= hi)
     if m.any():
         print("  L %3d-%3d (nb=%d): %5d workgroups, prologue %.2f us, tasks %.2f us" % (lo, hi, hi // 32, m.sum(), pro[m].mean(), loop[m].mean()))
+if s[:, 4].any():    # the one-pass kernel also stamps the end of its phase 1 (P, dS, dK, dV), slowest wave
+    p1 = (s[:, 4] - s[:, 1]) / 100.0
+    for lo, hi in ((1, 32), (33, 64), (65, 96), (97, 128)):
+        m = (L >= lo) & (L <= hi)
+        if m.any():
+            print("  L %3d-%3d: phase 1 %.2f us, dS hand-over + dK/dV stores + phase 2 (dQ) %.2f us" % (lo, hi, p1[m].mean(), (loop[m] - p1[m]).mean()))
 span = (s[:, 2].max() - s[:, 0].min()) / 100.0
 print("  kernel span from the stamps %.1f us; sum of workgroup times / 512 slots = %.1f us" % (span, (pro + loop).sum() / 512))
