@@ -61,3 +61,22 @@ print("idle time along the step (window = 1/%d of the step; us of idle per step 
 for w in range(W):
     top = max(names[w].items(), key=lambda kv: kv[1])[0] if names[w] else "-"
     print("  %2d  idle %7.1f us   %s" % (w, idle[w], top))
+
+# steady state (the same five steps): launches and kernel time per step, this library's kernels against everything else
+ours = lambda n: ("anonymous namespace" in n or "_GLOBAL__N_" in n) and "at::native" not in n   # noqa: E731
+agg = {}
+for s_, e_, n_ in seg:
+    k = n_[:96]
+    a = agg.setdefault(k, [0, 0])
+    a[0] += 1
+    a[1] += e_ - s_
+mine = [(v[1] / 5e6, v[0] / 5.0, k) for k, v in agg.items() if ours(k)]
+other = [(v[1] / 5e6, v[0] / 5.0, k) for k, v in agg.items() if not ours(k)]
+print("steady state per step: %d launches, %.2f ms of kernel time; this library %d launches / %.2f ms; torch, rocBLAS and "
+      "runtime copies %d launches / %.3f ms" % (len(seg) // 5, sum(e - s for s, e, _ in seg) / 5e6, round(sum(c for _, c, _ in mine)),
+                                                sum(t for t, _, _ in mine), round(sum(c for _, c, _ in other)), sum(t for t, _, _ in other)))
+for t, c, k in sorted(mine, reverse=True)[:24]:
+    print("   %7.3f ms %6.1f x  %s" % (t, c, k))
+print("  not this library:")
+for t, c, k in sorted(other, reverse=True)[:40]:
+    print("   %7.3f ms %6.1f x  %s" % (t, c, k))

@@ -1,6 +1,6 @@
 # Round-3 profiles (run on the GPU box through gpurun): kernel summaries of the timed bench region, in-step and replay
-# roofline of the dominant kernel, PMC traffic, region-feature path, FETCH_SIZE calibration.  Output: gpurun_out/r03p/
-O=gpurun_out/r03p; mkdir -p $O
+# roofline of the dominant kernel, PMC traffic, region-feature path, FETCH_SIZE calibration.  Output: gpurun_out/r03prof/
+O=gpurun_out/r03prof; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 P="--kernel-trace --stats --output-format csv"
@@ -27,6 +27,9 @@ python3 tools/features_json.py $O/r03_region_features.json $O/feat/feat_kernel_s
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE $Q -d $O/pmc_mfma -- python3 tools/prof_dominant.py 2 >> $O/pmc.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE $Q -d $O/pmc_lds -- python3 tools/prof_dominant.py 2 >> $O/pmc.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_mfma $O/pmc_lds > $O/r03_pmc_mfma_lds.csv 2>> $O/pmc.log
+# steady-state launch table and GPU idle time of the last five steps (from the traces, before they are deleted)
+python3 tools/gpu_idle.py $O/packed/packed_kernel_trace.csv > $O/r03_step_launches_packed.txt 2>&1
+python3 tools/gpu_idle.py $O/fixed/fixed_kernel_trace.csv > $O/r03_step_launches_fixed.txt 2>&1
 # keep only the summaries (the traces are tens of MB)
 find $O -name "*kernel_trace.csv" -size +2M -delete
 find $O -name "*counter_collection.csv" -size +8M -delete
