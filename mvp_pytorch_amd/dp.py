@@ -151,20 +151,28 @@ class GradSync:
             if cur:
                 self._close(cur, cur_n, hot)
         self.n_hot = sum(1 for b in self.buckets if b["hot"])
+        # one allocation for all buckets (each starting on a 512-byte boundary): zero_grad() is one fill, the norm of
+        # the clip one pass
+        total = 0
+        for b in self.buckets:
+            b["base"] = total
+            total += (b["n"] + 127) & ~127
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self._arena = torch.zeros(total, device=dev, dtype=torch.float32)
+        for idx, b in enumerate(self.buckets):
+            b["flat"] = self._arena[b["base"]:b["base"] + b["n"]]
+            for p, off, k in b["items"]:
+                self.where[p] = idx
+                self.span[p] = (off, k, b["flat"].data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
 
     def _close(self, items, n, is_hot):
-        p0 = items[0][0]
-        idx = len(self.buckets)
-        flat = torch.zeros(n, device=p0.device, dtype=torch.float32)
-        self.buckets.append(dict(flat=flat, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set(),
+        self.buckets.append(dict(flat=None, n=n, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set(),
                                  rows_of=None, union=None))
-        for p, off, k in items:
-            self.where[p] = idx
-            self.span[p] = (off, k, flat.data_ptr() + 4 * off)   # O(1) lookups in the per-parameter hook
 
     def flats(self):
-        """The flat f32 gradient buffers (global-norm clipping reads these instead of ~400 tensors)."""
-        return [b["flat"] for b in self.buckets]
+        """The flat f32 gradient buffers (global-norm clipping reads these instead of ~400 tensors): the whole arena
+        as one buffer (the alignment gaps between buckets stay zero)."""
+        return [self._arena]
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
@@ -176,8 +184,8 @@ class GradSync:
             for p in self.params:
                 p.grad = None
             self._build()
+        self._arena.zero_()
         for b in self.buckets:
-            b["flat"].zero_()
             b["work"] = b["wire"] = b["union"] = None
             b["streams"] = set()
             for p, off, n in b["items"]:
