@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from mvp_pytorch_amd import modeling, train  # noqa: E402
+from mvp_pytorch_amd import dp, modeling, train  # noqa: E402
 from mvp_pytorch_amd.synthetic import synthetic_batch  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -19,12 +19,14 @@ dims = dict(B=B, T=70, P=5, G=20, R=50)
 torch.manual_seed(0)
 model = modeling.BiBertImgForPreTraining(modeling.make_config(bench.BASE_CFG)).to(dev).train()
 opt, sched = train.build_optimizer(model, lr=1e-4, adam_epsilon=1e-8, weight_decay=0.01, warmup_steps=10, t_total=steps)
+sync = dp.GradSync(model)      # gradient arena + fused global-norm clip (max_grad_norm below), as a training job runs it
 # a small pool of distinct batches generated up front (the generator is a Python loop), cycled + re-seeded lengths
 pool = [synthetic_batch(dims, bench.BASE_CFG, 1000 + i, device=dev) for i in range(12)]
 hist, mem = [], []
 t0 = time.time()
 for s in range(steps):
-    losses = train.pretrain_step(model, pool[s % len(pool)], opt, sched, max_tag_length=dims["G"], return_losses=True)
+    losses = train.pretrain_step(model, pool[s % len(pool)], opt, sched, max_tag_length=dims["G"], return_losses=True,
+                                 grad_sync=sync, max_grad_norm=10.0)
     if s % 10 == 0 or s == steps - 1:
         vals = [float(x) for x in losses]
         hist.append((s, vals))
