@@ -119,6 +119,14 @@ typedef struct {
   float* colsum;   /* optional f32[N] */
 } mvptr_tn_problem;
 int mvptr_gemm_tn_multi(const mvptr_tn_problem* problems, int count, void* stream);
+/* The same with a caller-provided workspace for the per-split partial tiles ("slabs"): launches of 6 000 .. 24 000 token
+ * rows then write every M-split's 256x256 f32 partial tile with plain stores into ws and a second kernel adds a tile's
+ * slabs into dW in split order — bitwise reproducible weight gradients, and faster where the f32 atomics of the splits
+ * are a quarter to a third of the launch (attention pair at M = 10 917: 91 -> 68 us).  mvptr_gemm_tn_ws_bytes: the
+ * bytes such a call would use (0: it writes out with atomics; only shapes and M are read).  ws NULL or too small:
+ * atomics.  Groups of one call run one after the other on the stream and share ws. */
+int mvptr_gemm_tn_multi_ws(const mvptr_tn_problem* problems, int count, void* ws, int64_t ws_bytes, void* stream);
+int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* problems, int count);
 
 /* Column sums: out[n] += sum_m X[m,n] (X bf16 [M, ldx]); bias gradients. */
 int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream);

@@ -43,6 +43,9 @@ struct GemmTnGroup {
   int base[MVPTR_TN_MAX_GROUP + 1];
   int count;
   int splits;
+  // "Q" kernel, slab write-out: workgroup g stores its 256x256 f32 partial tile as slab g (256 KiB, in register order)
+  // of this caller-provided buffer and tn_reduce_kernel adds a tile's slabs in split order; NULL = f32 atomics
+  float* slab;
 };
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
 // certifies stage st+1 sits between the two 16-row halves of stage st, and what follows it (issue of
 // stage st+STAGES into the buffer just freed, fragment reads of the next stage's first half) runs
 // under the 16 MFMAs of the second half, whose fragments are already in registers.
-template <int STAGES>
+template <int STAGES, bool SLAB>
 __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   constexpr int TM_ = 32;
   constexpr int SUB_B = TM_ * 256;     // one 32 x 128 bf16 sub-tile (8 KiB)
@@ -528,6 +531,31 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31 = lane_e & 31, hh = lane_e >> 5;
+  if constexpr (SLAB) {
+    // slab mode (few-row launches, where the atomics of the M-splits are a quarter to a third of the launch): the
+    // partial tile goes out as plain 16-byte stores, 1 KiB contiguous per wave instruction (float index
+    // ((((wave*4 + nb)*4 + kb)*4 + i)*64 + lane)*4 + j holds accumulator register r = 4 i + j); the sum over the
+    // splits is taken by tn_reduce_kernel in split order: bitwise reproducible
+    float* sl = grp.slab + (int64_t)gidx * 65536 + wave * 16384 + lane_e * 4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = {acc[nb][kb][4 * i], acc[nb][kb][4 * i + 1], acc[nb][kb][4 * i + 2], acc[nb][kb][4 * i + 3]};
+          *reinterpret_cast<f32x4*>(sl + ((nb * 4 + kb) * 4 + i) * 256) = v;
+        }
+    if (do_bias) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
+        const int n = n0 + wn * 128 + nb * 32 + l31;
+        if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
+      }
+    }
+    return;
+  }
   const int nw = n0 + wn * 128 + 4 * hh, kw = k0 + wk * 128 + l31;
   const bool full = (n0 + TN_ <= p.N) && (k0 + TKW <= p.K);
   float* wbase = p.dW + (int64_t)nw * p.ldw + kw;
@@ -562,6 +590,60 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
   }
 }
 
+
+// Sum of the M-splits' slabs of gemm_tn_q_kernel into dW (+=), splits in ascending order: the result does not depend
+// on the order in which workgroups finished (bitwise reproducible, unlike the atomic write-out).  One thread per
+// 16-byte slab position = four rows n..n+3 of one column k; a wave reads 1 KiB contiguous per split and updates
+// 2 x 128-byte row segments per row.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
+  const int splits = grp.splits;
+  const int tile_lin = blockIdx.x >> 6;
+  GemmTnArgs p = grp.prob[0];
+  int pbase = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TN_MAX_GROUP; ++i)
+    if (i < grp.count && tile_lin * splits >= grp.base[i]) {
+      p = grp.prob[i];
+      pbase = grp.base[i];
+    }
+  const int nt = p.tiles_n * p.tiles_k;
+  const int t = tile_lin - pbase / splits;
+  int tn, tk;
+  if (p.tiles_n < p.tiles_k && !p.order_n_major) {
+    tk = t / p.tiles_n;
+    tn = t - tk * p.tiles_n;
+  } else {
+    tn = t / p.tiles_k;
+    tk = t - tn * p.tiles_k;
+  }
+  const int e4 = (blockIdx.x & 63) * 256 + threadIdx.x;   // 16-byte position inside the tile's slab
+  const int lane = e4 & 63;
+  const f32x4* src = reinterpret_cast<const f32x4*>(grp.slab) + ((int64_t)(pbase + t) * 16384 + e4);
+  const int64_t sstride = (int64_t)nt * 16384;
+  // rows_per_split covers M with `active` splits (the planner's count may leave trailing ones empty)
+  const int active = min(splits, (p.M + p.rows_per_split - 1) / p.rows_per_split);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int sidx = 0;
+  for (; sidx + 4 <= active; sidx += 4) {
+    const f32x4 a = src[(int64_t)sidx * sstride], b = src[(int64_t)(sidx + 1) * sstride];
+    const f32x4 c = src[(int64_t)(sidx + 2) * sstride], d = src[(int64_t)(sidx + 3) * sstride];
+    sum += a;
+    sum += b;
+    sum += c;
+    sum += d;
+  }
+  for (; sidx < active; ++sidx) sum += src[(int64_t)sidx * sstride];
+  // e4 = (((wave*4 + nb)*4 + kb)*4 + i)*64 + lane, four waves 2(n) x 2(k)
+  const int i = (e4 >> 6) & 3, kb = (e4 >> 8) & 3, nb = (e4 >> 10) & 3, wave = e4 >> 12;
+  const int n = tn * TN_ + (wave >> 1) * 128 + nb * 32 + 8 * i + 4 * (lane >> 5);
+  const int k = tk * 256 + (wave & 1) * 128 + kb * 32 + (lane & 31);
+  if (k < p.K) {
+    float* o = p.dW + (int64_t)n * p.ldw + k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n + j < p.N) o[(int64_t)j * p.ldw] += sum[j];
+  }
+}
 
 __global__ void colsum_kernel(const __bf16* X, int64_t ldx, int M, int N, float* out,
                               int rows_per_block) {
@@ -599,9 +681,17 @@ int launch_tn(const GemmTnGroup& g, hipStream_t stream) {
 template <int STAGES>
 int launch_tn_q(GemmTnGroup& g, hipStream_t stream) {
   const int lds_b = STAGES * 4 * 32 * 256;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_q_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+  const void* fn = g.slab ? (const void*)gemm_tn_q_kernel<STAGES, true> : (const void*)gemm_tn_q_kernel<STAGES, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
+  if (g.slab) {
+    hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES, true>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
+    MVPTR_CHECK_LAUNCH("gemm_tn");
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((g.base[g.count] / g.splits) * 64), dim3(256), 0, stream, g);
+    MVPTR_CHECK_LAUNCH("gemm_tn reduce");
+    return MVPTR_OK;
+  }
+  hipLaunchKernelGGL((gemm_tn_q_kernel<STAGES, false>), dim3(g.base[g.count]), dim3(256), lds_b, stream, g);
   MVPTR_CHECK_LAUNCH("gemm_tn");
   return MVPTR_OK;
 }
@@ -614,7 +704,7 @@ struct TnPlan {
 // Estimated time of one configuration for `tiles` output tiles of one launch (all problems of a
 // group share M, so they share the split count): whole rounds of workgroups x steps per split,
 // plus the f32 atomics of every M-split (~1.3 TB/s chip-wide, partly overlapped).
-TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false) {
+TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad = false, bool slab = false) {
   const int slots = (tm == 32 && ksub == 1) ? 512 : 256;
   // microseconds per 64 token rows of one workgroup (measured on MI355X, round 1; "Q": round 2)
   const double t64 = quad ? 1.5 : (ksub == 2) ? (tm == 64 ? 1.75 : 3.1) : (tm == 64 ? 1.7 : 2.7);
@@ -624,8 +714,9 @@ TnPlan plan_tn(int M, int64_t out_elems, int tiles, int tm, int ksub, bool quad 
     const double rounds = (double)((tiles * sp + slots - 1) / slots);
     const double steps = (double)((M + sp * 64 - 1) / (sp * 64));
     const double out_b = (double)out_elems * 4.0;
-    // write-out: f32 atomics (~1.3 TB/s chip-wide, partly overlapped)
-    const double wr = sp * out_b / 1.3e6 * 0.7;
+    // write-out: f32 atomics (~1.3 TB/s chip-wide, partly overlapped), or plain slab stores (~6.5 TB/s) + the reduce
+    // kernel's reads of every slab (mostly L2 / Infinity-Cache hits) + its launch
+    const double wr = (slab && sp >= 2) ? sp * out_b / 6.5e6 + (sp + 2) * out_b / 5.0e6 + 4.0 : sp * out_b / 1.3e6 * 0.7;
     const double cost = rounds * steps * t64 + wr;
     if (cost < best.cost) {
       best.cost = cost;
@@ -645,13 +736,22 @@ int check_problem(const mvptr_tn_problem& q) {
 }
 
 // one launch for `count` problems with the same M
-int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
+// Slab write-out of the "Q" kernel is used for launches of at most this many token rows (measured, round 2 tables in
+// profiles/r02_experiments.txt: attention pair 91 -> 68 us and FFN pair 124 -> 111 us at M = 10 917, 118 -> 97 at 19 200;
+// at 37 748 the FFN pair loses 3 %): where the atomics of the M-splits are a quarter to a third of the launch.
+constexpr int TN_SLAB_MAX_ROWS = 24000;
+
+// one launch for `count` problems with the same M.  ws / ws_bytes: caller's slab workspace (may be NULL); need != NULL:
+// plan only — *need = slab bytes this group would use (0: atomics), nothing is launched
+int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, float* ws, int64_t ws_bytes, int64_t* need,
+              bool allow_slab = true) {
   const int M = probs[0].M;
   // four configurations (see gemm_tn_kernel); MVPTR_GEMM_TN = "32" | "64" | "k2" | "K" forces one
   // (tuning knob).  The 256x256 tiles measured no faster than 256x128 at two workgroups per CU on
   // this model's shapes, so only the 256x128 tiles compete by default.
   const int cfg_tm[5] = {32, 64, 32, 64, 32}, cfg_ks[5] = {1, 1, 2, 2, 2};
   TnPlan plans[5];
+  bool slab_plan = false;
   for (int c = 0; c < 5; ++c) {
     int tiles = 0;
     int64_t out_elems = 0;
@@ -660,6 +760,14 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
       out_elems += (int64_t)probs[i].N * probs[i].K;
     }
     plans[c] = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], c == 4);
+    if (c == 4 && allow_slab && M >= 6000 && M <= TN_SLAB_MAX_ROWS && (ws != nullptr || need != nullptr) &&
+        mvptr_knobs().gemm_tn[0] == 0 && (mvptr_knobs().nt_exp & (1 << 12)) == 0) {   // MVPTR_NT_EXP bit 12 (diagnostic build): atomics everywhere
+      const TnPlan sl = plan_tn(M, out_elems, tiles, cfg_tm[c], cfg_ks[c], true, true);
+      if (sl.splits >= 2) {
+        plans[c] = sl;
+        slab_plan = true;
+      }
+    }
   }
   // "Q" (256x256 tile, four waves of 128x128) wins from ~6 k token rows up (tools/sweep_tn.py,
   // tools/sweep_tn_group.py: 1.0-1.15 PF/s against 0.7-0.8 at M >= 19 k, +8 % at 11 k, -7 % at 3 k)
@@ -709,6 +817,18 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 #ifdef MVPTR_TIMELINE_BUILD
   for (int i = 0; i < MVPTR_TN_MAX_GROUP; ++i) g.prob[i].stamps = (unsigned long long*)mvptr_knobs().stamps;
 #endif
+  g.slab = nullptr;
+  const bool slab = slab_plan && pick == 4 && splits >= 2;
+  const int64_t slab_bytes = slab ? (int64_t)g.base[count] * 65536 * (int64_t)sizeof(float) : 0;
+  if (need != nullptr) {
+    *need = slab_bytes;
+    return MVPTR_OK;
+  }
+  if (slab) {
+    if (ws == nullptr || ws_bytes < slab_bytes || ((uintptr_t)ws & 15))
+      return run_group(probs, count, stream, nullptr, 0, nullptr, false);   // workspace too small: atomics with their own split plan
+    g.slab = ws;
+  }
   if (pick == 4) return launch_tn_q<4>(g, stream);
   if (pl.ksub == 2 && pl.tm == 64) return launch_tn<64, 2, 2>(g, stream);
   if (pl.ksub == 2) return launch_tn<32, 2, 3>(g, stream);
@@ -718,24 +838,44 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mvptr_gemm_tn_multi(const mvptr_tn_problem* probs, int count, void* stream) {
+namespace {
+int tn_multi(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, int64_t* need, void* stream) {
   if (!probs || count <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_tn_multi: no problems");
   for (int i = 0; i < count; ++i) {
     const int rc = check_problem(probs[i]);
     if (rc != MVPTR_OK) return rc;
   }
   // problems are grouped while they share M (one split plan per launch); MVPTR_TN_GROUP=0 issues
-  // them one by one (A/B knob)
+  // them one by one (A/B knob, diagnostic build)
   const int max_group = (mvptr_knobs().tn_group == 0) ? 1 : MVPTR_TN_MAX_GROUP;
+  int64_t most = 0;
   int i = 0;
   while (i < count) {
     int j = i + 1;
     while (j < count && j - i < max_group && probs[j].M == probs[i].M) ++j;
-    const int rc = run_group(probs + i, j - i, (hipStream_t)stream);
+    int64_t nb = 0;
+    const int rc = run_group(probs + i, j - i, (hipStream_t)stream, (float*)ws, ws_bytes, need ? &nb : nullptr);
     if (rc != MVPTR_OK) return rc;
+    if (nb > most) most = nb;   // the groups of one call run one after the other on the stream: they share the buffer
     i = j;
   }
+  if (need) *need = most;
   return MVPTR_OK;
+}
+}  // namespace
+
+extern "C" int mvptr_gemm_tn_multi(const mvptr_tn_problem* probs, int count, void* stream) {
+  return tn_multi(probs, count, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int mvptr_gemm_tn_multi_ws(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, void* stream) {
+  return tn_multi(probs, count, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* probs, int count) {
+  int64_t need = 0;
+  if (tn_multi(probs, count, nullptr, 0, &need, nullptr) != MVPTR_OK) return -1;
+  return need;
 }
 
 extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,

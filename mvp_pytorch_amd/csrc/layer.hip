@@ -80,6 +80,32 @@ extern "C" int64_t mvptr_layer_saved_bytes(const mvptr_layer_desc* d) {
   return carve(d, nullptr).total;
 }
 
+namespace {
+// slab workspace the two grouped weight-gradient launches of a layer may use (mvptr_gemm_tn_ws_bytes: 0 when they write
+// out with atomics): planned from the shapes alone
+int64_t wgrad_slab_bytes(int M, int H, int I) {
+  mvptr_tn_problem q[2];
+  auto fill = [&](mvptr_tn_problem& t, int N, int K) {
+    t.A = t.B = (const void*)(uintptr_t)4096;   // shape-only planning: the pointers are never dereferenced
+    t.dW = (float*)(uintptr_t)4096;
+    t.lda = N;
+    t.ldb = K;
+    t.M = M;
+    t.N = N;
+    t.K = K;
+    t.ldw = K;
+    t.colsum = nullptr;
+  };
+  fill(q[0], H, I);
+  fill(q[1], I, H);
+  const int64_t a = mvptr_gemm_tn_ws_bytes(q, 2);
+  fill(q[0], 3 * H, H);
+  fill(q[1], H, H);
+  const int64_t b = mvptr_gemm_tn_ws_bytes(q, 2);
+  return a > b ? a : b;
+}
+}  // namespace
+
 extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   if (check_desc("layer_workspace_bytes", d)) return -1;
   const int64_t M = layer_rows(d), H = d->H;
@@ -88,7 +114,7 @@ extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   // until the grouped weight-gradient launch at the end of the layer) + LayerNorm partials
   (void)W;
   return 5 * al256(M * H * 2) + al256(M * d->I * 2) + al256(M * 3 * H * 2) +
-         al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H));
+         al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H)) + al256(wgrad_slab_bytes((int)M, (int)H, d->I));
 }
 
 extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
@@ -142,6 +168,8 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   char* bufQ = bufU + al256((int64_t)M * I * 2);        // dqkv [M, 3H]
   char* lnws = bufQ + al256((int64_t)M * 3 * H * 2);
   const int64_t lnws_bytes = mvptr_layernorm_bwd_ws_bytes(M, H);
+  char* slabws = lnws + al256(lnws_bytes);              // per-split partial tiles of the weight-gradient launches (few-row stacks)
+  const int64_t slabws_bytes = wgrad_slab_bytes(M, H, I);
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
   const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
@@ -176,7 +204,7 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache
   if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, nullptr);
-  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi_ws(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, stream));
   nwg = 0;
   RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
                     nullptr, nullptr, stream));
@@ -205,6 +233,6 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
     wg[0] = wg[1];
     wg[1] = t;
   }
-  if (nwg > 0) RUN(mvptr_gemm_tn_multi(wg, nwg, stream));
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi_ws(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, stream));
   return MVPTR_OK;
 }

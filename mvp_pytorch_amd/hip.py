@@ -32,7 +32,7 @@ SYMBOLS = [
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
-    "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd",
+    "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
 ]
 
 
@@ -95,6 +95,9 @@ def load():
     lib.mvptr_gemm_nt_splitk.argtypes = [P, I64, P, I64, I, I, I, I, P, I64, P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
+    lib.mvptr_gemm_tn_multi_ws.argtypes = [POINTER(TnProblem), I, P, I64, P]
+    lib.mvptr_gemm_tn_ws_bytes.restype = c_int64
+    lib.mvptr_gemm_tn_ws_bytes.argtypes = [POINTER(TnProblem), I]
     lib.mvptr_colsum.argtypes = [P, I64, I, I, P, P]
     lib.mvptr_cast_multi.argtypes = [P, P, I, I, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
@@ -225,7 +228,7 @@ def gemm_tn(dy, x, dw, n=None, k=None, colsum=None):
     return dw
 
 
-def gemm_tn_multi(problems):
+def gemm_tn_multi(problems, slab_workspace=True):
     """problems: list of (dy, x, dw, colsum-or-None); one grouped launch per run of equal M."""
     arr = (TnProblem * len(problems))()
     for q, (dy, x, dw, cs) in zip(arr, problems):
@@ -234,7 +237,15 @@ def gemm_tn_multi(problems):
         q.A, q.lda, q.B, q.ldb = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
         q.M, q.N, q.K = dy.shape[0], dy.shape[1], x.shape[1]
         q.dW, q.ldw, q.colsum = dw.data_ptr(), dw.stride(0), (cs.data_ptr() if cs is not None else None)
-    _check(load().mvptr_gemm_tn_multi(arr, len(problems), _stream()))
+    lib = load()
+    if slab_workspace:
+        # few-row launches (6 000 .. 24 000 rows): per-split partial tiles + an ordered reduction instead of f32 atomics
+        need = int(lib.mvptr_gemm_tn_ws_bytes(arr, len(problems)))
+        if need > 0:
+            ws = torch.empty(need, device=problems[0][0].device, dtype=torch.uint8)
+            _check(lib.mvptr_gemm_tn_multi_ws(arr, len(problems), _p(ws), need, _stream()))
+            return
+    _check(lib.mvptr_gemm_tn_multi(arr, len(problems), _stream()))
 
 
 def colsum(x, out, n=None):

@@ -121,7 +121,7 @@ def test_gemm_tn(dev, M, N, K):
     assert _rel(dw, 2 * ref) < 1e-5
 
 
-@pytest.mark.parametrize("M", [700, 6400])
+@pytest.mark.parametrize("M", [700, 6400, 10917, 37748])
 def test_gemm_tn_multi(dev, M):
     """Grouped launch: four problems sharing M (an encoder layer's weight gradients) and one with a
     different M (split into its own launch) give the same results as separate calls."""
@@ -146,6 +146,40 @@ def test_gemm_tn_multi(dev, M):
         assert _rel(dw, ref) < 1e-5
         if cs is not None:
             assert _rel(cs, dy.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("M", [6400, 10917, 20011])
+def test_gemm_tn_slab_write_out_is_exact_and_reproducible(dev, M):
+    """Few-row grouped launches (6 000 .. 24 000 rows) write per-split partial tiles into the caller's workspace and add
+    them in split order (mvptr_gemm_tn_multi_ws): same values as the atomic write-out to f32 rounding, ACCUMULATED into
+    dW like it, bitwise identical from run to run, and odd shapes (partial tiles at the N / K edge) included."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M)
+    shapes = [(768, 768), (2304, 768), (520, 1000)]
+    data = []
+    for N, K in shapes:
+        dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+        x = _bf(torch.randn(M, K, generator=g)).to(dev)
+        data.append((dy, x, torch.randn(N, K, generator=g).to(dev)))
+    outs = []
+    for slab in (True, True, False):
+        probs = [(dy, x, init.clone(), torch.zeros(dy.shape[1], device=dev)) for dy, x, init in data]
+        arr_need = None
+        if slab:
+            arr = (hip.TnProblem * len(probs))()
+            for q, (dy, x, dw, cs) in zip(arr, probs):
+                q.A, q.lda, q.B, q.ldb, q.M, q.N, q.K = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, dy.shape[1], x.shape[1]
+                q.dW, q.ldw, q.colsum = dw.data_ptr(), dw.stride(0), cs.data_ptr()
+            arr_need = int(hip.load().mvptr_gemm_tn_ws_bytes(arr, len(probs)))
+            assert arr_need > 0, "these row counts are in the slab range"
+        hip.gemm_tn_multi(probs, slab_workspace=slab)
+        torch.cuda.synchronize()
+        outs.append([(dw, cs) for _, _, dw, cs in probs])
+    for (dy, x, init), (dw_a, cs_a), (dw_b, _), (dw_c, cs_c) in zip(data, outs[0], outs[1], outs[2]):
+        ref = init + dy.float().t() @ x.float()
+        assert _rel(dw_a, ref) < 1e-5 and _rel(dw_c, ref) < 1e-5
+        assert torch.equal(dw_a, dw_b)                 # fixed summation order
+        assert _rel(cs_a, dy.float().sum(0)) < 1e-5 and _rel(cs_c, dy.float().sum(0)) < 1e-5
 
 
 def test_gemm_tn_layout_exact(dev):
