@@ -16,10 +16,14 @@ tr = json.load(open(traffic))
 
 
 def avg_us(path, frag):
+    """mean duration and call count over EVERY kernel whose name contains frag (template variants of one kernel —
+    gemm_tn_q_kernel<4, false> / <4, true> — are one row each in the summary)"""
+    tot, calls = 0.0, 0
     for r in csv.DictReader(open(path)):
         if frag in r["Name"]:
-            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
-    return None, 0
+            tot += float(r["TotalDurationNs"]) / 1e3
+            calls += int(r["Calls"])
+    return (tot / calls, calls) if calls else (None, 0)
 
 
 def mix(Ms):
@@ -30,7 +34,7 @@ def mix(Ms):
     return sum(fl) / len(fl), sum(by) / len(by)
 
 
-res = {"_what": "gemm_tn_q_kernel<4> (grouped weight gradients, 36 launches per step), mean over the step's launch mix; "
+res = {"_what": "gemm_tn_q_kernel<4, slab?> (grouped weight gradients, 36 launches per step; atomic write-out for the joint stack, per-split slabs + tn_reduce_kernel for the text / visual stacks), mean over the step's launch mix; "
                 "duration = rocprofv3 --kernel-trace --stats AverageNs of tools/prof_dominant.py, gemm_tn_q_kernel + the tn_reduce_kernel "
                 "that sums its per-split slabs (one launch = both); FLOPs = 2MNK summed over the "
                 "problems of a launch; algorithmic bytes = operands read once + f32 outputs accumulated once; peak = 2500 TFLOP/s "
@@ -51,6 +55,9 @@ for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots
                 "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
     if bench_csv[key]:
         us_in, calls_in = avg_us(bench_csv[key], "gemm_tn_q_kernel")
+        red_in, red_calls = avg_us(bench_csv[key], "tn_reduce_kernel")
+        if us_in and red_in:
+            us_in += red_in * red_calls / calls_in      # the reduce kernel of the slab launches belongs to its launch
         if us_in:
             res[key]["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
                                    "frac_of_peak": flop / us_in / 1e6 / PEAK,
