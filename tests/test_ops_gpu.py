@@ -175,6 +175,16 @@ def test_gemm_tn_slab_write_out_is_exact_and_reproducible(dev, M):
         hip.gemm_tn_multi(probs, slab_workspace=slab)
         torch.cuda.synchronize()
         outs.append([(dw, cs) for _, _, dw, cs in probs])
+    # a workspace that is too small (or NULL) is not an error: the launch falls back to the atomic write-out
+    probs = [(dy, x, init.clone(), None) for dy, x, init in data]
+    arr = (hip.TnProblem * len(probs))()
+    for q, (dy, x, dw, cs) in zip(arr, probs):
+        q.A, q.lda, q.B, q.ldb, q.M, q.N, q.K = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, dy.shape[1], x.shape[1]
+        q.dW, q.ldw, q.colsum = dw.data_ptr(), dw.stride(0), None
+    small = torch.empty(4096, device=dev, dtype=torch.uint8)
+    hip._check(hip.load().mvptr_gemm_tn_multi_ws(arr, len(probs), hip._p(small), small.numel(), hip._stream()))
+    for (dy, x, init), (_, _, dw, _) in zip(data, probs):
+        assert _rel(dw, init + dy.float().t() @ x.float()) < 1e-5
     for (dy, x, init), (dw_a, cs_a), (dw_b, _), (dw_c, cs_c) in zip(data, outs[0], outs[1], outs[2]):
         ref = init + dy.float().t() @ x.float()
         assert _rel(dw_a, ref) < 1e-5 and _rel(dw_c, ref) < 1e-5
