@@ -7,6 +7,7 @@ import json
 import sys
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import engine
@@ -243,18 +244,31 @@ class BertLMPredictionHead(nn.Module):
         return scores.reshape(h.shape[:-1] + (scores.shape[-1],))
 
 
+class HeadLinear(nn.Linear):
+    """nn.Linear for the B-row f32 heads (fine-tune classifiers vl:1628-1640,1745-1756, the 3129-way VQA decoder
+    modeling_bert.py:518-533, the QA head vl:1207): on a HIP device the product runs on the f32 MFMA kernel
+    (engine.SmallLinearFn -> mvptr_sgemm_small: exact f32 operands, bias fused, gradients into the arena) instead of a
+    BLAS call that serves these few-row shapes with a single tile.  Same parameters / state_dict as nn.Linear."""
+
+    def forward(self, x, bias=None):
+        b = self.bias if bias is None else bias
+        if x.is_cuda and x.dim() == 2 and self.weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16):
+            return engine.SmallLinearFn.apply(x, self.weight, b, None, False)
+        return F.linear(x.to(self.weight.dtype), self.weight, b)
+
+
 class BertQAPredictionHead(nn.Module):
     """modeling_bert.py:518-533 — transform + Linear(hidden -> num_labels, no bias) + bias."""
 
     def __init__(self, config, only_vocab=False):
         super().__init__()
         self.transform = BertPredictionHeadTransform(config)
-        self.decoder = nn.Linear(config.hidden_size, config.num_labels, bias=False)
+        self.decoder = HeadLinear(config.hidden_size, config.num_labels, bias=False)
         self.bias = nn.Parameter(torch.zeros(config.num_labels))
 
     def forward(self, hidden_states):
-        h = self.transform(hidden_states).to(self.decoder.weight.dtype)
-        return self.decoder(h) + self.bias
+        h = self.transform(hidden_states)
+        return self.decoder(h, bias=self.bias)
 
 
 class BertPreTrainedModel(PreTrainedModel):

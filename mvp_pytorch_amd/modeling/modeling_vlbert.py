@@ -25,7 +25,7 @@ from torch.nn import CrossEntropyLoss, MSELoss
 
 from .. import engine
 from .modeling_bert import (BertConfig, BertEmbeddings, BertLayer, BertLayerNorm, BertLMPredictionHead,
-                            BertPooler, BertPreTrainedModel, BertQAPredictionHead, embed_inputs)
+                            BertPooler, BertPreTrainedModel, BertQAPredictionHead, HeadLinear, embed_inputs)
 from .modeling_utils import ImgPreTrainedModel
 
 logger = logging.getLogger(__name__)
@@ -882,7 +882,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         self.bert = BiBertImgModel(config)
         self.cls = BertPreTrainingHeads(config, only_vocab=True)
         self.half_mlm = BertLMPredictionHead(config, only_vocab=True)
-        self.qa_head = nn.Linear(config.hidden_size, config.qa_answer_size)
+        self.qa_head = HeadLinear(config.hidden_size, config.qa_answer_size)
         self.only_vocab_size = config.only_word_size
         self.num_seq_relations = config.num_contrast_classes if hasattr(config, "num_contrast_classes") else 2
         self.max_text_seq_length = config.max_text_seq_length if hasattr(config, "max_text_seq_length") else None
@@ -1130,11 +1130,11 @@ def _make_classifier(config, num_labels):
         if not hasattr(config, "cls_hidden_scale"):
             config.cls_hidden_scale = 2
         if config.classifier == "linear":
-            return nn.Linear(config.hidden_size, num_labels)
+            return HeadLinear(config.hidden_size, num_labels)
         if config.classifier == "mlp":
-            return nn.Sequential(nn.Linear(config.hidden_size, config.hidden_size * config.cls_hidden_scale), nn.ReLU(),
-                                 nn.Linear(config.hidden_size * config.cls_hidden_scale, num_labels))
-    return nn.Linear(config.hidden_size, num_labels)
+            return nn.Sequential(HeadLinear(config.hidden_size, config.hidden_size * config.cls_hidden_scale), nn.ReLU(),
+                                 HeadLinear(config.hidden_size * config.cls_hidden_scale, num_labels))
+    return HeadLinear(config.hidden_size, num_labels)
 
 
 def _bi_kwargs(kw):
