@@ -71,3 +71,17 @@ def par():
 
 
 print("6+6 forward layers at M = 10917 / 11143: one stream %.0f us, two streams %.0f us" % (bench(seq), bench(par)))
+
+# proxy for ONE grouped launch per GEMM over both stacks: a single stack with the rows of both (same weights — the
+# grouped kernel would read two weight sets of the same size, so tile counts, rounds and bytes are those of this proxy)
+c = Stack(10917 + 11143)
+
+
+def merged():
+    for _ in range(6):
+        c.layer()
+
+
+t_seq, t_par, t_mrg = bench(seq), bench(par), bench(merged)
+print("proxy for grouped launches over both stacks (one stack of %d rows, 6 forward layers): %.0f us  (one stream %.0f, two streams %.0f)"
+      % (c.M, t_mrg, t_seq, t_par))
