@@ -423,12 +423,18 @@ class EncoderPacks:
 class EncoderMeta:
     """Static description handed to EncoderFn (not a tensor)."""
 
-    def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn, seq_start=None, seq_len=None, rows=0):
+    def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn, seq_start=None, seq_len=None, rows=0,
+                 first=0, count=None):
         """seq_start / seq_len (device int32 [B]) + rows: row-packed mode — x holds `rows` valid token
-        rows, sequence b at [seq_start[b], +seq_len[b]), L = the longest sequence."""
+        rows, sequence b at [seq_start[b], +seq_len[b]), L = the longest sequence.
+        first / count: run layers [first, first + count) of the stack only (return_at_layer, vl:162-163); the
+        parameters handed to EncoderFn are then those layers' 16 * count."""
+        whole = first == 0 and (count is None or count == len(packs))
+        self.group = getattr(packs, "group", None) if whole else None     # the stack-wide refresher wants every layer
+        if not whole:
+            packs = list(packs)[first:first + (len(packs) - first if count is None else count)]
         self.packs, self.B, self.L, self.H, self.heads, self.I = packs, B, L, H, heads, I
         self.seq_start, self.seq_len, self.rows = seq_start, seq_len, rows
-        self.group = getattr(packs, "group", None)
         self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
 
 

@@ -129,10 +129,20 @@ class CaptionBertEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None,
                 return_at_layer=None, pack_hint=None):
-        if isinstance(attention_mask, list) or encoder_history_states is not None or return_at_layer is not None:
-            raise NotImplementedError("phase masks / history states / return_at_layer are outside the accelerated path")
+        if isinstance(attention_mask, list) or encoder_history_states is not None:
+            raise NotImplementedError("phase masks / history states are outside the accelerated path")
         if head_mask is not None and any(h is not None for h in head_mask):
             raise NotImplementedError("head_mask must stay None")
+        if return_at_layer is not None:
+            # vl:162-163,176-177: also hand back the hidden states after layer `return_at_layer` -> ((final,), mid).
+            # Two segments of the stack on padded tensors (the mid output is read position by position).
+            k = int(return_at_layer)
+            n = len(self.layer)
+            if not 0 <= k < n:
+                return self.forward(hidden_states, attention_mask, head_mask, None, None, pack_hint), None   # the reference leaves mid_output None
+            mid = self._run_layers(hidden_states, attention_mask, 0, k + 1)
+            out = mid if k + 1 == n else self._run_layers(mid, attention_mask, k + 1, n - k - 1)
+            return (out,), mid
         B, L, H = hidden_states.shape
         Hc, heads, I, eps = self._dims
         l0 = self.layer[0]
@@ -162,6 +172,21 @@ class CaptionBertEncoder(nn.Module):
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
+
+
+def _run_layers(self, hidden_states, attention_mask, first, count):
+    """Layers [first, first + count) of the stack on a padded [B, L, H] tensor (padded execution, as the reference)."""
+    B, L, H = hidden_states.shape
+    Hc, heads, I, eps = self._dims
+    l0 = self.layer[0]
+    x = hidden_states.to(torch.bfloat16).contiguous().view(B * L, H)
+    meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
+                              l0.output.dropout.p, l0.attention.self.dropout.p, first=first, count=count)
+    y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params()[16 * first:16 * (first + count)])
+    return y.view(B, L, H)
+
+
+CaptionBertEncoder._run_layers = _run_layers
 
 
 def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax):
@@ -373,8 +398,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         MLM head and the contrastive loss of the pre-training model).  It is queued on the side stream before the
         joint stack, so its small kernels — and, in the backward pass, their gradients — run beside the joint
         stack's GEMMs instead of after them; the caller waits for engine.side_stream before using its results."""
-        if head_mask is not None or encoder_history_states or phrase_layer is not None:
-            raise NotImplementedError("head_mask / encoder_history_states / phrase_layer are outside the accelerated path")
+        if head_mask is not None or encoder_history_states:
+            raise NotImplementedError("head_mask / encoder_history_states are outside the accelerated path")
         txt, vis, mask_a, mask_b = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
                                              input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats,
                                              pack_hints)
@@ -432,13 +457,25 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                 both_mask, hint = torch.cat([joint_mask, hard_mask], 0), None
             else:
                 hint = tuple(cnt.get())
-            both = self.mul_encoder(both_in, both_mask, pack_hint=hint)[0]
+            mid_joint = mid_hard = None
+            if phrase_layer is not None:      # vl:570-572,589-592: also the hidden states after layer `phrase_layer`
+                (both,), mid = self.mul_encoder(both_in, both_mask, return_at_layer=phrase_layer)
+                if mid is not None:
+                    mid_joint, mid_hard = mid[:n], mid[n:]
+            else:
+                both = self.mul_encoder(both_in, both_mask, pack_hint=hint)[0]
             sequence_output, hard_out = both[:n], both[n:]
             hard_pooled = self.pooler(hard_out)
         else:
-            sequence_output = self.mul_encoder(joint, joint_mask)[0]
+            mid_joint = mid_hard = None
+            if phrase_layer is not None:
+                (sequence_output,), mid_joint = self.mul_encoder(joint, joint_mask, return_at_layer=phrase_layer)
+            else:
+                sequence_output = self.mul_encoder(joint, joint_mask)[0]
         pooled_output = self.pooler(sequence_output)
         outputs = (sequence_output, pooled_output, hard_out, hard_pooled)
+        if phrase_layer is not None:          # vl:605-608: a fourth element
+            return outputs, (txt, vis, sim_mat), (hard_txt_full, hard_img_full), (mid_joint, mid_hard)
         return outputs, (txt, vis, sim_mat), (hard_txt_full, hard_img_full)
 
     # -- row-packed pipeline (training fast path) ------------------------------------------------------

@@ -1030,3 +1030,57 @@ def test_packed_pipeline_equals_general_path(dev, streams):
     worst = max((_rel(gb[n], ga[n]), n) for n in ga if ga[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
     print("worst gradient rel L2", worst)
     assert worst[0] < 1e-2, worst
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_return_at_layer_and_phrase_layer(dev, k):
+    """vl:162-163,176-177 (CaptionBertEncoder.forward(return_at_layer=k) -> ((final,), hidden states after layer k)) and
+    vl:570-572,589-592,605-608 (BiBertImgModel.forward(phrase_layer=k) -> a fourth output (mid_joint, mid_hard)): against the
+    oracle's layer loop, values and gradients through both segments."""
+    from mvp_pytorch_amd import modeling
+    from oracle import mvptr_oracle as orc
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(3)
+    model = modeling.BiBertImgModel(modeling.make_config(cfg)).to(dev).train()
+    sd = {n: p.detach().float().cpu() for n, p in model.state_dict().items()}
+    enc = model.mul_encoder
+    n_layers, heads = len(enc.layer), cfg["num_attention_heads"]
+    g = torch.Generator().manual_seed(8)
+    B, L, H = 5, 17, cfg["hidden_size"]
+    x = (torch.randn(B, L, H, generator=g) * 0.5).to(torch.bfloat16)
+    lens = torch.tensor([17, 9, 12, 3, 17])
+    mask01 = (torch.arange(L)[None, :] < lens[:, None]).long()
+    add = ((1.0 - mask01.float()) * -10000.0)
+    xd = x.to(dev).requires_grad_(True)
+    (final,), mid = enc(xd, add.to(dev), return_at_layer=k)
+    ref_final, ref_mid = orc.encoder(sd, "mul_encoder", n_layers, x.float(), add[:, None, None, :], heads, cfg["layer_norm_eps"], return_at_layer=k)
+    valid = mask01.bool()
+    assert _rel(final.float().cpu()[valid], ref_final[valid]) < 2e-2
+    assert _rel(mid.float().cpu()[valid], ref_mid[valid]) < 2e-2
+    # same values as the plain call; gradients flow through both segments
+    plain = enc(x.to(dev), add.to(dev))[0]
+    assert _rel(final.float().cpu()[valid], plain.float().cpu()[valid]) < 4e-3
+    (final.float()[valid.to(dev)].sum() + mid.float()[valid.to(dev)].sum()).backward()
+    assert xd.grad is not None and torch.isfinite(xd.grad.float()).all()
+    first = enc.layer[0].attention.self.query.weight.grad
+    last = enc.layer[-1].output.dense.weight.grad
+    assert first is not None and float(first.abs().sum()) > 0 and last is not None and float(last.abs().sum()) > 0
+    # the backbone's fourth output
+    dims = gu.TINY_DIMS
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    b = synthetic_batch(dict(dims, B=6), cfg, 4, device=dev)
+    kw = dict(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+              input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"],
+              img_feats=b["img_feats"], max_tag_length=dims["G"], encode_hn=True)
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(1)
+        out4 = model(phrase_layer=k, **kw)
+        torch.manual_seed(1)
+        out3 = model(**kw)
+    assert len(out4) == 4 and len(out3) == 3
+    mid_joint, mid_hard = out4[3]
+    assert mid_joint.shape == out4[0][0].shape and mid_hard.shape == out4[0][2].shape
+    assert torch.equal(out4[2][0], out3[2][0]) and _rel(out4[0][0], out3[0][0]) < 4e-3
+    if k == n_layers - 1:
+        assert torch.equal(mid_joint, out4[0][0])
