@@ -332,12 +332,9 @@ extern "C" int mvptr_wra_fwd(const void* txt, const void* reg, const int64_t* ph
   if (((uintptr_t)txt & 3) || ((uintptr_t)reg & 3)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "wra_fwd: rows must be 4-byte aligned");
   const size_t lds = wra_fwd_lds(Pw, Rw, H);
   if (lds > 150 * 1024) MVPTR_FAIL(MVPTR_BAD_SHAPE, "wra_fwd: phrase grid %d x %d with %d regions needs %zu bytes of LDS", Pw, H, Rw, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)wra_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      MVPTR_FAIL(MVPTR_HIP_ERROR, "wra_fwd: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  // per call, like the attention kernels: the attribute belongs to the current device's copy of the kernel
+  if (hipFuncSetAttribute((const void*)wra_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    MVPTR_FAIL(MVPTR_HIP_ERROR, "wra_fwd: cannot raise the dynamic LDS limit");
   WraArgs a{(const __bf16*)txt, (const __bf16*)reg, phrase_index, img_index, pos_pick, neg_pick, neg_img, n, Pw, Rw, H,
             hinge, cnt, sel, sval, inv_p, inv_r};
   hipLaunchKernelGGL(wra_fwd_kernel, dim3(n), dim3(WRA_THREADS), lds, (hipStream_t)stream, a);
