@@ -440,6 +440,7 @@ def main():
     ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
     ap.add_argument("--dp-sparse-rows", action="store_true", help="N > 1: word-table gradient exchanged by looked-up rows (default dense)")
     ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams as at N = 1")
+    ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream, as multi-rank jobs run by default")
     ap.add_argument("--no-arena", action="store_true", help="N = 1: gradients through autograd tensors instead of the gradient arena (A/B)")
     ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
@@ -488,6 +489,8 @@ def main():
     cls = modeling.BertImgForPreTraining if single else modeling.BiBertImgForPreTraining
     if world > 1 and args.dp_two_streams:
         cfg = dict(cfg, parallel_stacks="always")
+    if args.one_stream:
+        cfg = dict(cfg, parallel_stacks=False)
     model = cls(modeling.make_config(cfg)).to(dev)
     model.train()
     if single:
