@@ -124,7 +124,9 @@ int mvptr_gemm_tn_multi(const mvptr_tn_problem* problems, int count, void* strea
  * slabs into dW in split order — bitwise reproducible weight gradients, and faster where the f32 atomics of the splits
  * are a quarter to a third of the launch (attention pair at M = 10 917: 91 -> 68 us).  mvptr_gemm_tn_ws_bytes: the
  * bytes such a call would use (0: it writes out with atomics; only shapes and M are read).  ws NULL or too small:
- * atomics.  Groups of one call run one after the other on the stream and share ws. */
+ * atomics.  Groups of one call run one after the other on the stream and share ws.  The ordered reduction adds into dW
+ * with plain read-modify-writes: launches that accumulate into the SAME dW must be ordered by a stream (the atomic
+ * write-out has no such requirement). */
 int mvptr_gemm_tn_multi_ws(const mvptr_tn_problem* problems, int count, void* ws, int64_t ws_bytes, void* stream);
 int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* problems, int count);
 
