@@ -237,7 +237,7 @@ class DominantMix:
             self.tn.append(([(d1, ctx, z(H, H), None), (dqkv, x, z(3 * H, H), z(3 * H))], 2.0 * M * 4 * H * H))
         self.w = r(I, H)
         self.bias = torch.zeros(I, device=dev)
-        self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.bfloat16),
+        self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.uint8),
                     torch.empty(M, I, device=dev, dtype=torch.bfloat16), 2.0 * M * I * H) for M in self.Ms]
 
     def tn_launches(self):
@@ -259,7 +259,7 @@ class DominantMix:
 
     def nt_bytes(self):
         H, I = self.H, self.I
-        return sum(2.0 * M * H + 2.0 * I * H + 2 * 2.0 * M * I for M in self.Ms) / len(self.Ms)
+        return sum(2.0 * M * H + 2.0 * I * H + 3.0 * M * I for M in self.Ms) / len(self.Ms)    # gelu bf16 + gelu' 8-bit
 
 
 def _time_launches(launches, reps, cold):
@@ -340,6 +340,97 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                                    avg_launch_us=round(nt_ms * 1e3, 1), avg_launch_us_back_to_back=round(nt_hot_ms * 1e3, 1),
                                    algorithmic_bytes_per_launch=round(mix.nt_bytes()),
                                    traffic=(t_nt or {}).get("bytes_per_launch")))
+
+
+def _secondary_legs(dev, steps):
+    """Driver-visible secondary workloads (never `value`): BASELINE configs[3] — cached two-stage
+    retrieval re-ranking, README lengths 50 tok + 5 phrases / 30 tags / 50 regions, 1 000 captions x 200 images, top-64
+    re-ranked (the routine of tools/bench_rerank.py) — and configs[4] — one VQA fine-tune step (3129-way BCE head) at
+    the per-GPU batch 64 of "batch 512 over 8 GPUs", lengths 128 + 5 / 30 / 50.  Synthetic data, random-init weights."""
+    import golden_util as gu
+    from mvp_pytorch_amd import modeling, train
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    out = {}
+    try:
+        torch.manual_seed(0)
+        n_img, caps, topk = 200, 5, 64
+        dims = dict(B=n_img * caps, T=50, P=5, G=30, R=50)
+        cfg = dict(BASE_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, loss_type="ce", num_labels=2)
+        model = modeling.BiImageBertForRetrieval(modeling.make_config(cfg)).to(dev).eval()
+        b = synthetic_batch(dims, cfg, 7, device=dev)
+        n_txt = dims["B"]
+        rows = torch.arange(0, n_txt, caps, device=dev)
+
+        def encode():
+            text = {k: [] for k in ("seq", "mask", "glob")}
+            for s0 in range(0, n_txt, 500):
+                sl = slice(s0, s0 + 500)
+                t = model.encode_text(input_ids_a=b["input_ids_a"][sl], token_type_ids_a=b["segment_ids_a"][sl], attention_mask_a=b["input_mask_a"][sl])
+                for k in text:
+                    text[k].append(t[k])
+            text = {k: torch.cat(v) for k, v in text.items()}
+            image = model.encode_image(input_ids_b=b["input_ids_b"][rows], img_feats=b["img_feats"][rows], token_type_ids_b=b["segment_ids_b"][rows],
+                                       attention_mask_b=b["input_mask_b"][rows], max_tag_length=dims["G"])
+            return text, image
+
+        encode()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        text, image = encode()
+        torch.cuda.synchronize()
+        t_enc = time.perf_counter() - t0
+        cand = model.coarse_scores(text, image).topk(topk, dim=1).indices
+        ti, ii = torch.arange(n_txt, device=dev).repeat_interleave(topk), cand.reshape(-1)
+        model.rerank(text, image, ti[:4096], ii[:4096])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.rerank(text, image, ti, ii, chunk=4096)
+        torch.cuda.synchronize()
+        t_rr = time.perf_counter() - t0
+        out["configs3_retrieval_rerank"] = {
+            "pairs": int(ti.numel()), "rerank_pairs_per_s": round(ti.numel() / t_rr, 1), "encode_once_s": round(t_enc, 4),
+            "end_to_end_pairs_per_s": round(ti.numel() / (t_rr + t_enc), 1),
+            "workload": "BiImageBertForRetrieval BERT-base eval, 1000 captions x 200 images (55 / 80 slots), coarse top-64 -> 64000 pairs "
+                        "re-ranked from cached uni-modal outputs (row-packed)"}
+        del model, text, image
+    except Exception as e:   # a secondary leg never takes the headline down
+        out["configs3_retrieval_rerank"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        torch.manual_seed(1)
+        dims = dict(B=64, T=128, P=5, G=30, R=50)
+        cfg = dict(BASE_CFG, loss_type="bce", num_labels=3129)
+        model = modeling.BiImageBertForVQA(modeling.make_config(cfg)).to(dev).train()
+        opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.05, t_total=100000)
+        b = synthetic_batch(dims, cfg, 8, device=dev)
+        g = torch.Generator().manual_seed(2)
+        labels = ((torch.rand(dims["B"], 3129, generator=g) < 0.002).float() * torch.rand(dims["B"], 3129, generator=g)).to(dev)
+        kw = dict(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+                  input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"], img_feats=b["img_feats"])
+
+        def vqa_step():
+            loss = model(labels=labels, **kw)[0]
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)      # run_vqa.py max_grad_norm
+            opt.step()
+            sched.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+
+        for _ in range(3):
+            vqa_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = vqa_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out["configs4_vqa_step"] = {"ms_per_step": round(ms, 2), "questions_per_s": round(dims["B"] / (ms * 1e-3), 1), "steps": steps,
+                                    "final_loss": round(float(loss.item()), 4),
+                                    "workload": "BiImageBertForVQA BERT-base train step (fwd + bwd + clip + AdamW), 64 questions/GPU, 128 tok + 5 phrases / "
+                                                "30 tags / 50 regions, 3129-way BCE head, dropout 0.1"}
+    except Exception as e:
+        out["configs4_vqa_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def _single_stream_line(args):
@@ -433,8 +524,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="timed steps only (no all-slots-valid leg, kernel replay or CPU baseline): the command profiles/ are made from")
     ap.add_argument("--with-input-pipeline", action="store_true",
-                    help="extra leg: every step's batch comes from pinned host memory through input_pipeline.PretrainBatchStager "
-                         "(double-buffered H2D on a copy stream, bf16 K-padded features): the PCIe-inclusive rate")
+                    help="(default with the extras) extra leg: every step's batch comes from pinned host memory through "
+                         "input_pipeline.PretrainBatchStager (double-buffered H2D on a copy stream, bf16 K-padded features): the PCIe-inclusive rate")
+    ap.add_argument("--max-grad-norm", type=float, default=10.0,
+                    help="global-norm gradient clip inside the timed step (the reference's only working recipe clips at 10.0, "
+                         "oscar/tmp_config.json:27; run_pretrain_ml.py:639-640); 0 = no clip")
+    ap.add_argument("--no-dp-optins-leg", action="store_true", help="N > 1: skip the second timed leg with the data-parallel opt-ins")
     ap.add_argument("--model", choices=["bi", "single"], default="bi",
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
     ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
@@ -520,11 +615,11 @@ def main():
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
         loss = None
         for _ in range(warmup):
-            train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+            train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss = train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+            loss = train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -539,6 +634,38 @@ def main():
     n_tag = 0 if single else int((batch["lm_label_ids_b"] > -1).sum().item())
     ms_per_step, loss = timed(batch, args.warmup, args.steps)
     value = world * args.batch / (ms_per_step * 1e-3)
+
+    # N > 1: what the ranks saw, what the exchange costs, and a second timed leg with the data-parallel opt-ins:
+    # the driver's plain `bench.py --gpus 8` then measures the conservative defaults (f32 wire, dense word-table exchange, one
+    # compute stream) AND bf16 wire + row-sparse word table + two streams in one run, same fences and step count.
+    dp_info = None
+    if world > 1:
+        import torch.distributed as dist
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        dp_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(),
+                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                   "defaults": {"wire": "bf16" if args.dp_bf16_wire else "f32", "sparse_word_table": bool(args.dp_sparse_rows),
+                                "two_streams": bool(args.dp_two_streams)},
+                   "hot_buckets": sync.n_hot, "buckets": len(sync.buckets), "stalled_steps": sync.stalled_steps}
+        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows and args.dp_two_streams):
+            sync.close()
+            keep_ps = model.bert.parallel_stacks
+            model.bert.parallel_stacks = "always"
+            sync = dp.GradSync(model, sparse_rows=[model.bert.embeddings.word_embeddings.weight], comm_dtype=torch.bfloat16)
+            opt_ms, _ = timed(batch, 3, args.steps)
+            dp_info["dp_optins"] = {"ms_per_step": round(opt_ms, 2), "value": round(world * args.batch / (opt_ms * 1e-3), 1), "steps": args.steps,
+                                    "options": "bf16 wire + row-sparse word-table exchange + two compute streams", "stalled_steps": sync.stalled_steps}
+            sync.close()
+            model.bert.parallel_stacks = keep_ps
+            sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
+        # exposed communication = the headline step minus the same step without any collective (replicas diverge from here
+        # on: timing only, nothing after this reads the weights' values)
+        sync.exchange = False
+        noex_ms, _ = timed(batch, 2, args.steps)
+        sync.exchange = True
+        dp_info["exposed_comm_ms"] = round(ms_per_step - noex_ms, 2)
+        dp_info["ms_per_step_without_exchange"] = round(noex_ms, 2)
 
     # The same step with every token / region slot valid ("256 x (70 tok + 50 region)", nothing to skip),
     # timed exactly like the headline: K steps between the same fences.  Reported beside `value` because
@@ -557,7 +684,7 @@ def main():
     # PCIe-inclusive rate (never `value`): the same batch staged from pinned host tensors every step, as a
     # DataLoader(pin_memory=True) would hand it over; the stager's copy stream overlaps the copy of batch i+1 with step i
     piped = None
-    if args.with_input_pipeline and not single:
+    if (args.with_input_pipeline or not args.no_extras) and not single and not args.fixed_length:
         from mvp_pytorch_amd.input_pipeline import PretrainBatchStager, INT_FIELDS
         host = {k: v.cpu().pin_memory() for k, v in batch.items() if k in INT_FIELDS or k == "img_feats"}
         stager = PretrainBatchStager(dev, args.batch, dims, cfg["img_feature_dim"], depth=2, features="both")
@@ -567,7 +694,7 @@ def main():
             for i in range(n):
                 b = stager.get()
                 b = {k: v for k, v in b.items() if k != "img_feats"}      # the model takes the bf16 operand
-                train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+                train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
                 stager.release()
                 if i + 1 < n:
                     stager.put_collated(host)
@@ -613,11 +740,15 @@ def main():
                        "lengths": "fixed (all slots valid)" if args.fixed_length else
                                   "variable (SURVEY 8d: tokens U{8..68}, phrases U{0..5}, tags U{3..18}, regions U{10..50})",
                        "valid_slot_fraction": valid, "padded_slots_computed": False,
-                       "all_slots_valid": full, "with_input_pipeline": piped},
+                       "all_slots_valid": full, "with_input_pipeline": piped, "max_grad_norm": args.max_grad_norm,
+                       "data_parallel": dp_info},
             "roofline": roof,
         }
         if world == 1 and not args.no_extras and not single:
             out["config"]["single_stream_model"] = _single_stream_line(args)
+            del model, opt, sync, batch
+            torch.cuda.empty_cache()
+            out["config"]["secondary"] = _secondary_legs(dev, args.steps)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(single=single)
         print(json.dumps(out), flush=True)

@@ -42,14 +42,14 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 3
+#define MVPTR_ABI_VERSION 4
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
   MVPTR_EPI_BIAS = 0,        /* out0(bf16) = acc + bias                                  */
-  MVPTR_EPI_BIAS_GELU = 1,   /* u = acc + bias: out0(bf16) = gelu_erf'(u) ; out1(bf16) = gelu_erf(u) */
+  MVPTR_EPI_BIAS_GELU = 1,   /* u = acc + bias: out0(u8) = q(gelu_erf'(u)) ; out1(bf16) = gelu_erf(u); q: see below */
   MVPTR_EPI_BIAS_RESID = 2,  /* out0(bf16) = dropout(acc + bias) + aux(bf16)              */
-  MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * aux, aux = the saved gelu_erf'(u) ; colsum -> vec_out f32 */
+  MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * g, g decoded from aux(u8) = the saved q(gelu_erf'(u)) ; colsum -> vec_out f32 */
   MVPTR_EPI_ADD = 4,         /* out0(bf16) = acc + aux(bf16)  (aux may be NULL)           */
   MVPTR_EPI_F32 = 5,         /* out0(f32)  = acc + bias                                   */
   MVPTR_EPI_BIAS_TANH = 6    /* out0(bf16) = tanh(acc + bias)                             */
@@ -78,7 +78,9 @@ const char* mvptr_last_error(void);
  * modeling_vlbert.py:71-73, and the data-gradient of the same layers (dX = dY * W, with
  * B = W^T as stored by mvptr_cast_pack).
  * lda/ldb/ldc/ld_aux in elements; K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned.
- * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual, or the saved gelu_erf'(u) for EPI_GELU_BWD) or NULL.
+ * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual) or, for EPI_GELU_BWD, u8 [M, ld_aux] (the gelu' stash) or NULL.
+ * The gelu' stash (ABI 4): one byte per element, q = rint(200 g) + 26, g = (q - 26) / 200 — gelu_erf' lies in
+ * [-0.129, 1.129], 0 and 1 are exact, |error| <= 0.0025; out0 of EPI_BIAS_GELU has row stride ldc BYTES, out1 ldc elements.
  * vec_out: f32[N] column sums (EPI_GELU_BWD), accumulated with atomics, or NULL.
  * drop: dropout on (acc + bias) for EPI_BIAS_RESID, element index = m * N + n. */
 int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
@@ -361,6 +363,21 @@ int mvptr_clip_ce_fwd(const float* sim, int n, int64_t ld, const float* logit_sc
 int mvptr_clip_ce_bwd(const float* sim, int n, int64_t ld, const float* logit_scale, const float* lse,
                       const float* gloss, float* dsim, float* parts, float* dlogit_scale, void* stream);
 
+/* In-batch hard negatives, hn_mod = 'hard' (oscar/modeling/modeling_vlbert.py:529-566): hard_img[i] = argmax_j (sim - 2 I)[i, j]
+ * (per text the most similar other image), hard_txt[j] = argmax_i (sim - 2 I)[i, j]; the lowest index wins a tie.  With
+ * perm (int64 [n], the caller's torch.randperm — the draw stays torch's): hard_txt_full = [perm[:n/2] ; hard_txt[perm[n/2:]]],
+ * hard_img_full = [hard_img[perm[:n/2]] ; perm[n/2:]] (vl:544-566) and, when given, sel_txt / sel_img int64 [2n] =
+ * [0..n) ++ hard_*_full (the `sel` vectors of the joint + hard-negative mvptr_pack_maps call).  All int64 device arrays. */
+int mvptr_hard_negative_mine(const float* sim, int n, int64_t ld, const int64_t* perm, int64_t* hard_img, int64_t* hard_txt,
+                             int64_t* hard_txt_full, int64_t* hard_img_full, int64_t* sel_txt, int64_t* sel_img, void* stream);
+
+/* instance_bce_with_logits (oscar/modeling/modeling_vlbert.py:878-883; the VQA loss, loss_type 'bce'):
+ * loss[0] = sum_{r,c} (max(x,0) - x y + log(1 + exp(-|x|))) / rows = binary_cross_entropy_with_logits(mean) * cols;
+ * dlogits (optional, f32 [rows, cols]) = (sigmoid(x) - y) / rows.  logits / labels f32 contiguous [rows, cols];
+ * parts: f32 [n_parts] scratch (one partial sum per workgroup, added in index order: reproducible). */
+int mvptr_bce_logits(const float* logits, const float* labels, int rows, int cols, float* loss, float* dlogits,
+                     float* parts, int n_parts, void* stream);
+
 /* ---- rows between the stacks (rows.hip) ------------------------------------------------------------------
  * Row gather / scatter-add over bf16 [rows, H] buffers: out[i,:] = src[idx[i],:] (idx < 0: zero row) and
  * dst[idx[i],:] += src[i,:] (src bf16, or f32 when src_f32; rows may repeat: f32 atomics into an f32 destination
@@ -455,9 +472,15 @@ typedef struct {
    * at rows [seq_start[b], +seq_len[b]); L = maximum length; mask_add may then be NULL.
    * M == 0 / NULL arrays: dense [B, L] layout. */
   int M;
-  int pad_;
+  /* Device-side row count (ABI 4, the sync-free joint + hard-negative pass whose row count depends on the mined negatives):
+   * rows_dev != NULL: device int32 holding the rows actually present (<= M).  M is then the BOUND the buffers (x, y, saved,
+   * ws) are sized for; every kernel clamps to *rows_dev (workgroups past it return at once), so the host never reads the
+   * count.  M_plan (0: M): rows the launches are planned for (tile configuration, M-splits) — e.g. the previous step's
+   * count.  Rows [*rows_dev, M) of y / dx / the stash are left unwritten. */
+  int M_plan;
   const int* seq_start;
   const int* seq_len;
+  const int* rows_dev;
 } mvptr_layer_desc;
 
 typedef struct {

@@ -61,6 +61,8 @@ struct GemmNtArgs {
   const __bf16* B;
   int64_t lda, ldb;
   int M, N, K;
+  const int* rows_dev;   // device int32: actual row count <= M (NULL: M); workgroups beyond it return at once
+  int m_plan;            // rows the tile configuration is chosen for (<= M; the grid always covers M)
   const float* bias;
   const __bf16* aux;
   int64_t ld_aux;
@@ -78,6 +80,7 @@ struct GemmNtArgs {
   int k_split_len;     // split-K launches (mvptr_gemm_nt_splitk): workgroups with blockIdx.y = z reduce over k in [z * k_split_len, +k_split_len)
   int64_t slab_stride; //   and write their f32 partial tile into slab z = out0 + z * slab_stride elements; 0 = whole K, no slabs
   int no_epi;          // diagnostic build (MVPTR_NT_EXP bit 10): skip the epilogue (loop-only timing; outputs are not written)
+  int store_mode;      // diagnostic build (MVPTR_NT_EXP bits 13-15, persistent kernel): 1 = stores dropped (zero-size descriptor), 2 = nt, 3 = sc1, 4 = sc0 sc1
   int stash_temporal;  // diagnostic build (MVPTR_NT_EXP bit 9): EPI_BIAS_GELU stores gelu'(u) with plain instead of non-temporal stores (A/B)
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
   // fused vocabulary decoder + cross entropy (mvptr_decoder_ce_fwd / _bwd)
@@ -101,7 +104,7 @@ extern __shared__ __attribute__((aligned(1024))) char lds[];
 // residual loads, 16-byte coalesced stores.  CHUNK 32: 32 x ST_LD floats per wave (inside the
 // operand ring); CHUNK 16: 16 x 64 floats, XOR-swizzled (4 KiB per wave, beside the ring).
 template <int EPI, int MT, int CHUNK>
-__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4][MT], float* st, int m0, int n0,
+__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (&acc)[4][MT], float* st, int m0, int n0,
                                             int wm, int wn, int lane) {
   constexpr int WROWS = MT * 16;
   const int c16 = lane & 15, q4 = lane >> 4;
@@ -147,22 +150,35 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
   // residual / pre-activation rows (aux): the four rows of a 32-row chunk are requested together, ONE CHUNK AHEAD of the
   // chunk being finished — issued in front of that chunk's stores, so they are older in the wave's in-order vmcnt queue
   // and their latency (HBM: the operand was written kernels ago) runs under the chunk's LDS round trip, math and stores
-  bf16x8 auxv[2][4];
-  auto load_aux = [&](int it0, bf16x8 (&dstv)[4]) {
+  // raw bits: eight bf16 (16 bytes), or for EPI_GELU_BWD the eight bytes of the 8-bit gelu' stash (words 0, 1)
+  u32x4 auxv[2][4];
+  auto load_aux = [&](int it0, u32x4 (&dstv)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int mj = m0 + wm * WROWS + (it0 + j) * 8 + rsub;
-      bf16x8 x;
+      u32x4 x = {0u, 0u, 0u, 0u};
+      if (has_aux && mj < Mv && n < p.N) {
+        if constexpr (EPI == MVPTR_EPI_GELU_BWD) {
+          const uint8_t* ap = reinterpret_cast<const uint8_t*>(p.aux) + (int64_t)mj * p.ld_aux + n;
+          if (nfull && p.vec_aux_ok) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(ap);
+            x[0] = w[0];
+            x[1] = w[1];
+          } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = f2bf(0.f);
-      if (has_aux && mj < p.M && n < p.N) {
-        const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
-        if (nfull && p.vec_aux_ok) {
-          x = *reinterpret_cast<const bf16x8*>(ap);
+            for (int e = 0; e < 8; ++e)
+              if (n + e < p.N) x[e >> 2] |= (uint32_t)ap[e] << (8 * (e & 3));
+          }
         } else {
+          const __bf16* ap = p.aux + (int64_t)mj * p.ld_aux + n;
+          if (nfull && p.vec_aux_ok) {
+            x = *reinterpret_cast<const u32x4*>(ap);
+          } else {
+            bf16x8 t;
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (n + e < p.N) x[e] = ap[e];
+            for (int e = 0; e < 8; ++e) t[e] = (n + e < p.N) ? ap[e] : f2bf(0.f);
+            x = __builtin_bit_cast(u32x4, t);
+          }
         }
       }
       dstv[j] = x;
@@ -226,7 +242,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
         sm = sm * __expf(mx - mm) + s2 * __expf(m2 - mm);
         mx = mm;
       }
-      if (m < p.M) {
+      if (m < Mv) {
         if (ch == 0 && (n0 >> 6) + wn < p.part_ld) {  // strips past the last column do not exist
           float* pp = p.part + ((int64_t)m * p.part_ld + ((n0 >> 6) + wn)) * 2;
           pp[0] = mx;
@@ -237,7 +253,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       }
       continue;
     }
-    if (m >= p.M || n >= (EPI == EPI_CE_BWD ? p.n_store : p.N)) continue;
+    if (m >= Mv || n >= (EPI == EPI_CE_BWD ? p.n_store : p.N)) continue;
     float v[8], a[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -265,8 +281,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       continue;
     }
     if (kNeedsAux) {
+      const u32x4 aw = auxv[(it >> 2) & 1][it & 3];
+      if constexpr (EPI == MVPTR_EPI_GELU_BWD) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = bf2f(auxv[(it >> 2) & 1][it & 3][e]);
+        for (int e = 0; e < 8; ++e) a[e] = dgelu_unpack(aw[e >> 2], e & 3);
+      } else {
+        const bf16x8 ab = __builtin_bit_cast(bf16x8, aw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = bf2f(ab[e]);
+      }
     }
     if (EPI == MVPTR_EPI_BIAS) {
       store_bf8(p.out0, m, v);
@@ -283,13 +306,16 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       }
       // gelu'(u) is only read in the backward pass: non-temporal stores keep it from displacing gelu(u) — the next
       // GEMM's operand — in the Infinity Cache (same-box A/B: all-slots step 41.71 -> 41.46 ms, packed 28.68 -> 28.60)
-      if (!p.stash_temporal && nfull && p.vec_out_ok) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(dg[e]);
-        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>((__bf16*)p.out0 + (int64_t)m * p.ldc + n));
+      // out0 = the 8-bit gelu' stash (common.h), one byte per element, row stride ldc bytes
+      uint8_t* dp = reinterpret_cast<uint8_t*>(p.out0) + (int64_t)m * p.ldc + n;
+      const u32x2 dq = {dgelu_pack4(dg[0], dg[1], dg[2], dg[3]), dgelu_pack4(dg[4], dg[5], dg[6], dg[7])};
+      if (nfull && p.vec_out_ok) {
+        if (!p.stash_temporal) __builtin_nontemporal_store(dq, reinterpret_cast<u32x2*>(dp));
+        else *reinterpret_cast<u32x2*>(dp) = dq;
       } else {
-        store_bf8(p.out0, m, dg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) dp[e] = (uint8_t)(dq[e >> 2] >> (8 * (e & 3)));
       }
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
@@ -306,7 +332,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[4]
       for (int e = 0; e < 8; ++e) v[e] += a[e];
       store_bf8(p.out0, m, v);
     } else if (EPI == MVPTR_EPI_GELU_BWD) {
-      // aux = gelu'(u) saved by the forward epilogue; rows / columns outside the problem have
+      // aux = gelu'(u) saved by the forward epilogue (8-bit stash, decoded above); rows / columns outside the problem have
       // acc = 0 (zero-filled operand rows), so the column sums need no guard
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -383,7 +409,9 @@ void gemm_nt_kernel(GemmNtArgs p) {
   const int tm = first_m + in_g % gm;
   const int tn = cn0 + in_g / gm;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int rows_a = min(BM, p.M - m0);
+  const int Mv = rows_clamped(p.M, p.rows_dev);     // device-side row count (sync-free joint pass): tiles past it do nothing
+  if (m0 >= Mv) return;
+  const int rows_a = min(BM, Mv - m0);
   const int rows_b = min(BN, p.N - n0);
 
   const __amdgpu_buffer_rsrc_t rsA =
@@ -550,7 +578,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
   }
 #endif
   __syncthreads();  // every wave is done with the operand ring
-  nt_epilogue<EPI, MT, 32>(p, acc, reinterpret_cast<float*>(lds) + wave * (32 * ST_LD), m0, n0, wm, wn, lane);
+  nt_epilogue<EPI, MT, 32>(p, Mv, acc, reinterpret_cast<float*>(lds) + wave * (32 * ST_LD), m0, n0, wm, wn, lane);
 #ifdef MVPTR_TIMELINE_BUILD
   asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_end)::"memory");
   if (p.stamps != nullptr && tid == 0) {
@@ -684,6 +712,424 @@ int launch_rowtile(GemmNtArgs a, hipStream_t s) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (diagnostic build only, MVPTR_GEMM_CFG=p): persistent ring form ("P", round 4) of the 256 x 256 tile for
+// the encoder-layer GEMMs (N % 256 == 0, K % 32 == 0).  Built to close the gap to hipBLASLt's plain kernels
+// (tools/blas_table.py: 1.05-1.8 x faster than gemm_nt_kernel on every GEMM shape of the step, cold operands).
+// MEASURED AND NOT FASTER — kept for the record and the next attempt (profiles/r04_experiments.txt):
+//   * first form: the BK 64 double-buffered loop of gemm_nt_kernel made persistent (next tile's two stages requested
+//     in front of the stores, epilogue straight from the registers, no workgroup turnover): the SAME times as
+//     gemm_nt_kernel on all 24 shape x row-count cases (sum 4 220 vs 4 164 us) — the serial cost per tile is neither
+//     the turnover nor the LDS restage nor the store drain;
+//   * this form: BK 32, FOUR 32-KiB stages, three in flight (96 KiB against 64), LDS-DMA from inline asm with
+//     hand-counted waits (a true ring: hipcc drains the builtin form with vmcnt(0), so the BK 32 rings of rounds 1-3
+//     never had more than one stage in flight), the four LDS-DMA instructions of a step spread between the MFMA
+//     groups: 8 % SLOWER (4 520 us) — the loop is not bound by bytes in flight either;
+//   * stores dropped at the descriptor (instructions still issued): -22 us of 189 (Q/K/V, M = 37 748), -88 of 302
+//     (FFN1 + GELU); loop-only build of gemm_nt_kernel: 139 us = what hipBLASLt needs for the whole GEMM.  The cost is
+//     the STORE ISSUE of the epilogue (~70 cycles per 1-KiB store instruction per CU = 14 B/clk: 4.7 us per 128-KiB
+//     tile) serialised with the wave's own MFMAs — overlapping it needs the two waves of a SIMD half a tile apart,
+//     which a shared operand ring does not allow;
+//   * sc1 (write-through) stores: FFN1 + GELU 302 -> 237 us in this kernel (its 8-byte gelu' stores are partial
+//     lines), nothing or worse elsewhere.
+// What it does:
+//   * the ring never drains between tiles: a workgroup keeps its CU and walks its tiles as one continuous stream of
+//     stages; the stages of tile i+1 that are requested during tile i's last steps sit IN FRONT of tile i's stores
+//     in the wave's in-order vector-memory queue, so the first three steps of a tile wait with vmcnt(2 * LPS + S)
+//     (S = the stores of the previous epilogue, a compile-time constant: buffer stores with a per-tile descriptor
+//     drop the rows past M instead of branching around them) and the stores have three steps to drain;
+//   * the epilogue works on the accumulators where they are: v_permlane16_swap_b32 trades the odd 16-lane rows of
+//     one 16 x 16 block with the even rows of its neighbour, which leaves every lane 8 CONSECUTIVE output columns
+//     (16 bytes of bf16) — no LDS round trip, no barrier, 16-byte aux loads and stores (16 rows x 64 B per wave
+//     instruction), bias / residual / gelu / gelu' arithmetic unchanged.
+// Tile order = the same XCD-aware order as above (virtual block id = blockIdx.x + i * gridDim.x keeps a workgroup on
+// the logical tiles of its own XCD when the grid is a multiple of 8).  grid = tiles / ceil(tiles / CUs): every
+// workgroup gets the same number of tiles (+-1).
+#ifdef MVPTR_DIAG_BUILD
+template <int EPI>
+__device__ __forceinline__ constexpr int ntp_stores() {
+  // vector-memory instructions a wave issues in EVERY epilogue (a lower bound is what the waits need; the optional
+  // bias-gradient atomics of EPI_GELU_BWD come after the stores and are not counted)
+  return EPI == MVPTR_EPI_BIAS_GELU ? 32 : 16;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
+  constexpr int OP_BYTES = 256 * 64, STAGE_BYTES = 2 * OP_BYTES, NSTAGE = 4;
+  constexpr int MT = 8, LPS = 4, S = ntp_stores<EPI>();
+  constexpr bool kBias = (EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID);
+  constexpr bool kAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
+  constexpr int AUXW = (EPI == MVPTR_EPI_GELU_BWD) ? 2 : 4;   // dwords of aux per lane and (row block, column pair)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int G = gridDim.x;
+  const int Mv = rows_clamped(p.M, p.rows_dev);
+  const uint32_t lds0 = lds_addr(lds);
+
+  // logical tile -> (m0, n0): the order of gemm_nt_kernel
+  auto tile_m0n0 = [&](int vb, int& m0, int& n0) {
+    const int t = xcd_remap(vb, nwg);
+    const int chunk_full = p.tiles_m * p.group_n;
+    const int chunk = t / chunk_full;
+    const int cn0 = chunk * p.group_n;
+    const int cn = min(p.group_n, p.tiles_n - cn0);
+    const int tc = t - chunk * chunk_full;
+    const int gsz = p.group_m * cn;
+    const int grp = tc / gsz;
+    const int first_m = grp * p.group_m;
+    const int gm = min(p.group_m, p.tiles_m - first_m);
+    const int in_g = tc - grp * gsz;
+    m0 = __builtin_amdgcn_readfirstlane((first_m + in_g % gm) * 256);
+    n0 = __builtin_amdgcn_readfirstlane((cn0 + in_g / gm) * 256);
+  };
+  auto operand_rsrc = [&](int m0, int n0, u32x4& rsA, u32x4& rsB) {
+    const int rows_a = min(256, Mv - m0);
+    rsA = make_rsrc_words(p.A + (int64_t)m0 * p.lda, (uint32_t)(((int64_t)(rows_a - 1) * p.lda + p.K) * 2));
+    rsB = make_rsrc_words(p.B + (int64_t)n0 * p.ldb, (uint32_t)(((int64_t)255 * p.ldb + p.K) * 2));
+  };
+
+  // staging: a wave instruction fills 16 LDS rows of 64 bytes (1 KiB, lane-linear: lane -> row lane / 4, 16-byte
+  // position lane % 4); 2 per wave for A, 2 for B.  Instruction i of a wave covers rows (i * 8 + wave) * 16 + lane / 4:
+  // the swizzle term (LUT of (row >> 2) & 3 = (lane >> 4) & 3) does not depend on i or the wave, so one per-lane base
+  // per operand + a uniform row step is all the addressing the loop keeps in registers
+  uint32_t offA0, offB0;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz_row(row, 4);
+    offA0 = (uint32_t)(row * p.lda * 2 + c * 16);
+    offB0 = (uint32_t)(row * p.ldb * 2 + c * 16);
+  }
+  const uint32_t stepA = (uint32_t)(128 * p.lda * 2), stepB = (uint32_t)(128 * p.ldb * 2);
+  // piece j (0..3) of a stage: A instructions 0, 1, then B instructions 0, 1
+  auto stage_piece = [&](int buf, const u32x4& rsA, const u32x4& rsB, int k0, int j) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_BYTES + wave * 1024);
+    if (j < 2) lds_dma16_add(rsA, offA0, (uint32_t)j * stepA + (uint32_t)k0 * 2, la + j * 8192);
+    else lds_dma16_add(rsB, offB0, (uint32_t)(j - 2) * stepB + (uint32_t)k0 * 2, la + OP_BYTES + (j - 2) * 8192);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  // fragment reads: row r of an operand tile sits at r * 64 bytes, 16-byte chunk q4 ^ LUT[(r >> 2) & 3]; the rows a
+  // lane reads (block * 16 + c16) share the swizzle term, so block i is an immediate offset of i * 1024 bytes
+  uint32_t fx0, fw0;
+  {
+    const int rx = wm * 128 + c16, rw = wn * 64 + c16;
+    fx0 = rx * 64 + ((q4 ^ swz_row(rx, 4)) << 4);
+    fw0 = OP_BYTES + rw * 64 + ((q4 ^ swz_row(rw, 4)) << 4);
+  }
+
+  f32x4 acc[4][MT];  // [nt][mt]
+  const int nk = p.K >> 5;      // >= 8 (launch rule)
+
+  int my = blockIdx.x;
+  if (my >= nwg) return;
+  const int ntiles = (nwg - my + G - 1) / G;
+  const int total = ntiles * nk;     // stages this workgroup streams
+  // issue cursor: the tile / K offset of the next stage to request, three stages ahead of the compute cursor
+  int iss_tile = my, iss_k = 0, iss_g = 0, iss_buf = 0;
+  int m0, n0;
+  tile_m0n0(my, m0, n0);
+  u32x4 rsA, rsB;
+  operand_rsrc(m0, n0, rsA, rsB);
+  auto advance_issue = [&]() {
+    ++iss_g;
+    iss_buf = (iss_buf + 1) & (NSTAGE - 1);
+    iss_k += 32;
+    if (iss_k == p.K) {
+      iss_k = 0;
+      iss_tile += G;
+      if (iss_tile < nwg) {
+        int im0, in0;
+        tile_m0n0(iss_tile, im0, in0);
+        operand_rsrc(im0, in0, rsA, rsB);
+      }
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) {
+    if (iss_g < total) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stage_piece(iss_buf, rsA, rsB, iss_k, j);
+      advance_issue();
+    }
+  }
+#define NTP_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+
+  int g = 0, buf = 0;
+  for (int ti = 0; ti < ntiles; ++ti) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage g has landed once only the (up to two) younger stages — and, in the first three steps of a tile that
+      // is not the workgroup's first, the previous epilogue's stores, which were issued behind them — remain
+      const int younger = min(NSTAGE - 2, total - 1 - g);
+      if (ti > 0 && kt < NSTAGE - 1) NTP_WAIT_BARRIER(2 * LPS + S);
+      else if (younger == 2) NTP_WAIT_BARRIER(2 * LPS);
+      else if (younger == 1) NTP_WAIT_BARRIER(LPS);
+      else NTP_WAIT_BARRIER(0);
+      const char* base = lds + buf * STAGE_BYTES;
+      bf16x8 xf[MT], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + fw0 + i * 1024);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(base + fx0 + i * 1024);
+      const bool do_issue = iss_g < total;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+        for (int mt = 2 * grp; mt < 2 * grp + 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // one of the four LDS-DMA instructions of stage g + 3 (into the buffer step g - 1 read: every wave has passed
+        // this step's barrier, so it is free) behind each group of eight MFMAs
+        if (do_issue) stage_piece(iss_buf, rsA, rsB, iss_k, grp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (do_issue) advance_issue();
+      ++g;
+      buf = (buf + 1) & (NSTAGE - 1);
+    }
+    // ------------------------------------------------------------------ epilogue, from the accumulators
+    // epilogue geometry: after the lane-row swap a lane owns 8 consecutive columns of the pair's 32: block (q4 & 1) of
+    // the pair, half (q4 >> 1) of the block.  Derived from an opaque copy of the lane id so that the addresses are
+    // formed here and not hoisted above the K loop (where they would be spilled to scratch).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int e16 = lane_e & 15, eq4 = lane_e >> 4;
+    const int ecol = wn * 64 + (eq4 & 1) * 16 + (eq4 >> 1) * 8;   // + pr * 32
+    const int erow = wm * 128 + e16;                              // + mt * 16
+    const int rows_valid = min(256, Mv - m0);
+    // residual / gelu' rows of the wave block: the first four row blocks are requested here, in front of the next
+    // tile's stage 1; block mt + 4 after block mt has been finished (its accumulator registers are free by then)
+    u32x4 auxr[kAux ? MT : 1][2];
+    const bool has_aux = kAux && p.aux != nullptr;
+    constexpr int xsz = (EPI == MVPTR_EPI_GELU_BWD) ? 1 : 2;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc_uniform(
+        reinterpret_cast<const char*>(p.aux) + ((int64_t)m0 * p.ld_aux + n0) * xsz,
+        has_aux ? (uint32_t)(((int64_t)(rows_valid - 1) * p.ld_aux + 256) * xsz) : 0u);
+    const uint32_t xoff = (uint32_t)((erow * p.ld_aux + ecol) * xsz);
+    auto load_aux = [&](int mt) {
+      if constexpr (kAux) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const uint32_t vo = xoff + (uint32_t)((mt * 16 * p.ld_aux + pr * 32) * xsz);
+          if constexpr (AUXW == 2) {
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsX, vo, 0, 0);
+            auxr[mt][pr] = u32x4{w[0], w[1], 0u, 0u};
+          } else {
+            auxr[mt][pr] = __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 0, 0);
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) load_aux(mt);
+    // bias of this tile's columns (16 floats per lane)
+    float b8[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b8[pr][e] = 0.f;
+    if constexpr (kBias) {
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(p.bias + n0 + ecol + pr * 32);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(p.bias + n0 + ecol + pr * 32 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            b8[pr][e] = lo[e];
+            b8[pr][4 + e] = hi[e];
+          }
+        }
+      }
+    }
+    {
+      const int osz0 = (EPI == MVPTR_EPI_BIAS_GELU) ? 1 : 2;      // out0 of the GELU epilogue is the 8-bit gelu' stash
+#ifdef MVPTR_DIAG_BUILD
+      const uint32_t keep = (p.store_mode == 1) ? 0u : 1u;     // 0: every store falls outside the descriptor and is dropped
+#else
+      constexpr uint32_t keep = 1u;
+#endif
+      const __amdgpu_buffer_rsrc_t rsO = make_rsrc_uniform(
+          reinterpret_cast<char*>(p.out0) + ((int64_t)m0 * p.ldc + n0) * osz0,
+          keep * (uint32_t)(((int64_t)(rows_valid - 1) * p.ldc + 256) * osz0));
+      const __amdgpu_buffer_rsrc_t rsO1 = (EPI == MVPTR_EPI_BIAS_GELU)
+          ? make_rsrc_uniform(reinterpret_cast<char*>(p.out1) + ((int64_t)m0 * p.ldc + n0) * 2,
+                              keep * (uint32_t)(((int64_t)(rows_valid - 1) * p.ldc + 256) * 2))
+          : rsO;
+      const uint32_t ooff = (uint32_t)(erow * p.ldc + ecol);    // elements
+      float cs[2][8];
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[pr][e] = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt >= 1 && mt + 3 < MT) load_aux(mt + 3);     // block mt - 1 is finished: its registers are free
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index,
+            //  hipcc / ROCm 7.2)
+            const float ea = acc[2 * pr][mt][r], eb = acc[2 * pr + 1][mt][r];
+            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, ea), __builtin_bit_cast(uint32_t, eb), false, false);
+            const uint32_t s0 = sw[0], s1 = sw[1];
+            v[r] = __builtin_bit_cast(float, s0);
+            v[4 + r] = __builtin_bit_cast(float, s1);
+          }
+          if constexpr (kBias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b8[pr][e];
+          }
+          float a[8];
+          if constexpr (kAux) {
+            const u32x4 aw = auxr[mt][pr];
+            if constexpr (EPI == MVPTR_EPI_GELU_BWD) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = dgelu_unpack(aw[e >> 2], e & 3);
+            } else {
+              const bf16x8 ab = __builtin_bit_cast(bf16x8, aw);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a[e] = bf2f(ab[e]);
+            }
+          }
+          const uint32_t eo = ooff + (uint32_t)(mt * 16 * p.ldc + pr * 32);
+          auto store8 = [&](const __amdgpu_buffer_rsrc_t& rs, const float (&x)[8]) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
+#ifdef MVPTR_DIAG_BUILD
+            if (p.store_mode == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 2);
+            else if (p.store_mode == 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 16);
+            else if (p.store_mode == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 17);
+            else
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 0);
+          };
+          if constexpr (EPI == MVPTR_EPI_BIAS) {
+            store8(rsO, v);
+          } else if constexpr (EPI == MVPTR_EPI_BIAS_GELU) {
+            float g[8], dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              f32x2 a2, d2;
+              gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+              g[e] = a2.x;
+              g[e + 1] = a2.y;
+              dg[e] = d2.x;
+              dg[e + 1] = d2.y;
+            }
+            const u32x2 dq = {dgelu_pack4(dg[0], dg[1], dg[2], dg[3]), dgelu_pack4(dg[4], dg[5], dg[6], dg[7])};
+            __builtin_amdgcn_raw_buffer_store_b64(dq, rsO, eo, 0, 2);      // aux 2 = nt: read once, in the backward pass
+            store8(rsO1, g);
+          } else if constexpr (EPI == MVPTR_EPI_BIAS_RESID) {
+            const uint64_t di = (uint64_t)(m0 + erow + mt * 16) * (uint64_t)p.N + (uint64_t)(n0 + ecol + pr * 32);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) drop_apply2(p.drop, di + (uint64_t)e, v[e], v[e + 1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+            store8(rsO, v);
+          } else if constexpr (EPI == MVPTR_EPI_GELU_BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] *= a[e];
+              cs[pr][e] += v[e];
+            }
+            store8(rsO, v);
+          } else {   // MVPTR_EPI_ADD
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a[e];
+            store8(rsO, v);
+          }
+        }
+      }
+      if constexpr (EPI == MVPTR_EPI_GELU_BWD) {
+        if (p.vec_out != nullptr) {
+          // bias gradient: column sums over the wave's 128 rows = over mt (above) and over the 16 lanes of a row
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float sum = cs[pr][e];
+              sum += __shfl_xor(sum, 1);
+              sum += __shfl_xor(sum, 2);
+              sum += __shfl_xor(sum, 4);
+              sum += __shfl_xor(sum, 8);
+              if (e16 == 0) atomicAdd(p.vec_out + n0 + ecol + pr * 32 + e, sum);
+            }
+        }
+      }
+    }
+    my += G;
+    if (ti + 1 < ntiles) tile_m0n0(my, m0, n0);
+  }
+#undef NTP_WAIT_BARRIER
+}
+
+int ntp_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <int EPI>
+bool ntp_eligible(const GemmNtArgs& a) {
+  if constexpr (!(EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD ||
+                  EPI == MVPTR_EPI_ADD))
+    return false;
+  if ((a.N & 255) || (a.K & 31) || a.K < 256 || a.splits > 1 || a.k_split_len > 0) return false;
+  if (!a.vec_out_ok || (a.bias && !a.vec_bias_ok) || (a.aux && !a.vec_aux_ok)) return false;
+  if ((EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD) && !a.aux) return false;
+  if (EPI == MVPTR_EPI_BIAS_RESID && (a.N & 1)) return false;
+  // 32-bit buffer offsets inside a tile
+  if ((int64_t)256 * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ldb * 2 >= (int64_t)0x7fffffff ||
+      (int64_t)256 * a.ldc * 2 >= (int64_t)0x7fffffff || (int64_t)256 * a.ld_aux * 2 >= (int64_t)0x7fffffff)
+    return false;
+  return true;
+}
+
+template <int EPI>
+int launch_ntp(GemmNtArgs a, hipStream_t s) {
+  constexpr int LDS_BYTES = 4 * 2 * 256 * 64;
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = a.N / 256;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
+  const int nwg = a.tiles_m * a.tiles_n;
+  const bool chunked = a.tiles_n > 4;
+  a.group_m = (EPI == MVPTR_EPI_BIAS_GELU && chunked) ? 6 : GROUP_M;
+  a.group_n = chunked ? ((EPI == MVPTR_EPI_GELU_BWD) ? 3 : 4) : a.tiles_n;
+  if (mvptr_knobs().nt_group[0] > 0) a.group_m = mvptr_knobs().nt_group[0];
+  if (mvptr_knobs().nt_group[1] > 0) a.group_n = min(mvptr_knobs().nt_group[1], a.tiles_n);
+  if (mvptr_knobs().nt_group[0] > 0 && mvptr_knobs().nt_group[1] <= 0) a.group_n = a.tiles_n;
+  // equal shares: tiles / ceil(tiles / CUs) workgroups (a multiple of 8 where that costs no extra round, so that a
+  // workgroup's tiles stay on its XCD's part of the tile order)
+  const int ncu = ntp_num_cus();
+  const int rounds = (nwg + ncu - 1) / ncu;
+  int grid = (nwg + rounds - 1) / rounds;
+  const int grid8 = (grid + 7) & ~7;
+  if (grid8 <= ncu && grid8 <= nwg) grid = grid8;
+  hipLaunchKernelGGL((gemm_ntp_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+  MVPTR_CHECK_LAUNCH("gemm_nt");
+  return MVPTR_OK;
+}
+#endif  // MVPTR_DIAG_BUILD (persistent ring experiment)
+
 template <int EPI, int BK, int STAGES, int WM, int WN, int MT_, int SCHED>
 int launch_bk(GemmNtArgs a, hipStream_t s) {
   using C = Cfg<BK, STAGES, WM, WN, MT_>;
@@ -734,17 +1180,26 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
       if constexpr (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_ADD) return launch_rowtile(a, s);
       else MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: MVPTR_GEMM_CFG=n768 supports the bias / residual / add epilogues only");
     }
+    if (env[0] == 'p') {                                                  // "p": persistent ring experiment
+      if constexpr (EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD ||
+                    EPI == MVPTR_EPI_ADD) {
+        if (ntp_eligible<EPI>(a)) return launch_ntp<EPI>(a, s);
+      }
+      return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
+    }
+    if (env[0] == 'v') return launch_bk<EPI, 32, 3, 2, 2, 8, 0>(a, s);  // "v4": 256x128, FOUR waves of 128x64, two workgroups per CU
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128"
     if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);  // "w4"
     if (env[0] == 't') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);  // "t256k"
     MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
   }
 #endif
-  const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const int Mp = (a.m_plan > 0 && a.m_plan < a.M) ? a.m_plan : a.M;     // rows the configuration is chosen for
+  const int64_t tiles256 = (int64_t)((Mp + 255) / 256) * ((a.N + 255) / 256);
   // few-row GEMMs (head transforms on the masked rows: M ~ 3 k, N = 768) would give a 256x256 tile to
   // a quarter of the CUs or fewer: 128x128 tiles, 4 waves, up to three workgroups per CU
   // (35 vs 74 us at M = 3000, N = 768, K = 3072; at M = 11 k the big tile still wins, 74 vs 87 us)
-  if (tiles256 <= 64 && a.M > 128) return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);
+  if (tiles256 <= 64 && Mp > 128) return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);
   if (a.N <= 768 && a.K <= 768 && tiles256 > 256) return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);
   return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
 }
@@ -848,6 +1303,12 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
                              int K, int epilogue, const float* bias, const void* aux,
                              int64_t ld_aux, void* out0, void* out1, int64_t ldc, float* vec_out,
                              const mvptr_dropout* drop, void* stream) {
+  return mvptr_gemm_nt_rows(A, lda, B, ldb, M, N, K, epilogue, bias, aux, ld_aux, out0, out1, ldc, vec_out, drop, nullptr, 0, stream);
+}
+
+int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epilogue, const float* bias,
+                       const void* aux, int64_t ld_aux, void* out0, void* out1, int64_t ldc, float* vec_out, const mvptr_dropout* drop,
+                       const int* rows_dev, int M_plan, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: M,N,K must be > 0");
   if ((K & 7) || (lda & 7) || (ldb & 7))
     MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%ld ldb=%ld)",
@@ -864,6 +1325,8 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   a.M = M;
   a.N = N;
   a.K = K;
+  a.rows_dev = rows_dev;
+  a.m_plan = M_plan;
   a.bias = bias;
   a.aux = (const __bf16*)aux;
   a.ld_aux = ld_aux;
@@ -883,6 +1346,7 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
   const MvptrKnobs& kn = mvptr_knobs();
   a.stash_temporal = (kn.nt_exp & 512) ? 1 : 0;
   a.no_epi = (kn.nt_exp & 1024) ? 1 : 0;
+  a.store_mode = (kn.nt_exp >> 13) & 7;
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
   a.stamps = (unsigned long long*)kn.stamps;
 #endif

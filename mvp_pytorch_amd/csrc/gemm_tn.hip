@@ -46,7 +46,23 @@ struct GemmTnGroup {
   // "Q" kernel, slab write-out: workgroup g stores its 256x256 f32 partial tile as slab g (256 KiB, in register order)
   // of this caller-provided buffer and tn_reduce_kernel adds a tile's slabs in split order; NULL = f32 atomics
   float* slab;
+  // device-side row count (sync-free joint pass): the rows actually present (<= prob[*].M); every split then covers
+  // ceil(rows / splits) rows rounded up to `tm_round` instead of the host's rows_per_split.  NULL: prob[*].M rows.
+  const int* rows_dev;
+  int tm_round;
 };
+
+// rows of this launch and rows per M-split: the host's plan, or — with a device-side count — the same number of splits
+// over the rows that are really there
+__device__ __forceinline__ void tn_split_rows(const GemmTnGroup& grp, const GemmTnArgs& p, int& Mv, int& rps) {
+  Mv = p.M;
+  rps = p.rows_per_split;
+  if (grp.rows_dev != nullptr) {
+    Mv = min(p.M, __builtin_amdgcn_readfirstlane(*grp.rows_dev));
+    rps = ((Mv + grp.splits - 1) / grp.splits + grp.tm_round - 1) / grp.tm_round * grp.tm_round;
+    rps = max(rps, grp.tm_round);
+  }
+}
 
 __device__ __forceinline__ int swz256(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -114,8 +130,10 @@ __global__ __launch_bounds__(512, ((TM_ == 32 && KSUB == 1) ? 4 : 2)) void gemm_
   const int tn = t / p.tiles_k;
   const int tk = t - tn * p.tiles_k;
   const int n0 = tn * TN_, k0 = tk * TKW;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  int Mv, rps;
+  tn_split_rows(grp, p, Mv, rps);
+  const int m_begin = split * rps;
+  const int m_end = min(Mv, m_begin + rps);
   const int rows = m_end - m_begin;
   if (rows <= 0) return;
   const int ncols = min(TN_, p.N - n0);
@@ -349,8 +367,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
     tk = t - tn * p.tiles_k;
   }
   const int n0 = tn * TN_, k0 = tk * TKW;
-  const int m_begin = split * p.rows_per_split;
-  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  int Mv, rps;
+  tn_split_rows(grp, p, Mv, rps);
+  const int m_begin = split * rps;
+  const int m_end = min(Mv, m_begin + rps);
   const int rows = m_end - m_begin;
   if (rows <= 0) return;
   const int ncols = min(TN_, p.N - n0);
@@ -621,7 +641,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(GemmTnGroup grp) {
   const f32x4* src = reinterpret_cast<const f32x4*>(grp.slab) + ((int64_t)(pbase + t) * 16384 + e4);
   const int64_t sstride = (int64_t)nt * 16384;
   // rows_per_split covers M with `active` splits (the planner's count may leave trailing ones empty)
-  const int active = min(splits, (p.M + p.rows_per_split - 1) / p.rows_per_split);
+  int Mv, rps;
+  tn_split_rows(grp, p, Mv, rps);
+  const int active = min(splits, (Mv + rps - 1) / rps);
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   int sidx = 0;
   for (; sidx + 4 <= active; sidx += 4) {
@@ -744,8 +766,9 @@ constexpr int TN_SLAB_MAX_ROWS = 24000;
 // one launch for `count` problems with the same M.  ws / ws_bytes: caller's slab workspace (may be NULL); need != NULL:
 // plan only — *need = slab bytes this group would use (0: atomics), nothing is launched
 int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, float* ws, int64_t ws_bytes, int64_t* need,
-              bool allow_slab = true) {
-  const int M = probs[0].M;
+              bool allow_slab = true, const int* rows_dev = nullptr, int M_plan = 0) {
+  const int Mb = probs[0].M;                                              // rows the buffers hold (bound)
+  const int M = (rows_dev != nullptr && M_plan > 0 && M_plan < Mb) ? M_plan : Mb;   // rows the launch is planned for
   // four configurations (see gemm_tn_kernel); MVPTR_GEMM_TN = "32" | "64" | "k2" | "K" forces one
   // (tuning knob).  The 256x256 tiles measured no faster than 256x128 at two workgroups per CU on
   // this model's shapes, so only the 256x128 tiles compete by default.
@@ -786,10 +809,17 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, floa
     if (probs[i].ldb > ldmax) ldmax = probs[i].ldb;
   }
   while ((int64_t)rps * ldmax * 2 >= (int64_t)0x7fffffff && rps > pl.tm) rps = (rps / 2 + pl.tm - 1) / pl.tm * pl.tm;
-  const int splits = (M + rps - 1) / rps;
+  int splits = (M + rps - 1) / rps;
+  if (rows_dev != nullptr) {
+    // the kernels spread the rows that are really there over `splits`; a split never spans more than ceil(Mb / splits)
+    // rows (+ rounding), which must stay below 2 GiB of operand bytes
+    while ((int64_t)((Mb + splits - 1) / splits + pl.tm) * ldmax * 2 >= (int64_t)0x7fffffff) ++splits;
+  }
   GemmTnGroup g;
   g.count = count;
   g.splits = splits;
+  g.rows_dev = rows_dev;
+  g.tm_round = pl.tm;
   g.base[0] = 0;
   for (int i = 0; i < count; ++i) {
     GemmTnArgs& a = g.prob[i];
@@ -797,7 +827,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, floa
     a.B = (const __bf16*)probs[i].B;
     a.lda = probs[i].lda;
     a.ldb = probs[i].ldb;
-    a.M = M;
+    a.M = Mb;
     a.N = probs[i].N;
     a.K = probs[i].K;
     a.dW = probs[i].dW;
@@ -826,7 +856,7 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, floa
   }
   if (slab) {
     if (ws == nullptr || ws_bytes < slab_bytes || ((uintptr_t)ws & 15))
-      return run_group(probs, count, stream, nullptr, 0, nullptr, false);   // workspace too small: atomics with their own split plan
+      return run_group(probs, count, stream, nullptr, 0, nullptr, false, rows_dev, M_plan);   // workspace too small: atomics with their own split plan
     g.slab = ws;
   }
   if (pick == 4) return launch_tn_q<4>(g, stream);
@@ -839,7 +869,8 @@ int run_group(const mvptr_tn_problem* probs, int count, hipStream_t stream, floa
 }  // namespace
 
 namespace {
-int tn_multi(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, int64_t* need, void* stream) {
+int tn_multi(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, int64_t* need, void* stream,
+             const int* rows_dev = nullptr, int M_plan = 0) {
   if (!probs || count <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_tn_multi: no problems");
   for (int i = 0; i < count; ++i) {
     const int rc = check_problem(probs[i]);
@@ -854,7 +885,7 @@ int tn_multi(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_byte
     int j = i + 1;
     while (j < count && j - i < max_group && probs[j].M == probs[i].M) ++j;
     int64_t nb = 0;
-    const int rc = run_group(probs + i, j - i, (hipStream_t)stream, (float*)ws, ws_bytes, need ? &nb : nullptr);
+    const int rc = run_group(probs + i, j - i, (hipStream_t)stream, (float*)ws, ws_bytes, need ? &nb : nullptr, true, rows_dev, M_plan);
     if (rc != MVPTR_OK) return rc;
     if (nb > most) most = nb;   // the groups of one call run one after the other on the stream: they share the buffer
     i = j;
@@ -870,6 +901,11 @@ extern "C" int mvptr_gemm_tn_multi(const mvptr_tn_problem* probs, int count, voi
 
 extern "C" int mvptr_gemm_tn_multi_ws(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, void* stream) {
   return tn_multi(probs, count, ws, ws_bytes, nullptr, stream);
+}
+
+int mvptr_gemm_tn_multi_rows(const mvptr_tn_problem* probs, int count, void* ws, int64_t ws_bytes, const int* rows_dev, int M_plan,
+                             void* stream) {
+  return tn_multi(probs, count, ws, ws_bytes, nullptr, stream, rows_dev, M_plan);
 }
 
 extern "C" int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* probs, int count) {

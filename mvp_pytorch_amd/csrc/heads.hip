@@ -375,3 +375,106 @@ extern "C" int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_
   MVPTR_CHECK_LAUNCH("ce_mean_small");
   return MVPTR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// In-batch hard negatives (oscar/modeling/modeling_vlbert.py:529-566, hn_mod = 'hard'): per text the most similar
+// OTHER image, per image the most similar other text (argmax of sim - 2 I along rows / columns), then the two halves of
+// a random permutation decide which side of each hard pair is replaced:
+//   hard_txt_full = [dice[:n/2] ; hard_txt[dice[n/2:]]],  hard_img_full = [hard_img[dice[:n/2]] ; dice[n/2:]]
+// (the `dice` = torch.randperm(n) stays torch's draw, so torch.manual_seed controls it and the parity tests replay it).
+// Also writes the `sel` vectors of the joint + hard-negative pack maps, [0..n) ++ hard_*_full.  Two launches instead of
+// the ~25 small torch kernels (eye, sub, 2 x max, 4 x index_select, arange, 4 x cat ...).  Ties: the lowest index wins.
+namespace {
+__global__ __launch_bounds__(256) void hn_argmax_kernel(const float* sim, int n, int64_t ld, int64_t* hard_img, int64_t* hard_txt) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= 2 * n) return;
+  const bool col = w >= n;
+  const int i = col ? w - n : w;
+  float best = -INFINITY;
+  int arg = n;
+  for (int j = lane; j < n; j += 64) {
+    float v = col ? sim[(int64_t)j * ld + i] : sim[(int64_t)i * ld + j];
+    if (j == i) v -= 2.0f;
+    if (v > best) best = v, arg = j;       // ascending j per lane: the first maximum stays
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float b2 = __shfl_xor(best, o);
+    const int a2 = __shfl_xor(arg, o);
+    if (b2 > best || (b2 == best && a2 < arg)) best = b2, arg = a2;
+  }
+  if (lane == 0) (col ? hard_txt : hard_img)[i] = arg < n ? arg : 0;
+}
+
+__global__ __launch_bounds__(256) void hn_select_kernel(const int64_t* perm, const int64_t* hard_img, const int64_t* hard_txt, int n,
+                                                        int64_t* hard_txt_full, int64_t* hard_img_full, int64_t* sel_txt, int64_t* sel_img) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  int64_t d = perm[k];
+  d = d < 0 ? 0 : (d >= n ? n - 1 : d);
+  const bool first = k < n / 2;
+  const int64_t t = first ? d : hard_txt[d], i = first ? hard_img[d] : d;
+  hard_txt_full[k] = t;
+  hard_img_full[k] = i;
+  if (sel_txt) sel_txt[k] = k, sel_txt[n + k] = t;
+  if (sel_img) sel_img[k] = k, sel_img[n + k] = i;
+}
+
+// sum over all elements of max(x, 0) - x y + log(1 + exp(-|x|)), divided by `rows` = instance_bce_with_logits
+// (vl:878-883: binary_cross_entropy_with_logits(mean) * labels.size(1)); dlogits = (sigmoid(x) - y) / rows.
+__global__ __launch_bounds__(256) void bce_partial_kernel(const float* x, const float* y, int64_t total, float inv_rows, float* dx, float* part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const float v = x[e], t = y[e];
+    const float ex = __expf(-fabsf(v));
+    s += fmaxf(v, 0.f) - v * t + log1pf(ex);
+    if (dx) {
+      const float sig = v >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex);
+      dx[e] = (sig - t) * inv_rows;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void bce_final_kernel(const float* part, int n, float inv_rows, float* loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];     // fixed order: reproducible
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] * inv_rows;
+}
+}  // namespace
+
+extern "C" int mvptr_hard_negative_mine(const float* sim, int n, int64_t ld, const int64_t* perm, int64_t* hard_img, int64_t* hard_txt,
+                                        int64_t* hard_txt_full, int64_t* hard_img_full, int64_t* sel_txt, int64_t* sel_img, void* stream) {
+  if (n <= 0 || ld < n || !sim || !hard_img || !hard_txt) MVPTR_FAIL(MVPTR_BAD_ARG, "hard_negative_mine: bad argument");
+  if (perm != nullptr && (!hard_txt_full || !hard_img_full)) MVPTR_FAIL(MVPTR_BAD_ARG, "hard_negative_mine: perm without outputs");
+  hipLaunchKernelGGL(hn_argmax_kernel, dim3((2 * n + 3) / 4), dim3(256), 0, (hipStream_t)stream, sim, n, ld, hard_img, hard_txt);
+  if (perm != nullptr)
+    hipLaunchKernelGGL(hn_select_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, perm, hard_img, hard_txt, n,
+                       hard_txt_full, hard_img_full, sel_txt, sel_img);
+  MVPTR_CHECK_LAUNCH("hard_negative_mine");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_bce_logits(const float* logits, const float* labels, int rows, int cols, float* loss, float* dlogits,
+                                float* parts, int n_parts, void* stream) {
+  if (rows <= 0 || cols <= 0 || !logits || !labels || !loss || !parts || n_parts < 1 || n_parts > 4096)
+    MVPTR_FAIL(MVPTR_BAD_ARG, "bce_logits: bad argument (1 <= n_parts <= 4096)");
+  const float inv = 1.0f / (float)rows;
+  hipLaunchKernelGGL(bce_partial_kernel, dim3(n_parts), dim3(256), 0, (hipStream_t)stream, logits, labels, (int64_t)rows * cols, inv, dlogits, parts);
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, n_parts, inv, loss);
+  MVPTR_CHECK_LAUNCH("bce_logits");
+  return MVPTR_OK;
+}

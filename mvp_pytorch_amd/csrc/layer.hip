@@ -30,7 +30,7 @@ Stash carve(const mvptr_layer_desc* d, void* base) {
   s.ctx = take(M * H * 2);
   s.z1 = take(M * H * 2);
   s.x1 = take(M * H * 2);
-  s.u = take(M * I * 2);
+  s.u = take(M * I);          // gelu'(u), 8-bit fixed point (common.h, dgelu_pack4)
   s.a = take(M * I * 2);
   s.z2 = take(M * H * 2);
   s.lse = (float*)take((int64_t)d->B * d->heads * d->L * 4);
@@ -64,6 +64,8 @@ int check_desc(const char* who, const mvptr_layer_desc* d) {
   if (d->M < 0 || (int64_t)d->M > (int64_t)d->B * d->L) MVPTR_FAIL(MVPTR_BAD_SHAPE, "%s: M=%d outside [0, B*L]", who, d->M);
   if ((d->M > 0) != (d->seq_start != nullptr) || (d->M > 0) != (d->seq_len != nullptr))
     MVPTR_FAIL(MVPTR_BAD_ARG, "%s: M, seq_start and seq_len go together (row-packed mode)", who);
+  if (d->rows_dev != nullptr && d->M == 0) MVPTR_FAIL(MVPTR_BAD_ARG, "%s: rows_dev needs the row-packed mode (M = the bound)", who);
+  if (d->M_plan < 0 || d->M_plan > d->M) MVPTR_FAIL(MVPTR_BAD_ARG, "%s: M_plan outside [0, M]", who);
   return MVPTR_OK;
 }
 
@@ -129,20 +131,22 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
   const mvptr_dropout dr_out = site_drop(d, 2, d->p_hidden16);
-  RUN(mvptr_gemm_nt(x, H, w->w_qkv, H, M, 3 * H, H, MVPTR_EPI_BIAS, w->b_qkv, nullptr, 0, s.qkv,
-                    nullptr, 3 * H, nullptr, nullptr, stream));
+  const int* rd = d->rows_dev;     // device-side row count of a row-packed pass (NULL: M rows)
+  const int Mp = d->M_plan;
+  RUN(mvptr_gemm_nt_rows(x, H, w->w_qkv, H, M, 3 * H, H, MVPTR_EPI_BIAS, w->b_qkv, nullptr, 0, s.qkv,
+                         nullptr, 3 * H, nullptr, nullptr, rd, Mp, stream));
   RUN(mvptr_attention_fwd_packed(s.qkv, mask_add, s.ctx, s.lse, d->seq_start, d->seq_len, d->B, d->L, d->heads,
                                  &dr_attn, stream));
-  RUN(mvptr_gemm_nt(s.ctx, H, w->w_o, H, M, H, H, MVPTR_EPI_BIAS_RESID, w->b_o, x, H, s.z1, nullptr,
-                    H, nullptr, &dr_o, stream));
-  RUN(mvptr_layernorm_fwd(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
-                          nullptr, stream));
-  RUN(mvptr_gemm_nt(s.x1, H, w->w_i, H, M, I, H, MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
-                    nullptr, nullptr, stream));
-  RUN(mvptr_gemm_nt(s.a, I, w->w_out, I, M, H, I, MVPTR_EPI_BIAS_RESID, w->b_out, s.x1, H, s.z2,
-                    nullptr, H, nullptr, &dr_out, stream));
-  RUN(mvptr_layernorm_fwd(s.z2, w->ln2_g, w->ln2_b, d->eps, y, s.mean2, s.rstd2, M, H, M, 0, 0,
-                          nullptr, stream));
+  RUN(mvptr_gemm_nt_rows(s.ctx, H, w->w_o, H, M, H, H, MVPTR_EPI_BIAS_RESID, w->b_o, x, H, s.z1, nullptr,
+                         H, nullptr, &dr_o, rd, Mp, stream));
+  RUN(mvptr_layernorm_fwd_rows(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
+                               nullptr, rd, stream));
+  RUN(mvptr_gemm_nt_rows(s.x1, H, w->w_i, H, M, I, H, MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
+                         nullptr, nullptr, rd, Mp, stream));
+  RUN(mvptr_gemm_nt_rows(s.a, I, w->w_out, I, M, H, I, MVPTR_EPI_BIAS_RESID, w->b_out, s.x1, H, s.z2,
+                         nullptr, H, nullptr, &dr_out, rd, Mp, stream));
+  RUN(mvptr_layernorm_fwd_rows(s.z2, w->ln2_g, w->ln2_b, d->eps, y, s.mean2, s.rstd2, M, H, M, 0, 0,
+                               nullptr, rd, stream));
   return MVPTR_OK;
 }
 
@@ -194,28 +198,30 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   };
 
   // output.LayerNorm / output.dense
-  RUN(mvptr_layernorm_bwd(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
-                          g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
-                          hdrop ? &dr_out : nullptr, lnws, lnws_bytes, stream));
+  const int* rd = d->rows_dev;     // device-side row count of a row-packed pass (NULL: M rows)
+  const int Mp = d->M_plan;
+  RUN(mvptr_layernorm_bwd_rows(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
+                               g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
+                               hdrop ? &dr_out : nullptr, lnws, lnws_bytes, rd, stream));
   const char* d2 = hdrop ? bufB : bufA;
   if (g->w_out) add_wgrad(d2, H, s.a, I, H, I, g->w_out, nullptr);
-  RUN(mvptr_gemm_nt(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
-                    I, g->b_i, nullptr, stream));
+  RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
+                         I, g->b_i, nullptr, rd, Mp, stream));
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache
   if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, nullptr);
-  if (nwg > 0) RUN(mvptr_gemm_tn_multi_ws(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, stream));
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi_rows(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, rd, Mp, stream));
   nwg = 0;
-  RUN(mvptr_gemm_nt(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
-                    nullptr, nullptr, stream));
+  RUN(mvptr_gemm_nt_rows(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
+                         nullptr, nullptr, rd, Mp, stream));
   // attention.output.LayerNorm / dense
-  RUN(mvptr_layernorm_bwd(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
-                          g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
-                          hdrop ? &dr_o : nullptr, lnws, lnws_bytes, stream));
+  RUN(mvptr_layernorm_bwd_rows(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
+                               g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
+                               hdrop ? &dr_o : nullptr, lnws, lnws_bytes, rd, stream));
   const char* d1 = hdrop ? bufE : bufD;
   if (g->w_o) add_wgrad(d1, H, s.ctx, H, H, H, g->w_o, nullptr);
-  RUN(mvptr_gemm_nt(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
-                    nullptr, nullptr, stream));
+  RUN(mvptr_gemm_nt_rows(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
+                         nullptr, nullptr, rd, Mp, stream));
   // attention core
   RUN(mvptr_attention_bwd_packed(s.qkv, mask_add, s.ctx, bufC, s.lse, bufQ, d->seq_start, d->seq_len, d->B,
                                  d->L, d->heads, &dr_attn, stream));
@@ -223,16 +229,17 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   if (g->w_qkv) {
     add_wgrad(bufQ, 3 * H, x, H, 3 * H, H, g->w_qkv, g->b_qkv);
   } else if (g->b_qkv) {
+    if (rd) MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd: a device-side row count needs the Q/K/V weight gradient (b_qkv rides on it)");
     RUN(mvptr_colsum(bufQ, 3 * H, M, 3 * H, g->b_qkv, stream));
   }
-  RUN(mvptr_gemm_nt(bufQ, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufD, H, dx,
-                    nullptr, H, nullptr, nullptr, stream));
+  RUN(mvptr_gemm_nt_rows(bufQ, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufD, H, dx,
+                         nullptr, H, nullptr, nullptr, rd, Mp, stream));
   // largest problem first: the exposed atomic write-out at the end of the launch is then the small one's
   if (nwg == 2 && (int64_t)wg[0].N * wg[0].K < (int64_t)wg[1].N * wg[1].K) {
     const mvptr_tn_problem t = wg[0];
     wg[0] = wg[1];
     wg[1] = t;
   }
-  if (nwg > 0) RUN(mvptr_gemm_tn_multi_ws(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, stream));
+  if (nwg > 0) RUN(mvptr_gemm_tn_multi_rows(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, rd, Mp, stream));
   return MVPTR_OK;
 }

@@ -22,8 +22,9 @@ __device__ __forceinline__ int remap_row(int r, int rpg, int gstride, int roff) 
 // ------------------------------------------------------------------------------ LayerNorm fwd
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const float* gamma,
                                                       const float* beta, float eps, __bf16* y,
-                                                      float* mean, float* rstd, int M, int H,
-                                                      int rpg, int gstride, int roff, DropDev drop) {
+                                                      float* mean, float* rstd, int M_arg, int H,
+                                                      int rpg, int gstride, int roff, DropDev drop, const int* rows_dev) {
+  const int M = rows_clamped(M_arg, rows_dev);
   const int lane = threadIdx.x & 63;
   const int nch = H >> 3;
   // gamma / beta of this lane's columns stay in registers across rows
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
                                                        const float* mean, const float* rstd,
                                                        const float* gamma, __bf16* dz, __bf16* dd,
                                                        float* partial,
-                                                       int M, int H, int rpg, int gstride, int roff,
-                                                       DropDev ydrop, DropDev ddrop) {
+                                                       int M_arg, int H, int rpg, int gstride, int roff,
+                                                       DropDev ydrop, DropDev ddrop, const int* rows_dev) {
+  const int M = rows_clamped(M_arg, rows_dev);
   __shared__ float red[3][3][1024];  // waves 1..3 publish, wave 0 sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -233,8 +235,9 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* parti
 template <int J, int RPW>
 __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const float* gamma,
                                                         const float* beta, float eps, __bf16* y,
-                                                        float* mean, float* rstd, int M, int rpg,
-                                                        int gstride, int roff, DropDev drop) {
+                                                        float* mean, float* rstd, int M_arg, int rpg,
+                                                        int gstride, int roff, DropDev drop, const int* rows_dev) {
+  const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gm[J], bt[J];
@@ -301,8 +304,9 @@ template <int J, int RPW>
 __global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, const __bf16* z,
                                                         const float* mean, const float* rstd,
                                                         const float* gamma, __bf16* dz, __bf16* dd,
-                                                        float* partial, int M, int rpg, int gstride,
-                                                        int roff, DropDev ydrop, DropDev ddrop) {
+                                                        float* partial, int M_arg, int rpg, int gstride,
+                                                        int roff, DropDev ydrop, DropDev ddrop, const int* rows_dev) {
+  const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
   __shared__ float red[3][3][H];  // waves 1..3 publish, wave 0 sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -725,6 +729,12 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
                                    void* y, float* mean, float* rstd, int M, int H,
                                    int rows_per_group, int group_stride, int row_offset,
                                    const mvptr_dropout* drop, void* stream) {
+  return mvptr_layernorm_fwd_rows(z, gamma, beta, eps, y, mean, rstd, M, H, rows_per_group, group_stride, row_offset, drop, nullptr, stream);
+}
+
+int mvptr_layernorm_fwd_rows(const void* z, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int M,
+                             int H, int rows_per_group, int group_stride, int row_offset, const mvptr_dropout* drop, const int* rows_dev,
+                             void* stream) {
   if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: M must be > 0");
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_fwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_fwd: rows_per_group must be > 0");
@@ -735,7 +745,7 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL((ln_fwd_j_kernel<3, RPW>), dim3(g), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)z, gamma, beta, eps, (__bf16*)y, mean, rstd, M, rows_per_group,
-                       group_stride, row_offset, make_dropdev(drop));
+                       group_stride, row_offset, make_dropdev(drop), rows_dev);
     MVPTR_CHECK_LAUNCH("layernorm_fwd");
     return MVPTR_OK;
   }
@@ -743,7 +753,7 @@ extern "C" int mvptr_layernorm_fwd(const void* z, const float* gamma, const floa
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)z, gamma, beta, eps, (__bf16*)y, mean, rstd, M, H,
-                     rows_per_group, group_stride, row_offset, make_dropdev(drop));
+                     rows_per_group, group_stride, row_offset, make_dropdev(drop), rows_dev);
   MVPTR_CHECK_LAUNCH("layernorm_fwd");
   return MVPTR_OK;
 }
@@ -768,6 +778,14 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
                                    int rows_per_group, int group_stride, int row_offset,
                                    const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop,
                                    void* ws, int64_t ws_bytes, void* stream) {
+  return mvptr_layernorm_bwd_rows(dy, z, mean, rstd, gamma, dz, dd, dgamma, dbeta, dbias, M, H, rows_per_group, group_stride, row_offset,
+                                  y_drop, dense_drop, ws, ws_bytes, nullptr, stream);
+}
+
+int mvptr_layernorm_bwd_rows(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz, void* dd,
+                             float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_group, int group_stride, int row_offset,
+                             const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes,
+                             const int* rows_dev, void* stream) {
   if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: M must be > 0");
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: rows_per_group must be > 0");
@@ -785,12 +803,12 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
     hipLaunchKernelGGL((ln_bwd_j_kernel<3, RPW>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
                        (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
-                       make_dropdev(dense_drop));
+                       make_dropdev(dense_drop), rows_dev);
   } else {
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,
                        (__bf16*)dd, (float*)ws, M, H, rows_per_group, group_stride,
-                       row_offset, make_dropdev(y_drop), make_dropdev(dense_drop));
+                       row_offset, make_dropdev(y_drop), make_dropdev(dense_drop), rows_dev);
   }
   MVPTR_CHECK_LAUNCH("layernorm_bwd");
   hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32), dim3(256), 0,

@@ -122,9 +122,12 @@ __global__ __launch_bounds__(WRA_THREADS) void wra_fwd_kernel(WraArgs a) {
           v2 = s, i2 = r;
         }
       }
-      const int k = clampi((side ? a.neg_pick : a.pos_pick)[(size_t)i * Pw + p], 0, 2);
-      const float pv = k == 0 ? v0 : (k == 1 ? v1 : v2);
-      const int pi = k == 0 ? i0 : (k == 1 ? i1 : i2);
+      // The reference's topk(3) needs >= 3 valid regions per image (vl:1547 raises otherwise; the Python side asserts it
+      // on the device).  An image with fewer must not leak -inf into the loss: the drawn rank is clamped to the
+      // regions that exist, and an image without any contributes a similarity of 0 and no gradient (sel = -1).
+      const int k = min(clampi((side ? a.neg_pick : a.pos_pick)[(size_t)i * Pw + p], 0, 2), max(cnt, 1) - 1);
+      const float pv = cnt == 0 ? 0.f : (k == 0 ? v0 : (k == 1 ? v1 : v2));
+      const int pi = cnt == 0 ? -1 : (k == 0 ? i0 : (k == 1 ? i1 : i2));
       picked[side * Pw + p] = pv;
       a.sel[((size_t)i * Pw + p) * 2 + side] = pi;
       a.sval[((size_t)i * Pw + p) * 2 + side] = pv;

@@ -70,7 +70,8 @@ from . import engine
 
 class GradSync:
     def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype=torch.float32, sparse_rows=(),
-                 force_collectives=False, demote_after=8):
+                 force_collectives=False, demote_after=8, check_mixed_use=False):
+        self.check_mixed_use = check_mixed_use
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if force_collectives and not dist.is_initialized():
@@ -109,10 +110,22 @@ class GradSync:
                     self._model_units.append(u)
                     claimed.update(u)
         self._build()
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         engine.set_grad_sink(self)
         self.zero_grad()
+
+    def close(self):
+        """Detach from the model: remove the hooks, drop the gradient views and the engine registration (a second
+        GradSync with other options can then be built over the same parameters, bench.py's opt-in leg)."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        for p in self.params:
+            p.grad = None
+            if engine.grad_sink(p) is self:
+                engine._SINKS.pop(id(p), None)
+        if engine.grad_sink() is self:
+            engine._last_sink_ref[0] = None
 
     # ------------------------------------------------------------------ bucket layout
     def _build(self):
@@ -196,7 +209,7 @@ class GradSync:
         self._ready = set()       # parameters counted towards their bucket's readiness in the exchanging backward
         self._touched = set()     # parameters that received a gradient in ANY backward of this step
         self._uses, self._done = {}, {}   # direct delivery: uses noted in forward passes / deliveries so far
-        self._hook_skip = set()           # parameters whose next post-accumulate hook repeats a completed direct delivery
+        self._hook_skip = {}              # parameter whose next post-accumulate hook repeats a completed direct delivery -> None (or, check_mixed_use, a clone of its .grad then)
         self._rows = {}
         self._next = 0            # buckets [0, _next) have been launched this step
 
@@ -287,14 +300,22 @@ class GradSync:
                 self._note(p, final=False)
                 return
             # this torch runs the parameter's AccumulateGrad node (and so its post-accumulate hook) even when every
-            # function returned None for it: that one call is this delivery seen again, not a new gradient
-            self._hook_skip.add(p)
+            # function returned None for it: that one call is this delivery seen again, not a new gradient.  INVARIANT:
+            # within one graph a parameter is used EITHER through engine functions (counted by note_use) OR through
+            # plain torch ops, never both — a torch-side contribution would arrive after the bucket may have been
+            # launched and its hook would be taken for the repeat.  Every model of this package keeps to it (tied
+            # weights go through engine functions only); `check_mixed_use=True` verifies it by value for new heads
+            # (a clone per delivery: debugging only — version counters cannot tell, all views of the arena share one).
+            self._hook_skip[p] = p.grad.detach().clone() if self.check_mixed_use else None
         self._note(p)
 
     # ---------------------------------------------------------------------------------------------------
     def _hook(self, p):
         if p in self._hook_skip:
-            self._hook_skip.discard(p)
+            snap = self._hook_skip.pop(p)
+            if snap is not None and p.grad is not None and not torch.equal(snap, p.grad):
+                raise RuntimeError("GradSync: a parameter received a gradient through a torch op AND through the HIP engine in "
+                                   "one graph; its bucket may already be in flight.  Use one path per parameter and graph.")
             return
         off, n, ptr = self.span[p]
         if p.grad.data_ptr() != ptr:

@@ -51,40 +51,59 @@ def _caller_grad_enabled():
     return torch.is_grad_enabled() if g is None else g
 
 
-# Gradient arena (mvp_pytorch_amd.dp.GradSync): when one is registered, the autograd functions below let the
-# kernels accumulate weight gradients straight into the arena views that are the parameters' .grad and report
-# `delivered(p)` instead of handing autograd a fresh tensor per parameter (a zero fill, a copy and an
-# AccumulateGrad add per gradient otherwise).  Held weakly: a sink dies with its owner.
-_grad_sink_ref = [None]
+# Gradient arena (mvp_pytorch_amd.dp.GradSync): the autograd functions below let the kernels accumulate weight gradients
+# straight into the arena views that are the parameters' .grad and report `delivered(p)` instead of handing autograd a
+# fresh tensor per parameter (a zero fill, a copy and an AccumulateGrad add per gradient otherwise).  The arena is found
+# PER PARAMETER (each GradSync registers the parameters it lays out), so several models with their own GradSync can live
+# in one process; a parameter no GradSync has claimed takes the plain autograd path.  Held weakly: a sink dies with its
+# owner, an entry with its parameter.
+_SINKS = {}        # id(parameter) -> (weakref(parameter), weakref(sink))
+_last_sink_ref = [None]
 
 
-def set_grad_sink(sink):
+def set_grad_sink(sink, params=None):
+    """Register `sink` (a dp.GradSync) as the gradient arena of `params` (default: sink.params); sink=None drops every
+    registration (tests)."""
     import weakref
-    _grad_sink_ref[0] = None if sink is None else weakref.ref(sink)
+    if sink is None:
+        _SINKS.clear()
+        _last_sink_ref[0] = None
+        return
+    sref = weakref.ref(sink)
+    for p in (sink.params if params is None else params):
+        key = id(p)
+        _SINKS[key] = (weakref.ref(p, lambda _r, k=key: _SINKS.pop(k, None)), sref)
+    _last_sink_ref[0] = sref
 
 
-def grad_sink():
-    r = _grad_sink_ref[0]
-    return None if r is None else r()
+def grad_sink(p=None):
+    """The arena that lays out parameter p, or None.  Without an argument: the most recently registered live arena
+    (kept for tools and tests that have exactly one)."""
+    if p is None:
+        r = _last_sink_ref[0]
+        return None if r is None else r()
+    ent = _SINKS.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    return ent[1]()
 
 
 def note_uses(ctx, params, first_index):
     """Called from an autograd function's forward: tell the gradient arena which parameters this call will deliver a
     gradient for (params[i] is input first_index + i of the function; ctx.needs_input_grad says whether autograd wants
     it — all False under no_grad), see dp.GradSync.note_use."""
-    sink = grad_sink()
-    if sink is None:
-        return
     needs = ctx.needs_input_grad
     for i, p in enumerate(params):
         if p is not None and needs[first_index + i]:
-            sink.note_use(p)
+            sink = grad_sink(p)
+            if sink is not None:
+                sink.note_use(p)
 
 
 def grad_buffer(p, shape=None):
     """-> (f32 buffer the kernels ACCUMULATE p's gradient into, True when it is the arena view p.grad)."""
-    sink = grad_sink()
-    if sink is not None and p is not None and p.requires_grad and p.dtype == torch.float32:
+    sink = grad_sink(p) if p is not None else None
+    if sink is not None and p.requires_grad and p.dtype == torch.float32:
         g = sink.direct(p)
         if g is not None and g.is_contiguous() and (shape is None or tuple(g.shape) == tuple(shape)):
             return g, True
@@ -94,7 +113,7 @@ def grad_buffer(p, shape=None):
 def grad_result(p, buf, direct):
     """What backward returns for p: None when the kernels wrote into the arena (the sink is told), else the buffer."""
     if direct:
-        grad_sink().delivered(p)
+        grad_sink(p).delivered(p)
         return None
     return buf
 
@@ -424,17 +443,29 @@ class EncoderMeta:
     """Static description handed to EncoderFn (not a tensor)."""
 
     def __init__(self, packs, B, L, H, heads, I, eps, training, p_hidden, p_attn, seq_start=None, seq_len=None, rows=0,
-                 first=0, count=None):
+                 first=0, count=None, all_params=None, rows_dev=None, rows_plan=0):
         """seq_start / seq_len (device int32 [B]) + rows: row-packed mode — x holds `rows` valid token
         rows, sequence b at [seq_start[b], +seq_len[b]), L = the longest sequence.
         first / count: run layers [first, first + count) of the stack only (return_at_layer, vl:162-163); the
-        parameters handed to EncoderFn are then those layers' 16 * count."""
+        parameters handed to EncoderFn are then those layers' 16 * count, and all_params names the WHOLE stack's
+        parameters: a segment refreshes the stack-wide working copies (the buffers the fused optimizer writes) and
+        uses its slice of them — never per-layer copies of its own, which a later whole-stack call would not see
+        (ADVICE r03)."""
         whole = first == 0 and (count is None or count == len(packs))
-        self.group = getattr(packs, "group", None) if whole else None     # the stack-wide refresher wants every layer
+        self.group = getattr(packs, "group", None)
+        self.segment = None
         if not whole:
-            packs = list(packs)[first:first + (len(packs) - first if count is None else count)]
+            n_seg = len(packs) - first if count is None else count
+            if self.group is None or all_params is None:
+                self.group = None                                           # per-layer LayerPack path
+            else:
+                self.segment = (first, n_seg, list(all_params))
+            packs = list(packs)[first:first + n_seg]
         self.packs, self.B, self.L, self.H, self.heads, self.I = packs, B, L, H, heads, I
         self.seq_start, self.seq_len, self.rows = seq_start, seq_len, rows
+        # rows_dev (device integer tensor, first 4 bytes = the count as int32): the rows actually present; `rows` is then
+        # the bound the buffers are sized for and rows_plan the host-side planning hint (mvptr_layer_desc.rows_dev / M_plan)
+        self.rows_dev, self.rows_plan = rows_dev, int(rows_plan)
         self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
 
 
@@ -477,6 +508,10 @@ class AsyncCounts:
         self._host.copy_(t, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
+
+    def ready(self):
+        """True once the copy has landed (get() then returns without waiting)."""
+        return self._event is None or self._event.query()
 
     def get(self):
         if self._event is not None:
@@ -527,7 +562,10 @@ class EncoderFn(GradAwareFunction):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         cur = x
         scratch = None
-        if meta.group is not None:
+        if meta.group is not None and meta.segment is not None:
+            first, n_seg, all_params = meta.segment
+            lws = meta.group.refresh(all_params)[first:first + n_seg]
+        elif meta.group is not None:
             lws = meta.group.refresh(params)
         else:
             lws = [meta.packs[li].refresh(params[16 * li:16 * (li + 1)]) for li in range(n)]
@@ -535,9 +573,10 @@ class EncoderFn(GradAwareFunction):
             lw = lws[li]
             d = hip.LayerDesc(meta.B, meta.L, meta.H, meta.heads, meta.I, meta.eps,
                               1 if meta.training else 0, _thresh(meta.p_hidden), _thresh(meta.p_attn),
-                              next_seed() if meta.training else 0, meta.rows, 0,
+                              next_seed() if meta.training else 0, meta.rows, min(meta.rows_plan, meta.rows) if meta.rows_dev is not None else 0,
                               meta.seq_start.data_ptr() if meta.rows else None,
-                              meta.seq_len.data_ptr() if meta.rows else None)
+                              meta.seq_len.data_ptr() if meta.rows else None,
+                              meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None)
             nbytes = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
             if nbytes < 0:
                 hip._check(-1)
@@ -575,7 +614,7 @@ class EncoderFn(GradAwareFunction):
         sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
         total = sum(sizes)
         grads = [None] * (16 * n)
-        sink = grad_sink()
+        sink = grad_sink(ctx.params[0]) if ctx.params else None
         d_cur = dy.contiguous()
         for li in reversed(range(n)):
             ps = ctx.params[16 * li:16 * (li + 1)]
@@ -785,10 +824,10 @@ class LinearFn(GradAwareFunction):
             pad[:, :N] = dy2
             dy2 = pad
         if u is not None:
-            # dy2 is d(gelu(u)); u holds gelu'(u) saved by the forward epilogue (head-sized rows:
+            # dy2 is d(gelu(u)); u holds gelu'(u) saved by the forward epilogue as 8-bit fixed point (head-sized rows:
             # a torch multiply is enough here, the encoder layers use the fused GEMM epilogue)
             du = torch.zeros((dy2.shape[0], Np), device=dev, dtype=torch.bfloat16)
-            du[:, :N] = dy2[:, :N] * u
+            du[:, :N] = (dy2[:, :N].float() * hip.dgelu_decode(u[:, :N])).to(torch.bfloat16)
             dy2 = du
         dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
         dw, dw_d = None, False
@@ -1075,3 +1114,20 @@ class CeMeanFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         return ctx.save * gloss, None
+
+
+class BceLogitsFn(torch.autograd.Function):
+    """instance_bce_with_logits (vl:878-883; the VQA loss): binary_cross_entropy_with_logits(mean) * n_classes on f32
+    [rows, classes] logits — loss and gradient in one pass over the logits (two launches) instead of torch's chain."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, d = hip.bce_logits(logits.contiguous().float(), labels.contiguous().float(), want_grad=logits.requires_grad)
+        ctx.save = d
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        d = ctx.save
+        ctx.save = None
+        return (d * gloss if d is not None else None), None

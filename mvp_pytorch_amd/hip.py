@@ -33,6 +33,7 @@ SYMBOLS = [
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
+    "mvptr_hard_negative_mine", "mvptr_bce_logits",
 ]
 
 
@@ -44,7 +45,7 @@ class LayerDesc(Structure):
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("heads", c_int), ("I", c_int),
                 ("eps", c_float), ("training", c_int), ("p_hidden16", c_uint32),
                 ("p_attn16", c_uint32), ("seed", c_uint64),
-                ("M", c_int), ("pad_", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p)]
+                ("M", c_int), ("M_plan", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p), ("rows_dev", c_void_p)]
 
 
 class LayerWeights(Structure):
@@ -123,6 +124,8 @@ def load():
     lib.mvptr_clip_coef.argtypes = [P, I, F, P, P, P]
     lib.mvptr_sgemm_small.argtypes = [P, I64, I, I, P, P, I64, I, I, P, I, I, I, F, P, I, I, P, I64, P]
     lib.mvptr_ce_mean_small.argtypes = [P, I64, P, I, I, P, P, P]
+    lib.mvptr_hard_negative_mine.argtypes = [P, I, I64, P, P, P, P, P, P, P, P]
+    lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
     lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
     lib.mvptr_clip_ce_fwd.argtypes = [P, I, I64, P, P, P, P, P]
@@ -197,14 +200,34 @@ def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, v
     N = b.shape[0] if n is None else n
     assert b.shape[1] == K
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16)
-    if epilogue == EPI_BIAS_GELU and out1 is None:
-        out1 = torch.empty_like(out)
+        # EPI_BIAS_GELU: out = the 8-bit gelu'(u) stash (dgelu_decode), out1 = gelu(u) in bf16
+        dt = torch.float32 if epilogue == EPI_F32 else (torch.uint8 if epilogue == EPI_BIAS_GELU else torch.bfloat16)
+        out = torch.empty((M, N), device=a.device, dtype=dt)
+    if epilogue == EPI_BIAS_GELU:
+        assert out.dtype == torch.uint8
+        if out1 is None:
+            out1 = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+        assert out1.stride(0) == out.stride(0)
+    if epilogue == EPI_GELU_BWD:
+        assert aux is not None and aux.dtype == torch.uint8
     assert out.stride(1) == 1
     _check(load().mvptr_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, epilogue, _p(bias),
                                 _p(aux), aux.stride(0) if aux is not None else 0, _p(out), _p(out1),
                                 out.stride(0), _p(vec_out), _dp(drop), _stream()))
     return (out, out1) if epilogue == EPI_BIAS_GELU else out
+
+
+DGELU_SCALE, DGELU_ZERO = 200.0, 26.0
+
+
+def dgelu_decode(q):
+    """The 8-bit gelu'(u) stash of EPI_BIAS_GELU (csrc/common.h: q = rint(200 g) + 26) -> f32."""
+    return (q.to(torch.float32) - DGELU_ZERO) * (1.0 / DGELU_SCALE)
+
+
+def dgelu_encode(g):
+    """f32 gelu' values -> the 8-bit stash (test support; the kernels write it themselves)."""
+    return torch.clamp(torch.round(g.float() * DGELU_SCALE) + DGELU_ZERO, 0, 255).to(torch.uint8)
 
 
 def gemm_nt_splitk(a, b, splits, n=None):
@@ -554,6 +577,36 @@ def ce_mean_small(logits, labels, want_grad=True):
     return loss.reshape(()), d
 
 
+def hard_negative_mine(sim, perm=None, want_sel=False):
+    """mvptr_hard_negative_mine: sim f32 [n, n] -> (hard_img, hard_txt) int64 [n]; with perm (torch.randperm(n) on the
+    device) also (hard_txt_full, hard_img_full) and, with want_sel, the [2n] `sel` vectors of the joint pack maps."""
+    n = sim.shape[0]
+    assert sim.dtype == torch.float32 and sim.dim() == 2 and sim.shape[1] == n and sim.stride(1) == 1
+    i64 = dict(device=sim.device, dtype=torch.int64)
+    hard_img, hard_txt = torch.empty(n, **i64), torch.empty(n, **i64)
+    if perm is None:
+        _check(load().mvptr_hard_negative_mine(_p(sim), n, sim.stride(0), None, _p(hard_img), _p(hard_txt), None, None, None, None, _stream()))
+        return hard_img, hard_txt
+    perm = perm.to(torch.int64).contiguous()
+    htf, hif = torch.empty(n, **i64), torch.empty(n, **i64)
+    st, si = (torch.empty(2 * n, **i64), torch.empty(2 * n, **i64)) if want_sel else (None, None)
+    _check(load().mvptr_hard_negative_mine(_p(sim), n, sim.stride(0), _p(perm), _p(hard_img), _p(hard_txt), _p(htf), _p(hif), _p(st), _p(si),
+                                           _stream()))
+    return hard_img, hard_txt, htf, hif, st, si
+
+
+def bce_logits(logits, labels, want_grad=True):
+    """mvptr_bce_logits: instance_bce_with_logits (vl:878-883) -> (loss f32 [], d loss / d logits or None)."""
+    rows, cols = logits.shape
+    assert logits.dtype == torch.float32 and labels.dtype == torch.float32 and logits.is_contiguous() and labels.is_contiguous()
+    n_parts = max(1, min(1024, (rows * cols + 8191) // 8192))
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    parts = torch.empty(n_parts, device=logits.device, dtype=torch.float32)
+    d = torch.empty_like(logits) if want_grad else None
+    _check(load().mvptr_bce_logits(_p(logits), _p(labels), rows, cols, _p(loss), _p(d), _p(parts), n_parts, _stream()))
+    return loss.reshape(()), d
+
+
 def gather_rows(src, idx, out=None, src2=None):
     """out[i] = src[idx[i]] (bf16 rows; idx int32, negative = zero row); with src2, idx >= src.shape[0] reads
     src2[idx - src.shape[0]]."""
@@ -577,7 +630,7 @@ def scatter_add_rows(src, idx, dst, dst2=None):
     return dst
 
 
-def pack_maps(segs, n_seq):
+def pack_maps(segs, n_seq, fill_idx=False):
     """segs: 1 or 2 dicts(mask f32 [rows, ld] additive, sel int64 [n_seq] or None, col0, len, pos int32 [rows, ld_pos] or
     None, src_seq_stride, src_base) -> (pos int32 [n_seq, Ltot], idx int32 [n_seq * Ltot] (first `rows` entries valid),
     seq_start int32 [n_seq], seq_len int32 [n_seq], counts int64 [2] = rows, longest) — see mvptr_pack_maps."""
@@ -596,7 +649,9 @@ def pack_maps(segs, n_seq):
         a.src_seq_stride, a.src_base = int(sg.get("src_seq_stride", 0)), int(sg.get("src_base", 0))
         Ltot += a.len
     pos_out = torch.empty((n_seq, Ltot), device=dev, dtype=torch.int32)
-    idx_out = torch.empty(n_seq * Ltot, device=dev, dtype=torch.int32)
+    # fill_idx: entries past the valid rows read -1 (a gather of the WHOLE vector then yields zero rows there: the
+    # sync-free joint pass, whose row count stays on the device)
+    idx_out = (torch.full if fill_idx else torch.empty)(*(((n_seq * Ltot,), -1) if fill_idx else ((n_seq * Ltot,),)), device=dev, dtype=torch.int32)
     seq_start = torch.empty(n_seq, device=dev, dtype=torch.int32)
     seq_len = torch.empty(n_seq, device=dev, dtype=torch.int32)
     counts = torch.empty(2, device=dev, dtype=torch.int64)

@@ -186,6 +186,12 @@ class PretrainBatchStager:
                 hip.cast_pack(s.feat_d.view(self.B * self.R, self.D), dst=s.bf16_d)
             s.ready.record(self.copy_stream)
         s.decoded, s.staged, s.have_bf16 = False, True, s.bf16_d is not None
+        # the input-only counts of the step, taken from the host tensors while they are at hand (the model then needs no
+        # read-back for them, synthetic.host_counts)
+        s.host_counts = None
+        if all(k in batch for k in ("input_mask_a", "input_mask_b", "lm_label_ids_a", "lm_label_ids_b")):
+            from .synthetic import host_counts
+            s.host_counts = host_counts(batch)
 
     # ------------------------------------------------------------------ device side
     def get(self, check=False):
@@ -212,6 +218,8 @@ class PretrainBatchStager:
             batch["img_feats"] = s.feat_d
         if s.bf16_d is not None and (s.decoded or getattr(s, "have_bf16", False)):
             batch["img_feats_bf16"] = s.bf16_d
+        if getattr(s, "host_counts", None) is not None and not s.decoded:
+            batch["host_counts"] = s.host_counts
         s.in_use = True
         self._pending = s
         return batch

@@ -49,6 +49,9 @@ def soft_cross_entropy(target, input_prob, reduction="mean"):
 def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
     """vl:878-883."""
     assert logits.dim() == 2
+    if (reduction == "mean" and pos_weight is None and logits.is_cuda and logits.dtype == torch.float32 and labels.shape == logits.shape and
+            not labels.requires_grad):
+        return engine.BceLogitsFn.apply(logits, labels.to(torch.float32))     # mvptr_bce_logits: loss (x classes) + gradient
     loss = F.binary_cross_entropy_with_logits(logits, labels, reduction=reduction, pos_weight=pos_weight)
     if reduction == "mean":
         loss = loss * labels.size(1)
@@ -181,7 +184,8 @@ def _run_layers(self, hidden_states, attention_mask, first, count):
     l0 = self.layer[0]
     x = hidden_states.to(torch.bfloat16).contiguous().view(B * L, H)
     meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
-                              l0.output.dropout.p, l0.attention.self.dropout.p, first=first, count=count)
+                              l0.output.dropout.p, l0.attention.self.dropout.p, first=first, count=count,
+                              all_params=self._flat_params())
     y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params()[16 * first:16 * (first + count)])
     return y.view(B, L, H)
 
@@ -189,15 +193,16 @@ def _run_layers(self, hidden_states, attention_mask, first, count):
 CaptionBertEncoder._run_layers = _run_layers
 
 
-def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax):
+def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax, rows_dev=None, rows_plan=0):
     """The layer stack on row-packed input: x_rows bf16 [rows, H] holds the valid token rows of n_seq sequences
     back to back (sequence b at [seq_start[b], +seq_len[b]), device int32; lmax = the longest) -> [rows, H].
-    The caller owns the packing (hip.pack_maps + engine.MultiTapFn)."""
+    The caller owns the packing (hip.pack_maps + engine.MultiTapFn).  rows_dev: device-side count of the rows that are
+    really present (x_rows then has the BOUND's rows, the tail is never read; lmax an upper bound): no host read-back."""
     Hc, heads, I, eps = self._dims
     l0 = self.layer[0]
     meta = engine.EncoderMeta(self._packs.for_device(x_rows.device), n_seq, lmax, Hc, heads, I, eps, self.training,
                               l0.output.dropout.p, l0.attention.self.dropout.p, seq_start=seq_start, seq_len=seq_len,
-                              rows=x_rows.shape[0])
+                              rows=x_rows.shape[0], rows_dev=rows_dev, rows_plan=rows_plan)
     return engine.EncoderFn.apply(x_rows, None, meta, *self._flat_params())
 
 
@@ -283,6 +288,13 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         # see _uni: True = whenever this process is not part of a multi-rank job, "always" = also under
         # torch.distributed, False = never
         self.parallel_stacks = getattr(config, "parallel_stacks", True)
+        # rebuild the three stacks' bf16 weight copies on the second stream beside the embedding kernels (first step / foreign
+        # optimizers; the fused AdamW keeps them current afterwards); config.prefetch_weights = False: in front of each stack
+        self.prefetch_weights = bool(getattr(config, "prefetch_weights", True))
+        # the joint + hard-negative pass of the packed pipeline without reading its row count back (mvptr_layer_desc.rows_dev);
+        # config.sync_free_joint = False: wait for the count and size the pass exactly
+        self.sync_free_joint = bool(getattr(config, "sync_free_joint", True))
+        self._joint_rows_seen = None       # engine.AsyncCounts of the previous step's joint row count: the planning hint
         self.apply(self.init_weights)
 
     # -- stage 1: uni-modal encoders (vl:479-513)
@@ -299,7 +311,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         mask_a = additive_mask(attention_mask_a)
         mask_b = additive_mask(attention_mask_b)
         two_streams = bool(self.parallel_stacks) and input_ids_a.is_cuda and _streams_allowed(self.parallel_stacks)
-        prefetch = two_streams and self.training and torch.is_grad_enabled() and os.environ.get("MVPTR_NO_PREFETCH") != "1"
+        prefetch = two_streams and self.training and torch.is_grad_enabled() and self.prefetch_weights
         if prefetch:
             # training rebuilds the bf16 weight copies of every stack each forward pass (one ~0.1-ms launch per stack):
             # all three go to the side stream now, beside the embedding kernels, instead of in front of each stack
@@ -355,6 +367,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         text ('hard': argmax of sim - 2 I; 'sample': one multinomial draw from softmax(logit * sim)
         with the diagonal at -10000) -> (hard_img_index [n], hard_txt_index [n]) int64."""
         n = sim_mat.shape[0]
+        if hn_mod == "hard" and sim_mat.is_cuda and sim_mat.dtype == torch.float32:
+            from .. import hip
+            return hip.hard_negative_mine(sim_mat.detach().contiguous())          # mvptr_hard_negative_mine: two argmax passes, one launch
         eye = torch.eye(n, dtype=sim_mat.dtype, device=sim_mat.device)
         if hn_mod == "hard":
             masked = sim_mat - 2 * eye
@@ -488,7 +503,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
 
     def forward_packed(self, input_ids_a, token_type_ids_a, attention_mask_a, max_tag_length, input_ids_b, token_type_ids_b,
                        attention_mask_b, img_feats, position_ids_a=None, position_ids_b=None, use_b=False, hn_mod="hard",
-                       logit=None, uni_taps=None, beside=None):
+                       logit=None, uni_taps=None, beside=None, host_counts=None):
         """The two-stage backbone of `forward(encode_hn=True)` without ever materialising a padded activation tensor
         between the stacks (vl:479-600): the valid rows of the text / visual inputs are gathered once, each stack
         runs on packed rows, the packed joint + hard-negative input is gathered straight from the two packed outputs
@@ -514,11 +529,13 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         mask_a, mask_b = additive_mask(attention_mask_a), additive_mask(attention_mask_b)
         pos_a, idx_a, st_a, ln_a, cnt_a = hip.pack_maps([dict(mask=mask_a, len=La, src_seq_stride=La)], B)
         pos_b, idx_b, st_b, ln_b, cnt_b = hip.pack_maps([dict(mask=mask_b, len=Lb, src_seq_stride=Lb)], B)
-        counts = engine.AsyncCounts([cnt_a[0], cnt_a[1], cnt_b[0], cnt_b[1]])
+        # rows / longest sequence of the two uni-modal passes: from the caller (host_counts, computed where the batch was
+        # built) or read back from the device behind the embedding kernels
+        counts = None if host_counts is not None else engine.AsyncCounts([cnt_a[0], cnt_a[1], cnt_b[0], cnt_b[1]])
         two_streams = bool(self.parallel_stacks) and _streams_allowed(self.parallel_stacks)
         main = torch.cuda.current_stream(dev)
         side = engine.side_stream(dev) if two_streams else None
-        prefetch = two_streams and torch.is_grad_enabled() and os.environ.get("MVPTR_NO_PREFETCH") != "1"
+        prefetch = two_streams and torch.is_grad_enabled() and self.prefetch_weights
         if prefetch:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -529,7 +546,12 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         xb = embed_inputs(self.embeddings, input_ids_b, token_type_ids_b, position_ids_b, img_feats, self, share)
         if prefetch:
             main.wait_stream(side)
-        ra, la_max, rb, lb_max = counts.get()
+        if host_counts is not None:
+            ra, la_max, rb, lb_max = (int(host_counts[k]) for k in ("rows_a", "lmax_a", "rows_b", "lmax_b"))
+            ok = (cnt_a[0] == ra) & (cnt_a[1] == la_max) & (cnt_b[0] == rb) & (cnt_b[1] == lb_max)
+            torch._assert_async(ok, "host_counts do not describe this batch's attention masks")
+        else:
+            ra, la_max, rb, lb_max = counts.get()
         xa_p = engine.tap_rows(xa.view(B * La, H), idx_a[:ra])
         if two_streams:
             side.wait_stream(main)
@@ -548,20 +570,31 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         # [CLS] states + whatever else the caller reads from the uni-modal outputs: one tap call
         extra_t, extra_v = uni_taps(pos_a, pos_b) if uni_taps is not None else ([], [])
         cls_t, cls_v = pos_a[:, 0].contiguous(), pos_b[:, 0].contiguous()
-        taps = engine.MultiTapFn.apply(txt_p, vis_p, cls_t, cls_v + ra, *extra_t, *[v + ra for v in extra_v])
+        # rows of the second source are addressed at offset ra; a -1 entry (padded slot) must stay a zero row
+        off = lambda v: torch.where(v >= 0, v + ra, v)       # noqa: E731
+        taps = engine.MultiTapFn.apply(txt_p, vis_p, cls_t, off(cls_v), *extra_t, *[off(v) for v in extra_v])
         global_txt, global_img = self._project(taps[0], self.txt_proj), self._project(taps[1], self.vis_proj)
         sim_mat = self._sim(global_txt, global_img)
         n = B
-        hard_img, hard_txt = self.mine_hard_negatives(sim_mat.detach(), hn_mod, logit)
-        dice = torch.randperm(n, device=dev)
-        first, second = dice[: n // 2], dice[n // 2:]
-        ar = torch.arange(n, device=dev)
-        hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
-        hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
+        own_mining = "mine_hard_negatives" not in self.__dict__        # tests inject captured indices on the instance
+        if own_mining and hn_mod == "hard" and sim_mat.dtype == torch.float32:
+            # argmax of sim - 2 I along rows and columns, the permutation split and the `sel` vectors of the joint maps in
+            # two launches (mvptr_hard_negative_mine); the permutation itself stays torch's draw
+            dice = torch.randperm(n, device=dev)
+            _, _, hard_txt_full, hard_img_full, sel_txt, sel_img = hip.hard_negative_mine(sim_mat.detach().contiguous(), dice, want_sel=True)
+        else:
+            hard_img, hard_txt = self.mine_hard_negatives(sim_mat.detach(), hn_mod, logit)
+            dice = torch.randperm(n, device=dev)
+            first, second = dice[: n // 2], dice[n // 2:]
+            ar = torch.arange(n, device=dev)
+            hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
+            hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
+            sel_txt, sel_img = torch.cat([ar, hard_txt_full]), torch.cat([ar, hard_img_full])
         cut = 1 if use_b else max_tag_length
+        sync_free = self.sync_free_joint
         pos_j, idx_j, st_j, ln_j, cnt_j = hip.pack_maps(
-            [dict(mask=mask_a, sel=torch.cat([ar, hard_txt_full]), len=La, pos=pos_a),
-             dict(mask=mask_b, sel=torch.cat([ar, hard_img_full]), col0=cut, len=Lb - cut, pos=pos_b, src_base=ra)], 2 * n)
+            [dict(mask=mask_a, sel=sel_txt, len=La, pos=pos_a),
+             dict(mask=mask_b, sel=sel_img, col0=cut, len=Lb - cut, pos=pos_b, src_base=ra)], 2 * n, fill_idx=sync_free)
         cj = engine.AsyncCounts([cnt_j[0], cnt_j[1]])
         if beside is not None:
             if two_streams:
@@ -572,9 +605,19 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                     t.record_stream(side)
             else:
                 beside(taps[2:2 + len(extra_t)], taps[2 + len(extra_t):], sim_mat)
-        rj, lj_max = cj.get()
-        xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j[:rj])[0]
-        both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, lj_max)
+        if sync_free:
+            # The row count of this pass depends on the mined hard negatives.  Instead of waiting for it the pass is
+            # sized for its bound (every slot valid): the gather yields zero rows past the count (idx = -1), every layer
+            # kernel clamps to the device-side count (workgroups past it return at once) and the launches are planned
+            # for the previous step's count, which has long landed.
+            prev, self._joint_rows_seen = self._joint_rows_seen, cj
+            plan = prev.get()[0] if (prev is not None and prev.ready()) else 0
+            xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j)[0]
+            both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, La + Lb - cut, rows_dev=cnt_j, rows_plan=plan)
+        else:
+            rj, lj_max = cj.get()
+            xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j[:rj])[0]
+            both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, lj_max)
         return dict(both=both, pos_j=pos_j, seq_start_j=st_j, sim_mat=sim_mat, hard_txt_full=hard_txt_full,
                     hard_img_full=hard_img_full, pos_a=pos_a, pos_b=pos_b, n_txt_rows=ra, text_len=La)
 
@@ -929,28 +972,32 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         self.wra_on_device = True
         # Heads on the second stream (2, default): the visual-MLM and contrastive heads only need the uni-modal outputs and
         # are queued beside the joint stack; ITM / QA / WRA (chains of small kernels) run beside the text MLM head's
-        # vocabulary GEMMs.  MVPTR_HEADS_BESIDE (A/B knob): 1 = only the first pair, 0 = everything on one stream.
-        self.heads_beside = int(os.environ.get("MVPTR_HEADS_BESIDE", "2") or 2)
+        # vocabulary GEMMs.  config.heads_beside: 1 = only the first pair, 0 = everything on one stream.
+        self.heads_beside = int(getattr(config, "heads_beside", 2))
         # training steps run the row-packed pipeline (BiBertImgModel.forward_packed + tapped rows for every head);
-        # False (or MVPTR_PACKED_PIPELINE=0) = the general path through padded tensors (same results to rounding)
-        self.packed_pipeline = os.environ.get("MVPTR_PACKED_PIPELINE", "1") != "0"
+        # config.packed_pipeline = False: the general path through padded tensors (same results to rounding)
+        self.packed_pipeline = bool(getattr(config, "packed_pipeline", True))
         self.apply(self.init_weights)
         self.tie_weights()
 
     def _forward_packed(self, input_ids_a, token_type_ids_a, attention_mask_a, masked_lm_labels_a, qa_ans, input_ids_b,
                         token_type_ids_b, attention_mask_b, masked_lm_labels_b, max_tag_length, position_ids_a, position_ids_b,
-                        img_feats, img_index, phrase_index):
+                        img_feats, img_index, phrase_index, host_counts=None):
         """forward() for a training step, on packed rows end to end (vl:1218-1311): the backbone hands back the packed
         joint output and row maps; every head reads its rows through ONE engine.MultiTapFn call per stack output.
         Same losses as forward() (tests/test_model_gpu.py::test_packed_pipeline_equals_general_path)."""
         dev = input_ids_a.device
         n, La = input_ids_a.shape
         keep_a, keep_b = (masked_lm_labels_a > -1).reshape(-1), (masked_lm_labels_b > -1).reshape(-1)
-        scored = engine.AsyncCounts([keep_a.sum(), keep_b.sum()])
+        if host_counts is not None:
+            n_scored = (int(host_counts["scored_a"]), int(host_counts["scored_b"]))
+        else:
+            scored = engine.AsyncCounts([keep_a.sum(), keep_b.sum()])
+            n_scored = None
         early = {}
 
         def uni_taps(pos_a, pos_b):
-            ib = torch.nonzero_static(keep_b, size=scored.get()[1]).view(-1)
+            ib = torch.nonzero_static(keep_b, size=(n_scored or scored.get())[1]).view(-1)
             early["labels_b"] = masked_lm_labels_b.reshape(-1).index_select(0, ib)
             return [], [pos_b.view(-1).index_select(0, ib)]      # masked tag rows of the packed visual output
 
@@ -961,7 +1008,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         bb = self.bert
         out = bb.forward_packed(input_ids_a, token_type_ids_a, attention_mask_a, max_tag_length, input_ids_b, token_type_ids_b,
                                 attention_mask_b, img_feats, position_ids_a=position_ids_a, position_ids_b=position_ids_b,
-                                uni_taps=uni_taps, beside=uni_heads)
+                                uni_taps=uni_taps, beside=uni_heads, host_counts=host_counts)
         two_streams = bool(bb.parallel_stacks) and _streams_allowed(bb.parallel_stacks)
         main = torch.cuda.current_stream(dev)
         side = engine.side_stream(dev) if two_streams else None
@@ -972,7 +1019,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         both, pos_j = out["both"], out["pos_j"]
         Lj = pos_j.shape[1]
         # rows of the packed joint output the heads read: [CLS] of the 2n sequences, scored text rows, phrase / region rows
-        ia = torch.nonzero_static(keep_a, size=scored.get()[0]).view(-1)           # flat positions in [n, La]
+        ia = torch.nonzero_static(keep_a, size=(n_scored or scored.get())[0]).view(-1)           # flat positions in [n, La]
         labels_a = masked_lm_labels_a.reshape(-1).index_select(0, ia)
         rows_mlm = pos_j[:n, :La].reshape(-1).index_select(0, ia)
         idxs = [pos_j[:, 0].contiguous(), rows_mlm]
@@ -983,6 +1030,10 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
             if getattr(self.config, "max_phrases", None):
                 torch._assert_async(((phrase_index[:, 1] - phrase_index[:, 0]) <= Pw).all(),
                                     "a sample has more phrases than config.max_phrases")
+            # topk(3) of the reference (vl:1547) raises for an image with fewer than 3 regions; here the check runs on the
+            # device (no host sync) and the kernel clamps the drawn rank (csrc/wra.hip)
+            torch._assert_async(((img_index[:, 1] - img_index[:, 0]) >= 3).all(),
+                                "word-region alignment needs >= 3 valid regions per image (topk(3), vl:1547)")
             from .. import hip
             rows_p, rows_r = hip.wra_rows(pos_j, phrase_index, img_index, n, Pw, Rw)
             idxs += [rows_p.view(-1), rows_r.view(-1)]
@@ -1040,13 +1091,16 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 qa_ans=None, input_ids_b=None, token_type_ids_b=None, attention_mask_b=None,
                 masked_lm_labels_b=None, max_tag_length=20, position_ids_a=None, position_ids_b=None,
                 head_mask=None, img_feats=None, is_img_match=None, img_index=None, phrase_index=None,
-                phrase_mod="sample"):
+                phrase_mod="sample", host_counts=None):
+        """host_counts (optional, not a reference argument): synthetic.host_counts(batch) — the input-only counts a step
+        needs on the host (valid rows / longest sequence of both inputs, scored MLM rows), computed where the batch was
+        built, so that the row-packed training step does not read them back from the device."""
         if (self.packed_pipeline and self.training and masked_lm_labels_a is not None and masked_lm_labels_b is not None and
                 head_mask is None and phrase_mod == "sample" and (phrase_index is None or (img_index is not None and self.wra_on_device)) and
                 self.bert.packed_ok(attention_mask_a, attention_mask_b, input_ids_a)):
             return self._forward_packed(input_ids_a, token_type_ids_a, attention_mask_a, masked_lm_labels_a, qa_ans, input_ids_b,
                                         token_type_ids_b, attention_mask_b, masked_lm_labels_b, max_tag_length, position_ids_a,
-                                        position_ids_b, img_feats, img_index, phrase_index)
+                                        position_ids_b, img_feats, img_index, phrase_index, host_counts)
         # Every data-dependent COUNT that only depends on the inputs (scored rows of the two MLM heads,
         # valid rows / longest sequence of the two uni-modal stacks) is fetched in ONE device->host copy
         # here, before any encoder work is queued: a sync in the middle of the step drains the launch
@@ -1098,11 +1152,17 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         def small_heads():
             """ITM, QA and word-region alignment: chains of small kernels on the joint output; run beside the text MLM
             head's vocabulary GEMMs (second stream) when streams are in use."""
-            seq_relationship_score = self.cls.seq_relationship(torch.cat([pooled_output, hard_pooled_output], dim=0))
+            both_pooled = torch.cat([pooled_output, hard_pooled_output], dim=0)
             n = pooled_output.shape[0]
-            dev = seq_relationship_score.device      # built on the device: a pageable host->device copy is a sync
+            dev = both_pooled.device      # built on the device: a pageable host->device copy is a sync
             next_sentence_label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
-            late["itm"] = ce_loss(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
+            sr = self.cls.seq_relationship
+            if both_pooled.is_cuda and sr.weight.dtype == torch.float32 and self.num_seq_relations <= 64:
+                # the 2-way head and its mean cross entropy on the f32 HIP kernels, as the packed pipeline runs them
+                score = engine.SmallLinearFn.apply(both_pooled, sr.weight, sr.bias, None, False)
+                late["itm"] = engine.CeMeanFn.apply(score.view(-1, self.num_seq_relations), next_sentence_label)
+            else:
+                late["itm"] = ce_loss(sr(both_pooled).view(-1, self.num_seq_relations), next_sentence_label.view(-1))
             if qa_ans is not None:
                 late["qa"] = ce_loss(self.qa_head(pooled_output), qa_ans)
             if phrase_index is None:

@@ -63,7 +63,9 @@ class AdamW(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from . import engine
         fresh = set()     # weight caches whose bf16 copies this step's kernels rewrote
+        stale = set()     # ... and caches holding a copy of a parameter that was updated outside the mirror kernel
         for group in self.param_groups:
             ps, gs, ms, vs = [], [], [], []
             b1, b2 = group["betas"]
@@ -81,7 +83,10 @@ class AdamW(Optimizer):
                 st["step"] += 1
                 step_no = st["step"] if step_no is None else step_no
                 if st["step"] != step_no:  # parameters of a group that joined later: single-tensor path
-                    self._single(p, st, group)
+                    self._single(p, st, group, grad_scale)
+                    m = engine.mirror_of(p)
+                    if m is not None and m["cache"]() is not None:
+                        stale.add(m["cache"]())     # its bf16 copies were NOT rewritten by this step's kernels
                     continue
                 ps.append(p)
                 gs.append(p.grad)
@@ -95,7 +100,6 @@ class AdamW(Optimizer):
             if ps[0].is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for p in ps) and \
                     all(g.dtype == torch.float32 and g.is_contiguous() for g in gs):
                 decay = 1.0 - group["lr"] * group["weight_decay"]
-                from . import engine
                 mir = [engine.mirror_of(p) for p in ps]
                 plain = [i for i, m in enumerate(mir) if m is None]
                 mirrored = [i for i, m in enumerate(mir) if m is not None]
@@ -112,7 +116,7 @@ class AdamW(Optimizer):
                             fresh.add(c)
                 continue
             if grad_scale is not None:
-                gs = torch._foreach_mul(gs, grad_scale)
+                gs = torch._foreach_mul(gs, grad_scale.reshape(()))
             torch._foreach_mul_(ms, b1)
             torch._foreach_add_(ms, gs, alpha=1.0 - b1)
             torch._foreach_mul_(vs, b2)
@@ -122,7 +126,7 @@ class AdamW(Optimizer):
             torch._foreach_addcdiv_(ps, ms, denom, value=-step_size)
             if group["weight_decay"] > 0.0:
                 torch._foreach_mul_(ps, 1.0 - group["lr"] * group["weight_decay"])
-        for c in fresh:
+        for c in fresh - stale:
             c.mark_fresh()      # after the version bumps of _fused_mirror: the next forward pass finds the copies current
         return loss
 
@@ -238,10 +242,14 @@ class AdamW(Optimizer):
         self._bump(ps)
 
     @staticmethod
-    def _single(p, st, group):
+    def _single(p, st, group, grad_scale=None):
+        """One parameter whose step counter differs from its group's (a head that first received a gradient in a later
+        step): plain torch ops.  grad_scale (the clip coefficient, a device scalar) multiplies the gradient first, as the
+        fused kernels do."""
         b1, b2 = group["betas"]
-        st["exp_avg"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
-        st["exp_avg_sq"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+        g = p.grad if grad_scale is None else p.grad * grad_scale.to(p.grad.dtype)
+        st["exp_avg"].mul_(b1).add_(g, alpha=1.0 - b1)
+        st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
         denom = st["exp_avg_sq"].sqrt().add_(group["eps"])
         step_size = group["lr"]
         if group["correct_bias"]:

@@ -77,6 +77,29 @@ def synthetic_batch(dims, cfg, seed, single_stream=False, fixed_length=False, de
                      segment_ids_b=torch.ones_like(ids_b), lm_label_ids_b=lab_b,
                      is_next=torch.zeros(B, dtype=torch.long), is_img_match=torch.zeros(B, dtype=torch.long),
                      phrase_index=phrase_index, image_index=image_index)
+    if not single_stream:
+        batch["host_counts"] = host_counts(batch)     # input-only row counts, taken while the batch is still on the host
     if device is not None:
-        batch = {k: v.to(device) for k, v in batch.items()}
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     return batch
+
+
+class HostCounts(dict):
+    """Plain host integers that travel inside a batch dict: `.to()` / `.cuda()` / `.cpu()` return the object itself, so
+    the usual `{k: v.to(device) for k, v in batch.items()}` keeps working."""
+
+    def to(self, *a, **k):
+        return self
+
+    cuda = cpu = pin_memory = to
+
+
+def host_counts(batch):
+    """The data-dependent counts of a two-stage pre-training batch that only depend on its INPUTS, as a collate function
+    or input_pipeline.PretrainBatchStager computes them on the host while the batch is still there: valid rows / longest
+    sequence of the text and of the tag + region inputs, scored rows of the two MLM heads.  Handed to the model as
+    `host_counts=` (train.model_inputs) so that a training step does not read them back from the device."""
+    ma, mb = batch["input_mask_a"], batch["input_mask_b"]
+    la, lb = ma.sum(1), mb.sum(1)
+    return HostCounts(rows_a=int(la.sum()), lmax_a=int(la.max()), rows_b=int(lb.sum()), lmax_b=int(lb.max()),
+                      scored_a=int((batch["lm_label_ids_a"] > -1).sum()), scored_b=int((batch["lm_label_ids_b"] > -1).sum()))

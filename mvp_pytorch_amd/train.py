@@ -34,10 +34,7 @@ def model_inputs(batch, max_tag_length):
                 input_ids_b=batch["input_ids_b"], img_feats=feats,
                 token_type_ids_b=batch["segment_ids_b"], attention_mask_b=batch["input_mask_b"],
                 masked_lm_labels_b=batch["lm_label_ids_b"], phrase_index=batch.get("phrase_index"),
-                img_index=batch.get("image_index"), max_tag_length=max_tag_length)
-
-
-_clip_scratch = {}
+                img_index=batch.get("image_index"), max_tag_length=max_tag_length, host_counts=batch.get("host_counts"))
 
 
 def clip_coefficient(model, grad_sync, max_grad_norm):
@@ -48,8 +45,8 @@ def clip_coefficient(model, grad_sync, max_grad_norm):
     flats = grad_sync.flats() if (grad_sync is not None and hasattr(grad_sync, "flats")) else None
     if flats and flats[0].is_cuda:
         from . import hip
-        key = flats[0].device.index
-        _, coef, _clip_scratch[key] = hip.grad_clip_coef(flats, max_grad_norm, _clip_scratch.get(key))
+        # the partial-sum scratch belongs to the arena it is sized for (one GradSync per model)
+        _, coef, grad_sync._clip_scratch = hip.grad_clip_coef(flats, max_grad_norm, getattr(grad_sync, "_clip_scratch", None))
         return coef
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     return None

@@ -10,6 +10,15 @@ from mvp_pytorch_amd.synthetic import synthetic_batch  # noqa: F401  (re-exporte
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+
+def free_port():
+    """A TCP port the kernel has just handed out on 127.0.0.1 (bind to port 0) — rendezvous ports derived from the pid
+    collide between test processes (VERDICT r03 #9)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
 TINY_CFG = dict(vocab_size=1200, only_word_size=1000, hidden_size=128, num_hidden_layers=4,
                 num_attention_heads=2, intermediate_size=512, layer_norm_eps=1e-12,
                 img_feature_dim=2054, img_feature_type="faster_r-cnn", use_img_layernorm=1,

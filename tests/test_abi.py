@@ -30,7 +30,7 @@ def test_library_exports_header_symbols():
 def test_abi_version_and_error_string():
     from mvp_pytorch_amd import hip
     lib = hip.load()
-    assert hip.query(0) == 3   # MVPTR_ABI_VERSION (3: grad_scale in mvptr_adamw_multi, mirror AdamW, clip, f32 heads, row gather/scatter)
+    assert hip.query(0) == 4   # MVPTR_ABI_VERSION (4: the gelu' stash of EPI_BIAS_GELU / EPI_GELU_BWD is 8-bit fixed point)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.mvptr_gemm_nt(None, 8, None, 8, 0, 8, 8, 0, None, None, 0, None, None, 8, None, None, None)
     assert rc == -1
@@ -49,6 +49,13 @@ def test_abi_version_and_error_string():
     assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1  # M > B*L
     d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 50, 0, 4096, 4096)
     assert 0 < lib.mvptr_layer_saved_bytes(ctypes.byref(d)) < dense
+    # device-side row count: only in row-packed mode, planning hint inside [0, M]
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 0, 0, None, None, 4096)
+    assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1 and b"rows_dev" in lib.mvptr_last_error()
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 50, 60, 4096, 4096, 4096)
+    assert lib.mvptr_layer_saved_bytes(ctypes.byref(d)) == -1 and b"M_plan" in lib.mvptr_last_error()
+    d = hip.LayerDesc(2, 40, 128, 2, 512, 1e-12, 1, 0, 0, 0, 50, 30, 4096, 4096, 4096)
+    assert 0 < lib.mvptr_layer_saved_bytes(ctypes.byref(d)) < dense
 
 
 def test_struct_sizes_match_header():
@@ -56,4 +63,4 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(hip.Dropout) == 16
     assert ctypes.sizeof(hip.LayerWeights) == 16 * 8
     assert ctypes.sizeof(hip.LayerGrads) == 12 * 8
-    assert ctypes.sizeof(hip.LayerDesc) == 72
+    assert ctypes.sizeof(hip.LayerDesc) == 80      # ABI 4: + rows_dev (device-side row count); pad_ became M_plan

@@ -47,7 +47,7 @@ def _run(sparse):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000) + (11 if sparse else 0)
+    port = gu.free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sparse)) for r in range(2)]
     for p in procs:
         p.start()
@@ -100,6 +100,14 @@ def test_bench_launcher_two_ranks_on_one_gpu(dev):
     assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 32
     assert line["scaling"] == "weak" and line["value"] > 0 and line["ms_per_step"] > 0
     assert abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 0.02 * line["value"]
+    # the N > 1 line checks what the ranks saw, times a second leg with the opt-ins and reports the
+    # communication the step could not hide
+    dpi = line["config"]["data_parallel"]
+    assert dpi["rccl_ranks_seen"] == 2 and dpi["backend"] == "gloo" and dpi["rccl_version"] is None
+    assert dpi["defaults"] == {"wire": "f32", "sparse_word_table": False, "two_streams": False}
+    assert dpi["dp_optins"]["ms_per_step"] > 0 and dpi["dp_optins"]["steps"] == 2 and dpi["dp_optins"]["stalled_steps"] == 0
+    assert isinstance(dpi["exposed_comm_ms"], float) and dpi["ms_per_step_without_exchange"] > 0
+    assert line["config"]["max_grad_norm"] == 10.0
 
 
 # ------------------------------------------------------------------------------ round-3: the RCCL path on one GPU
@@ -178,7 +186,7 @@ def _one_rank(mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 30700 + (os.getpid() % 1000) + {"plain": 0, "arena": 1, "rccl": 2, "rccl_opts": 3}[mode]
+    port = gu.free_port()
     p = ctx.Process(target=_one_rank_worker, args=(mode, port, q))
     p.start()
     res = q.get(timeout=600)

@@ -598,6 +598,21 @@ def test_bi_pretrain_parity_b64_vs_oracle(dev, gain):
         assert rel.max() < LOSS_RTOL, rel
     else:
         assert rel[:4].max() < 3e-3 and rel[4] < 1.5e-2, rel
+    if gain == 1.0:
+        # once more in TRAINING mode (dropout 0): the row-packed pipeline bench.py times, against the same oracle losses
+        # 
+        model.train()
+        model.wra_on_device = True
+        with torch.no_grad(), Replay(dict(draw_randperm=[perm.numpy()]), dev), gu.InjectHard(model.bert, masked.max(1)[1], masked.max(0)[1]):
+            res_t = model(input_ids_a=bd["input_ids_a"], token_type_ids_a=bd["segment_ids_a"], attention_mask_a=bd["input_mask_a"],
+                          masked_lm_labels_a=bd["lm_label_ids_a"], input_ids_b=bd["input_ids_b"], img_feats=bd["img_feats"],
+                          token_type_ids_b=bd["segment_ids_b"], attention_mask_b=bd["input_mask_b"],
+                          masked_lm_labels_b=bd["lm_label_ids_b"], max_tag_length=dims["G"])
+        rel_t = np.abs(np.array([x.item() for x in res_t]) - ref) / np.abs(ref)
+        print("B=64 training mode (packed pipeline) rel", rel_t)
+        assert rel_t[:4].max() < LOSS_RTOL and rel_t[4] < SMALL_ROWS_RTOL, rel_t      # [4]: the 128-row ITM loss (measured 1.06e-3)
+        model.eval()
+        model.wra_on_device = False
     # free-running argmax: hard-negative indices against the f32 oracle's
     with torch.no_grad(), Replay(dict(draw_randperm=[perm.numpy()]), dev):
         _, single, hard = model.bert(input_ids_a=bd["input_ids_a"], token_type_ids_a=bd["segment_ids_a"],
@@ -1084,3 +1099,189 @@ def test_return_at_layer_and_phrase_layer(dev, k):
     assert torch.equal(out4[2][0], out3[2][0]) and _rel(out4[0][0], out3[0][0]) < 4e-3
     if k == n_layers - 1:
         assert torch.equal(mid_joint, out4[0][0])
+
+
+@pytest.mark.parametrize("name", ["tiny_bi_pretrain_nophrase", "cfg1_bi_pretrain_nophrase"])
+def test_packed_training_path_matches_reference(dev, name):
+    """the path bench.py times — model.train(), row-packed pipeline (_forward_packed + forward_packed +
+    MultiTapFn), HIP ITM / contrastive heads, heads on the second stream — against the REFERENCE directly: the fixture is
+    the reference's 5-tuple with phrase_index=None (vl:1309; nothing but the hard-negative permutation is drawn), dropout
+    0 on both sides.  Losses to north_star's 1e-3, gradient norms / full gradients within twice their measured error,
+    hard-negative indices bit-exact (free-running on the BERT-base fixture, whose margin allows it)."""
+    d = gu.load(name)
+    cfg, dims = d["config"], d["dims"]
+    model, sd = _build("BiBertImgForPreTraining", cfg, int(d["seed"]), dev, train=True, gain=float(d["weight_gain"]))
+    model.wra_on_device = True                   # the product default; no phrase_index here anyway
+    assert model.training and model.packed_pipeline and model.heads_beside == 2
+    kw = _bi_inputs(d, dev)
+    t = lambda k: torch.from_numpy(d["in:" + k]).to(dev)  # noqa: E731
+    calls = {"packed": 0, "hard": None}
+    orig_fp, orig_bp = model._forward_packed, model.bert.forward_packed
+
+    def spy_fp(*a, **k):
+        calls["packed"] += 1
+        return orig_fp(*a, **k)
+
+    def spy_bp(*a, **k):
+        out = orig_bp(*a, **k)
+        calls["hard"] = (out["hard_txt_full"].cpu().numpy(), out["hard_img_full"].cpu().numpy())
+        return out
+
+    model._forward_packed, model.bert.forward_packed = spy_fp, spy_bp
+    sim_ref = torch.from_numpy(d["sim_mat"])
+    masked = sim_ref - 2 * torch.eye(sim_ref.shape[0])
+    free_running = name.startswith("cfg1")
+    import contextlib
+    inject = contextlib.nullcontext() if free_running else gu.InjectHard(model.bert, masked.max(1)[1], masked.max(0)[1])
+    with Replay(d, dev), inject:
+        res = model(masked_lm_labels_a=t("lm_label_ids_a"), masked_lm_labels_b=t("lm_label_ids_b"), max_tag_length=dims["G"], **kw)
+    assert calls["packed"] == 1, "the training step did not take the row-packed pipeline"
+    assert len(res) == 5
+    assert np.array_equal(calls["hard"][0], d["hard_txt_index"]) and np.array_equal(calls["hard"][1], d["hard_img_index"])
+    got = np.array([x.item() for x in res])
+    ref = d["losses"]
+    rel = np.abs(got - ref) / np.abs(ref)
+    print(name, "losses", got, "ref", ref, "rel", rel)
+    assert max(rel[0], rel[1], rel[3]) < LOSS_RTOL, rel
+    assert max(rel[2], rel[4]) < SMALL_ROWS_RTOL, rel            # contrastive, ITM (B = 4 rows)
+    res[0].backward()
+    torch.cuda.synchronize()
+    worst_n = worst_g = 0.0
+    for pname, p in model.named_parameters():
+        key = "gnorm:" + pname
+        if key not in d:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        gn, rn = p.grad.double().norm().item(), float(d[key])
+        if pname == "logit_scale":
+            assert abs(gn - rn) < 5e-3, (pname, gn, rn)
+        elif rn > 1e-6:
+            e = abs(gn - rn) / rn
+            if pname in CLIP_BRANCH:
+                if not name.startswith("tiny"):
+                    assert e < 1e-1, (pname, gn, rn)
+            else:
+                worst_n = max(worst_n, e)
+        else:
+            assert gn < 2e-3, (pname, gn, rn)
+            continue
+        full = "grad:" + pname
+        if full in d and pname != "logit_scale" and not (pname in CLIP_BRANCH and name.startswith("tiny")):
+            e = _rel(p.grad, torch.from_numpy(d[full]))
+            if pname in CLIP_BRANCH:
+                assert e < 1e-1, (pname, e)
+            else:
+                worst_g = max(worst_g, e)
+    check_measured(name + ":train_gnorm", worst_n, 6e-2)
+    check_measured(name + ":train_grad", worst_g, 5e-2)
+
+
+def test_sync_free_joint_pass_and_host_counts(dev):
+    """the training step without count read-backs — the input-only counts come with the batch
+    (synthetic.host_counts), the joint + hard-negative pass is sized for its bound and clamps to a DEVICE-side row
+    count (mvptr_layer_desc.rows_dev; launches planned for the previous step's count).  Same losses and gradients as
+    the pass that waits for its counts, over three steps (the third one runs with the planning hint), and
+    engine.AsyncCounts is never awaited inside the step."""
+    from mvp_pytorch_amd import engine, modeling
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_phrases=3)
+    dims = dict(B=16, T=12, P=3, G=6, R=5)
+    batch = synthetic_batch(dims, cfg, 33, device=dev)
+    perm = torch.randperm(dims["B"], generator=torch.Generator().manual_seed(9))
+    res = {}
+    waits = {}
+    orig_get = engine.AsyncCounts.get
+    for mode in ("sized", "free"):
+        torch.manual_seed(0)
+        model = modeling.BiBertImgForPreTraining(modeling.make_config(dict(cfg, sync_free_joint=(mode == "free")))).to(dev)
+        model.train()
+        assert model.bert.sync_free_joint == (mode == "free")
+        kw = dict(input_ids_a=batch["input_ids_a"], token_type_ids_a=batch["segment_ids_a"], attention_mask_a=batch["input_mask_a"],
+                  masked_lm_labels_a=batch["lm_label_ids_a"], input_ids_b=batch["input_ids_b"], img_feats=batch["img_feats"],
+                  token_type_ids_b=batch["segment_ids_b"], attention_mask_b=batch["input_mask_b"], masked_lm_labels_b=batch["lm_label_ids_b"],
+                  max_tag_length=dims["G"], host_counts=batch["host_counts"] if mode == "free" else None)
+        n_wait = [0]
+
+        def counting_get(self, _n=n_wait):
+            if not self.ready():
+                _n[0] += 1
+            return orig_get(self)
+
+        engine.AsyncCounts.get = counting_get
+        try:
+            for step in range(3):
+                model.zero_grad(set_to_none=True)
+                with Replay(dict(draw_randperm=[perm.numpy()]), dev):
+                    out = model(**kw)
+                out[0].backward()
+                torch.cuda.synchronize()
+        finally:
+            engine.AsyncCounts.get = orig_get
+        waits[mode] = n_wait[0]
+        res[mode] = ([float(x) for x in out], {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    print("count read-backs awaited inside the three steps:", waits)
+    assert waits["free"] == 0 and waits["sized"] > 0
+    la, lb = np.array(res["sized"][0]), np.array(res["free"][0])
+    print("sized", la, "sync-free", lb)
+    assert np.abs(la - lb).max() / np.abs(la).max() < 5e-4
+    ga, gb = res["sized"][1], res["free"][1]
+    assert set(ga) == set(gb)
+    worst = max((_rel(gb[n], ga[n]), n) for n in ga if ga[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
+    print("worst gradient rel L2", worst)
+    assert worst[0] < 1e-2, worst
+    # wrong host counts are caught on the device
+    bad = dict(batch["host_counts"], rows_a=batch["host_counts"]["rows_a"] - 1)
+    with pytest.raises(RuntimeError):
+        with Replay(dict(draw_randperm=[perm.numpy()]), dev):
+            model(**dict(kw, host_counts=bad))
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("bound,rows", [(20000, 9000), (9000, 9000), (3000, 1100)])
+def test_encoder_stack_with_device_side_row_count(dev, bound, rows):
+    """mvptr_layer_desc.rows_dev at BERT-base width: one encoder layer over `rows` packed rows inside buffers sized for
+    `bound`, the count living on the device, against the same layer run on exactly `rows` rows — output rows, input
+    gradient and every weight gradient (the 256 x 256 GEMM tiles, the weight-gradient M-splits and the LayerNorm
+    kernels all clamp to the device count)."""
+    from mvp_pytorch_amd import modeling
+    cfg = dict(gu.BASE_CFG, num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    enc = modeling.modeling_vlbert.CaptionBertEncoder(modeling.make_config(cfg)).to(dev).train()
+    g = torch.Generator().manual_seed(rows)
+    L = 100
+    lens = torch.randint(20, L + 1, (bound // 20,), generator=g)
+    cum = torch.cumsum(lens, 0)
+    nseq = int((cum <= rows).sum())
+    lens = lens[:nseq].clone()
+    lens[-1] += rows - int(lens.sum())            # exactly `rows` rows
+    assert int(lens.sum()) == rows and int(lens.max()) <= 2 * L
+    starts = (torch.cumsum(lens, 0) - lens).to(torch.int32).to(dev)
+    lens_d = lens.to(torch.int32).to(dev)
+    x = (torch.randn(rows, 768, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.randn(rows, 768, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    lmax = int(lens.max())
+
+    def run(use_dev):
+        enc.zero_grad(set_to_none=True)
+        if use_dev:
+            xin = torch.zeros(bound, 768, dtype=torch.bfloat16, device=dev)
+            xin[:rows] = x
+            xin.requires_grad_(True)
+            cnt = torch.tensor([rows, lmax], dtype=torch.int64, device=dev)
+            y = enc.forward_rows(xin, starts, lens_d, nseq, lmax, rows_dev=cnt, rows_plan=rows // 2)
+            d = torch.zeros(bound, 768, dtype=torch.bfloat16, device=dev)
+            d[:rows] = dy
+            y.backward(d)
+            return y[:rows].float(), xin.grad[:rows].float(), {n: p.grad.float().clone() for n, p in enc.named_parameters()}
+        xin = x.clone().requires_grad_(True)
+        y = enc.forward_rows(xin, starts, lens_d, nseq, lmax)
+        y.backward(dy)
+        return y.float(), xin.grad.float(), {n: p.grad.float().clone() for n, p in enc.named_parameters()}
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    torch.cuda.synchronize()
+    assert _rel(y1, y0) < 2e-3 and _rel(dx1, dx0) < 4e-3, (_rel(y1, y0), _rel(dx1, dx0))
+    for n in g0:
+        if g0[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"):
+            assert _rel(g1[n], g0[n]) < 4e-3, (n, _rel(g1[n], g0[n]))

@@ -33,7 +33,7 @@ def _bi_kwargs(d):
                 img_feats=_t(d, "img_feats"))
 
 
-@pytest.mark.parametrize("name", ["tiny_bi_pretrain", "cfg1_bi_pretrain", "tiny_bi_hn"])
+@pytest.mark.parametrize("name", ["tiny_bi_pretrain", "cfg1_bi_pretrain", "tiny_bi_hn", "tiny_bi_pretrain_nophrase", "cfg1_bi_pretrain_nophrase"])
 def test_bi_pretrain(name):
     from mvp_pytorch_amd.modeling import param_shapes
     d = gu.load(name)
@@ -41,10 +41,13 @@ def test_bi_pretrain(name):
     sd = _sd(param_shapes("BiBertImgForPreTraining", cfg), int(d["seed"]), float(d["weight_gain"]))
     for v in sd.values():
         v.requires_grad_(True)
+    nophrase = name.endswith("_nophrase")
     res, aux = orc.bi_bert_img_for_pretraining(
         sd, cfg, masked_lm_labels_a=_t(d, "lm_label_ids_a"), masked_lm_labels_b=_t(d, "lm_label_ids_b"),
-        max_tag_length=d["dims"]["G"], img_index=_t(d, "image_index"), phrase_index=_t(d, "phrase_index"),
-        draws=_draws(d), return_aux=True, **_bi_kwargs(d))
+        max_tag_length=d["dims"]["G"], img_index=None if nophrase else _t(d, "image_index"),
+        phrase_index=None if nophrase else _t(d, "phrase_index"),
+        draws=orc.Draws(randperm=list(d["draw_randperm"])) if nophrase else _draws(d), return_aux=True, **_bi_kwargs(d))
+    assert len(res) == (5 if nophrase else 6)      # vl:1309: the 5-tuple without word-region alignment
     got = np.array([x.item() for x in res])
     np.testing.assert_allclose(got, d["losses"], rtol=2e-5, atol=1e-6)
     assert np.array_equal(aux["hard_txt_index"].numpy(), d["hard_txt_index"])

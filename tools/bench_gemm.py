@@ -38,13 +38,13 @@ def main():
                   ("out  fwd  EPI_RESID", x, rnd(H, H), hip.EPI_BIAS_RESID, x),
                   ("ffn1 fwd  EPI_GELU", x, rnd(I, H), hip.EPI_BIAS_GELU, None),
                   ("ffn2 fwd  EPI_RESID", xi, rnd(H, I), hip.EPI_BIAS_RESID, x),
-                  ("ffn2 dgrad GELU_BWD", x, rnd(I, H), hip.EPI_GELU_BWD, xi),
+                  ("ffn2 dgrad GELU_BWD", x, rnd(I, H), hip.EPI_GELU_BWD, torch.randint(0, 256, (M, I), device=dev, dtype=torch.uint8)),
                   ("ffn1 dgrad EPI_ADD", xi, rnd(H, I), hip.EPI_ADD, x),
                   ("qkv  dgrad EPI_ADD", x3, rnd(H, 3 * H), hip.EPI_ADD, x)]
         for name, a, b, epi, aux in shapes:
             N, K = b.shape
             bias = torch.zeros(N, device=dev)
-            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            out = torch.empty(M, N, device=dev, dtype=torch.uint8 if epi == hip.EPI_BIAS_GELU else torch.bfloat16)
             out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
             vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
             us = timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec))

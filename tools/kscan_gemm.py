@@ -41,8 +41,10 @@ for M, N, epi, name in SHAPES:
             a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
             b = (torch.randn(N, K, device=dev) * 0.5).to(torch.bfloat16)
             bias = torch.zeros(N, device=dev)
-            aux = (torch.randn(M, N, device=dev)).to(torch.bfloat16) if epi in (hip.EPI_GELU_BWD, hip.EPI_BIAS_RESID) else None
-            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            aux = (torch.randn(M, N, device=dev)).to(torch.bfloat16) if epi == hip.EPI_BIAS_RESID else None
+            if epi == hip.EPI_GELU_BWD:
+                aux = torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8)
+            out = torch.empty(M, N, device=dev, dtype=torch.uint8 if epi == hip.EPI_BIAS_GELU else torch.bfloat16)
             out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
             vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
             ts.append(timeit(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out, out1=out1, vec_out=vec)))

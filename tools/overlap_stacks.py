@@ -24,7 +24,7 @@ class Stack:
         self.wq, self.wo, self.wi, self.wout = rnd(3 * H, H), rnd(H, H), rnd(I, H), rnd(H, I)
         self.b3, self.bh, self.bi = torch.zeros(3 * H, device=dev), torch.zeros(H, device=dev), torch.zeros(I, device=dev)
         self.o3, self.oh = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16), torch.empty(M, H, device=dev, dtype=torch.bfloat16)
-        self.oi, self.oi2 = torch.empty(M, I, device=dev, dtype=torch.bfloat16), torch.empty(M, I, device=dev, dtype=torch.bfloat16)
+        self.oi, self.oi2 = torch.empty(M, I, device=dev, dtype=torch.uint8), torch.empty(M, I, device=dev, dtype=torch.bfloat16)
         self.g = torch.ones(H, device=dev)
 
     def layer(self):

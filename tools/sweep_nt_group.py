@@ -36,9 +36,11 @@ for name, N, K, epi in SHAPES:
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     b = (torch.randn(N, K, device=dev) * 0.5).to(torch.bfloat16)
     bias = torch.zeros(N, device=dev)
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.uint8 if epi == hip.EPI_BIAS_GELU else torch.bfloat16)
     out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
-    aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (hip.EPI_BIAS_RESID, hip.EPI_GELU_BWD) else None
+    aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == hip.EPI_BIAS_RESID else None
+    if epi == hip.EPI_GELU_BWD:
+        aux = torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8)
     vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
     line = "M=%d %-12s N=%4d K=%4d" % (M, name, N, K)
     for o in ORDERS:

@@ -24,11 +24,13 @@ def run(cfg, M, N, K, epi, name, bm, bn):
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     b = (torch.randn(N, K, device=dev) * 0.5).to(torch.bfloat16)
     bias = torch.zeros(N, device=dev)
-    aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi in (hip.EPI_BIAS_RESID, hip.EPI_GELU_BWD) else None
+    aux = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == hip.EPI_BIAS_RESID else None
+    if epi == hip.EPI_GELU_BWD:
+        aux = torch.randint(0, 256, (M, N), device=dev, dtype=torch.uint8)
     nwg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     st = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     hip.set_knob("MVPTR_GEMM_STAMPS", str(st.data_ptr()))
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.uint8 if epi == hip.EPI_BIAS_GELU else torch.bfloat16)
     out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == hip.EPI_BIAS_GELU else None
     vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
     for _ in range(3):
