@@ -240,6 +240,36 @@ class DominantMix:
         self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.uint8),
                     torch.empty(M, I, device=dev, dtype=torch.bfloat16), 2.0 * M * I * H) for M in self.Ms]
 
+    def nt_all_launches(self):
+        """Every forward / data-gradient GEMM shape of an encoder layer (the gemm_nt_kernel family: Q/K/V, attention output,
+        FFN1 + GELU, FFN2, and their four data gradients) at the three row counts of the step -> [(fn, flops, bytes)]."""
+        hip, H, I = self.hip, self.H, self.I
+        dev = self.w.device
+        r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)  # noqa: E731
+        if not hasattr(self, "_nt_all"):
+            wq, wo, wi, wo2 = r(3 * H, H), r(H, H), r(I, H), r(H, I)
+            wqt, wit, wo2t = r(H, 3 * H), r(H, I), r(I, H)
+            out = []
+            for M in self.Ms:
+                x, xi, x3 = r(M, H), r(M, I), r(M, 3 * H)
+                gq = torch.randint(0, 256, (M, I), device=dev, dtype=torch.uint8)
+                o3, oh = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16), torch.empty(M, H, device=dev, dtype=torch.bfloat16)
+                oi, ou = torch.empty(M, I, device=dev, dtype=torch.bfloat16), torch.empty(M, I, device=dev, dtype=torch.uint8)
+                b3, bh, bi, vec = (torch.zeros(n, device=dev) for n in (3 * H, H, I, I))
+                E = hip
+                calls = [(x, wq, E.EPI_BIAS, dict(bias=b3, out=o3), 1), (x, wo, E.EPI_BIAS_RESID, dict(bias=bh, aux=x, out=oh), 2),
+                         (x, wi, E.EPI_BIAS_GELU, dict(bias=bi, out=ou, out1=oi), 1.5), (xi, wo2, E.EPI_BIAS_RESID, dict(bias=bh, aux=x, out=oh), 2),
+                         (x, wo2t, E.EPI_GELU_BWD, dict(aux=gq, out=oi, vec_out=vec), 1.5), (xi, wit, E.EPI_ADD, dict(aux=x, out=oh), 2),
+                         (x, wo, E.EPI_ADD, dict(out=oh), 1), (x3, wqt, E.EPI_ADD, dict(aux=x, out=oh), 2)]
+                for a, b, epi, kw, outs in calls:
+                    N, K = b.shape
+                    # operands once + outputs once (outs = bf16 matrices of [M, N] moved by the epilogue: output + aux, the
+                    # 8-bit gelu' stash counted as half)
+                    nbytes = 2.0 * M * K + 2.0 * N * K + 2.0 * M * N * outs
+                    out.append(((lambda a=a, b=b, epi=epi, kw=kw: hip.gemm_nt(a, b, epi, **kw)), 2.0 * M * N * K, nbytes))
+            self._nt_all = out
+        return self._nt_all
+
     def tn_launches(self):
         return [((lambda probs=probs: self.hip.gemm_tn_multi(probs)), f) for probs, f in self.tn]
 
@@ -301,9 +331,9 @@ def _pmc_traffic(kernel, packed=True):
     """HBM bytes per launch from the committed PMC passes (profiles/r02_dominant_traffic.json, made
     by tools/runs/r02_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
     WRITE_SIZE, FETCH_SIZE calibrated on a known 1-GiB stream by tools/calib_fetch.py), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_dominant_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_dominant_traffic.json")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(here, n) for n in ("r04_dominant_traffic.json", "r03_dominant_traffic.json", "r02_dominant_traffic.json")
+                 if os.path.exists(os.path.join(here, n))), os.path.join(here, "r04_dominant_traffic.json"))
     try:
         with open(path) as f:
             return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
@@ -317,25 +347,39 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     counts of the timed batch), timed with HIP events on the launch stream; the FFN1 forward GEMM
     (second by time) rides along."""
     mix = DominantMix(dev, dims, cfg, batch, single)
+    fam = mix.nt_all_launches()
+    fam_ms, fam_flops = _time_launches([(fn, f) for fn, f, _ in fam], 2, cold=True)
+    fam_hot_ms, _ = _time_launches([(fn, f) for fn, f, _ in fam], 3, cold=False)
+    fam_bytes = sum(b for _, _, b in fam) / len(fam)
     tn_ms, tn_flops = _time_launches(mix.tn_launches(), 3, cold=True)       # as inside the step: operands from HBM
     nt_ms, nt_flops = _time_launches(mix.nt_launches(), 3, cold=True)
     tn_hot_ms, _ = _time_launches(mix.tn_launches(), 4, cold=False)          # repeated back to back: Infinity-Cache resident
     nt_hot_ms, _ = _time_launches(mix.nt_launches(), 4, cold=False)
     tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
     nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
-    t_tn, t_nt = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_q_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>"))
-    return dict(bound="mfma", kernel="gemm_tn_q_kernel<4> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and "
-                                     "attention pair per layer; 256x256 tiles, four waves of 128x128; M = %s rows)" % " / ".join(str(m) for m in mix.Ms),
-                achieved=round(tn_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
+    t_tn, t_nt, t_fam = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_q_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernel (all epilogues)"))
+    fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
+    tn_entry = dict(kernel="gemm_tn_q_kernel<4> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and attention pair per layer; "
+                           "256x256 tiles, four waves of 128x128; 36 launches per step)",
+                    achieved=round(tn_ach, 1), frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
+                    avg_launch_us_back_to_back=round(tn_hot_ms * 1e3, 1), flop_per_launch=tn_flops,
+                    algorithmic_bytes_per_launch=round(mix.tn_bytes()), traffic=(t_tn or {}).get("bytes_per_launch"))
+    # The dominant kernel by total time is the gemm_nt_kernel FAMILY (every forward and data-gradient GEMM of the encoder
+    # layers, 144 launches and ~half of the kernel time of a step; VERDICT r03: report it, not only the largest single
+    # instantiation); the grouped weight-gradient kernel follows as second_kernel.
+    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI, 64, 2, 2, 4, 8> family: the 8 forward / data-gradient GEMMs of an encoder layer "
+                                     "(Q/K/V, attention output, FFN1 + GELU, FFN2 and their data gradients; fused bias / residual / dropout / "
+                                     "GELU epilogues) at M = %s rows, 144 launches per step" % " / ".join(str(m) for m in mix.Ms),
+                achieved=round(fam_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(fam_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(fam_ms * 1e3, 1),
                 timing="each launch behind a 768-MB write (operands from HBM, as inside the step); back to back (Infinity-Cache "
                        "resident operands): avg_launch_us_back_to_back",
-                avg_launch_us_back_to_back=round(tn_hot_ms * 1e3, 1), flop_per_launch=tn_flops, algorithmic_bytes_per_launch=round(mix.tn_bytes()),
-                traffic=(t_tn or {}).get("bytes_per_launch"),
-                traffic_source="profiles/r03_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                avg_launch_us_back_to_back=round(fam_hot_ms * 1e3, 1), flop_per_launch=fam_flops, algorithmic_bytes_per_launch=round(fam_bytes),
+                traffic=(t_fam or {}).get("bytes_per_launch"), second_kernel=tn_entry,
+                traffic_source="profiles/r04_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
                                "tools/prof_dominant.py; FETCH_SIZE divided by the factor measured on a known 1-GiB LDS-DMA stream, "
                                "tools/calib_fetch.py)",
-                second_kernel=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu and gelu')",
+                ffn1_forward=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu in bf16 and gelu' as 8-bit fixed point; a member of the family)",
                                    achieved=round(nt_ach, 1), frac=round(nt_ach / MFMA_BF16_PEAK_TFLOPS, 4),
                                    avg_launch_us=round(nt_ms * 1e3, 1), avg_launch_us_back_to_back=round(nt_hot_ms * 1e3, 1),
                                    algorithmic_bytes_per_launch=round(mix.nt_bytes()),
@@ -537,6 +581,8 @@ def main():
     ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams as at N = 1")
     ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream, as multi-rank jobs run by default")
     ap.add_argument("--no-arena", action="store_true", help="N = 1: gradients through autograd tensors instead of the gradient arena (A/B)")
+    ap.add_argument("--count-readbacks", action="store_true",
+                    help="A/B: the round-3 step — row counts read back from the device inside the step (no host_counts, joint pass sized exactly)")
     ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--budget", type=float, default=10.0, help=argparse.SUPPRESS)
@@ -586,6 +632,8 @@ def main():
         cfg = dict(cfg, parallel_stacks="always")
     if args.one_stream:
         cfg = dict(cfg, parallel_stacks=False)
+    if args.count_readbacks:
+        cfg = dict(cfg, sync_free_joint=False)
     model = cls(modeling.make_config(cfg)).to(dev)
     model.train()
     if single:
@@ -604,7 +652,10 @@ def main():
         sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
 
     def make_batch(fixed):
-        return synthetic_batch(dims, cfg, 1234 + rank, single_stream=single, fixed_length=fixed, device=dev)
+        b = synthetic_batch(dims, cfg, 1234 + rank, single_stream=single, fixed_length=fixed, device=dev)
+        if args.count_readbacks:
+            b.pop("host_counts", None)
+        return b
 
     def fence():
         if world > 1:

@@ -416,6 +416,12 @@ typedef struct {
 int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, int32_t* pos_out, int32_t* idx_out,
                     int32_t* seq_start, int32_t* seq_len, int64_t* counts, void* stream);
 
+/* Host-provided counts against the device's: counts_a / counts_b are the `counts` outputs of two mvptr_pack_maps calls (int64 [2]:
+ * rows, longest); a value that differs from the host's number traps the kernel (the process aborts with a message): host counts
+ * that do not describe the batch would silently truncate or over-read the packed rows. */
+int mvptr_check_counts(const int64_t* counts_a, const int64_t* counts_b, int64_t rows_a, int64_t lmax_a, int64_t rows_b, int64_t lmax_b,
+                       void* stream);
+
 /* Word-region alignment loss (phrase_mod == 'sample'), replaces oscar/modeling/modeling_vlbert.py:1285-1300 with
  * get_pos_neg_sims :1553-1596 and t2i_sim :1543-1550 on rows already gathered from the joint output:
  * txt bf16 [n, Pw, H] (row k of sample i = its k-th phrase row, rows beyond phrase_index[i,1] - phrase_index[i,0] are

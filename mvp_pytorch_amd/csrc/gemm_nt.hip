@@ -386,7 +386,12 @@ void gemm_nt_kernel(GemmNtArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = p.tiles_m * p.tiles_n;
+  // device-side row count (sync-free joint pass): the tile grid is laid over the rows that are really there, exactly as a
+  // launch of that size would lay it (valid tiles evenly spread over the XCDs); the surplus workgroups return at once
+  const int Mv = rows_clamped(p.M, p.rows_dev);
+  const int tiles_m = (p.rows_dev != nullptr) ? (Mv + BM - 1) / BM : p.tiles_m;
+  const int nwg = tiles_m * p.tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
 #ifdef MVPTR_TIMELINE_BUILD
   // diagnostic: wall-clock (100 MHz s_memrealtime) start / loop-end / end of every workgroup
   unsigned long long tl_start, tl_loop, tl_end;
@@ -396,7 +401,7 @@ void gemm_nt_kernel(GemmNtArgs p) {
   // order of the logical tiles (an XCD owns a contiguous run of them): column tiles in chunks of
   // group_n; inside a chunk, groups of group_m row tiles x the chunk's columns, row tile fastest.
   // A chunk narrower than the matrix keeps that part of B in the XCD's L2 while its rows stream by.
-  const int chunk_full = p.tiles_m * p.group_n;
+  const int chunk_full = tiles_m * p.group_n;
   const int chunk = t / chunk_full;
   const int cn0 = chunk * p.group_n;
   const int cn = min(p.group_n, p.tiles_n - cn0);
@@ -404,13 +409,11 @@ void gemm_nt_kernel(GemmNtArgs p) {
   const int gsz = p.group_m * cn;
   const int grp = tc / gsz;
   const int first_m = grp * p.group_m;
-  const int gm = min(p.group_m, p.tiles_m - first_m);
+  const int gm = min(p.group_m, tiles_m - first_m);
   const int in_g = tc - grp * gsz;
   const int tm = first_m + in_g % gm;
   const int tn = cn0 + in_g / gm;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int Mv = rows_clamped(p.M, p.rows_dev);     // device-side row count (sync-free joint pass): tiles past it do nothing
-  if (m0 >= Mv) return;
   const int rows_a = min(BM, Mv - m0);
   const int rows_b = min(BN, p.N - n0);
 
@@ -753,10 +756,22 @@ __device__ __forceinline__ constexpr int ntp_stores() {
   return EPI == MVPTR_EPI_BIAS_GELU ? 32 : 16;
 }
 
-template <int EPI>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// DEFER (MVPTR_GEMM_CFG=pd): the finished tile's bf16 output stays in 64 registers per lane and ONE store goes out behind each
+// of the first 16 K-steps of the next tile (a CU sustains ~70 cycles per store instruction: 128 of them in a burst hold the
+// address path — and the LDS-DMA behind them — for 4.5 us; one per step is noise).  The BK 32 ring leaves the registers for it
+// (182 without).  EPI_BIAS_GELU defers gelu(u) and stores the 8-bit gelu' stash at once.
+template <int EPI, bool DEFER>
 __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
   constexpr int OP_BYTES = 256 * 64, STAGE_BYTES = 2 * OP_BYTES, NSTAGE = 4;
-  constexpr int MT = 8, LPS = 4, S = ntp_stores<EPI>();
+  constexpr int MT = 8, LPS = 4, S = DEFER ? (EPI == MVPTR_EPI_BIAS_GELU ? 16 : 0) : ntp_stores<EPI>();   // stores issued AT the tile end
   constexpr bool kBias = (EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID);
   constexpr bool kAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_ADD);
   constexpr int AUXW = (EPI == MVPTR_EPI_GELU_BWD) ? 2 : 4;   // dwords of aux per lane and (row block, column pair)
@@ -858,44 +873,69 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
 #define NTP_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
 
   int g = 0, buf = 0;
+  // one K-step on the current ring buffer: 12 fragment reads, four groups of eight MFMAs with one LDS-DMA instruction of
+  // stage g + 3 behind each (into the buffer step g - 1 read: every wave has passed this step's barrier, so it is free)
+  auto kbody = [&]() {
+    const char* base = lds + buf * STAGE_BYTES;
+    bf16x8 xf[MT], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + fw0 + i * 1024);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(base + fx0 + i * 1024);
+    const bool do_issue = iss_g < total;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+      for (int mt = 2 * grp; mt < 2 * grp + 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_issue) stage_piece(iss_buf, rsA, rsB, iss_k, grp);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (do_issue) advance_issue();
+    ++g;
+    buf = (buf + 1) & (NSTAGE - 1);
+  };
+  // deferred output of the previous tile (DEFER): 16 x 16 bytes per lane, its descriptor, the lane's byte offset in a tile
+  u32x4 pend[DEFER ? MT : 1][2];
+  __amdgpu_buffer_rsrc_t rsP = make_rsrc_uniform(p.out0, 0u);
+  uint32_t pend_off = 0;
+  auto store_pending = [&](auto k_tag) {
+    constexpr int k = decltype(k_tag)::value;
+    const uint32_t vo = pend_off + (uint32_t)(((k >> 1) * 16 * p.ldc + (k & 1) * 32) * 2);
+    __builtin_amdgcn_raw_buffer_store_b128(pend[DEFER ? (k >> 1) : 0][k & 1], rsP, vo, 0, 0);
+  };
   for (int ti = 0; ti < ntiles; ++ti) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt = 0;
+    if (DEFER && ti > 0) {
+      // The queue behind stage g's LDS-DMA holds the two younger stages (8) and the pending stores of the last three steps
+      // (one per step while steps 0..15 run), plus — in the first three steps — whatever the previous tile end stored at once.
+      static_for<0, 19>([&](auto kt_tag) {
+        constexpr int KT = decltype(kt_tag)::value;
+        constexpr int ST = KT <= 16 ? (KT < 3 ? KT : 3) : (KT == 17 ? 2 : 1);
+        NTP_WAIT_BARRIER(2 * LPS + ST + (KT < 3 ? S : 0));
+        kbody();
+        if constexpr (KT < 16) store_pending(kt_tag);
+      });
+      kt = 19;
+    }
+    for (; kt < nk; ++kt) {
       // stage g has landed once only the (up to two) younger stages — and, in the first three steps of a tile that
       // is not the workgroup's first, the previous epilogue's stores, which were issued behind them — remain
       const int younger = min(NSTAGE - 2, total - 1 - g);
-      if (ti > 0 && kt < NSTAGE - 1) NTP_WAIT_BARRIER(2 * LPS + S);
+      if (!DEFER && ti > 0 && kt < NSTAGE - 1) NTP_WAIT_BARRIER(2 * LPS + S);
       else if (younger == 2) NTP_WAIT_BARRIER(2 * LPS);
       else if (younger == 1) NTP_WAIT_BARRIER(LPS);
       else NTP_WAIT_BARRIER(0);
-      const char* base = lds + buf * STAGE_BYTES;
-      bf16x8 xf[MT], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + fw0 + i * 1024);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(base + fx0 + i * 1024);
-      const bool do_issue = iss_g < total;
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int grp = 0; grp < 4; ++grp) {
-#pragma unroll
-        for (int mt = 2 * grp; mt < 2 * grp + 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // one of the four LDS-DMA instructions of stage g + 3 (into the buffer step g - 1 read: every wave has passed
-        // this step's barrier, so it is free) behind each group of eight MFMAs
-        if (do_issue) stage_piece(iss_buf, rsA, rsB, iss_k, grp);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (do_issue) advance_issue();
-      ++g;
-      buf = (buf + 1) & (NSTAGE - 1);
+      kbody();
     }
     // ------------------------------------------------------------------ epilogue, from the accumulators
     // epilogue geometry: after the lane-row swap a lane owns 8 consecutive columns of the pair's 32: block (q4 & 1) of
@@ -967,6 +1007,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
                               keep * (uint32_t)(((int64_t)(rows_valid - 1) * p.ldc + 256) * 2))
           : rsO;
       const uint32_t ooff = (uint32_t)(erow * p.ldc + ecol);    // elements
+      if constexpr (DEFER) {
+        rsP = (EPI == MVPTR_EPI_BIAS_GELU) ? rsO1 : rsO;
+        pend_off = ooff * 2;
+      }
       float cs[2][8];
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
@@ -1009,6 +1053,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(x[e]);
+            if constexpr (DEFER) {
+              pend[DEFER ? mt : 0][pr] = __builtin_bit_cast(u32x4, o);      // goes out during the next tile's first 16 steps
+              return;
+            }
 #ifdef MVPTR_DIAG_BUILD
             if (p.store_mode == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 2);
             else if (p.store_mode == 3) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, eo * 2, 0, 16);
@@ -1074,6 +1122,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
     my += G;
     if (ti + 1 < ntiles) tile_m0n0(my, m0, n0);
   }
+  if constexpr (DEFER) static_for<0, 16>([&](auto k_tag) { store_pending(k_tag); });      // the last tile's output
 #undef NTP_WAIT_BARRIER
 }
 
@@ -1103,12 +1152,12 @@ bool ntp_eligible(const GemmNtArgs& a) {
   return true;
 }
 
-template <int EPI>
+template <int EPI, bool DEFER>
 int launch_ntp(GemmNtArgs a, hipStream_t s) {
   constexpr int LDS_BYTES = 4 * 2 * 256 * 64;
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = a.N / 256;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, DEFER>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
   const bool chunked = a.tiles_n > 4;
@@ -1124,7 +1173,7 @@ int launch_ntp(GemmNtArgs a, hipStream_t s) {
   int grid = (nwg + rounds - 1) / rounds;
   const int grid8 = (grid + 7) & ~7;
   if (grid8 <= ncu && grid8 <= nwg) grid = grid8;
-  hipLaunchKernelGGL((gemm_ntp_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((gemm_ntp_kernel<EPI, DEFER>), dim3(grid), dim3(512), LDS_BYTES, s, a);
   MVPTR_CHECK_LAUNCH("gemm_nt");
   return MVPTR_OK;
 }
@@ -1183,7 +1232,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
     if (env[0] == 'p') {                                                  // "p": persistent ring experiment
       if constexpr (EPI == MVPTR_EPI_BIAS || EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD ||
                     EPI == MVPTR_EPI_ADD) {
-        if (ntp_eligible<EPI>(a)) return launch_ntp<EPI>(a, s);
+        if (ntp_eligible<EPI>(a)) return (env[1] == 'd' && a.K >= 32 * 24) ? launch_ntp<EPI, true>(a, s) : launch_ntp<EPI, false>(a, s);   // "pd": deferred stores
       }
       return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
     }

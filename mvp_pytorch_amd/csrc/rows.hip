@@ -208,3 +208,25 @@ extern "C" int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f
   MVPTR_CHECK_LAUNCH("scatter_add_rows");
   return MVPTR_OK;
 }
+
+
+// Host-provided counts against the device's (sync-free training step: the input-only counts of a batch come from where
+// the batch was built; the pack maps count them again on the device).  A mismatch is a caller bug that would silently
+// truncate or over-read the packed rows: trap.
+namespace {
+__global__ void check_counts_kernel(const int64_t* a, const int64_t* b, int64_t ra, int64_t la, int64_t rb, int64_t lb) {
+  if (a[0] != ra || a[1] != la || b[0] != rb || b[1] != lb) {
+    printf("mvptr_check_counts: host counts (%ld, %ld, %ld, %ld) != device counts (%ld, %ld, %ld, %ld)\n", (long)ra, (long)la, (long)rb,
+           (long)lb, (long)a[0], (long)a[1], (long)b[0], (long)b[1]);
+    __builtin_trap();
+  }
+}
+}  // namespace
+
+extern "C" int mvptr_check_counts(const int64_t* counts_a, const int64_t* counts_b, int64_t rows_a, int64_t lmax_a, int64_t rows_b,
+                                  int64_t lmax_b, void* stream) {
+  if (!counts_a || !counts_b) MVPTR_FAIL(MVPTR_BAD_ARG, "check_counts: NULL argument");
+  hipLaunchKernelGGL(check_counts_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counts_a, counts_b, rows_a, lmax_a, rows_b, lmax_b);
+  MVPTR_CHECK_LAUNCH("check_counts");
+  return MVPTR_OK;
+}

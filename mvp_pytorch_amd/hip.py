@@ -33,7 +33,7 @@ SYMBOLS = [
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
-    "mvptr_hard_negative_mine", "mvptr_bce_logits",
+    "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts",
 ]
 
 
@@ -126,6 +126,7 @@ def load():
     lib.mvptr_ce_mean_small.argtypes = [P, I64, P, I, I, P, P, P]
     lib.mvptr_hard_negative_mine.argtypes = [P, I, I64, P, P, P, P, P, P, P, P]
     lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
+    lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
     lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
     lib.mvptr_clip_ce_fwd.argtypes = [P, I, I64, P, P, P, P, P]
@@ -657,6 +658,12 @@ def pack_maps(segs, n_seq, fill_idx=False):
     counts = torch.empty(2, device=dev, dtype=torch.int64)
     _check(load().mvptr_pack_maps(arr, len(segs), n_seq, _p(pos_out), _p(idx_out), _p(seq_start), _p(seq_len), _p(counts), _stream()))
     return pos_out, idx_out, seq_start, seq_len, counts
+
+
+def check_counts(counts_a, counts_b, expect):
+    """mvptr_check_counts: the device-side counts of two pack_maps calls (int64 [2] each: rows, longest) must equal the
+    host's numbers `expect` = (rows_a, lmax_a, rows_b, lmax_b); a mismatch traps the kernel (the process aborts)."""
+    _check(load().mvptr_check_counts(_p(counts_a), _p(counts_b), int(expect[0]), int(expect[1]), int(expect[2]), int(expect[3]), _stream()))
 
 
 def wra_rows(pos, phrase_index, img_index, n, Pw, Rw):

@@ -294,7 +294,8 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         # the joint + hard-negative pass of the packed pipeline without reading its row count back (mvptr_layer_desc.rows_dev);
         # config.sync_free_joint = False: wait for the count and size the pass exactly
         self.sync_free_joint = bool(getattr(config, "sync_free_joint", True))
-        self._joint_rows_seen = None       # engine.AsyncCounts of the previous step's joint row count: the planning hint
+        self._joint_rows_seen = []         # engine.AsyncCounts of recent steps' joint row counts, oldest first
+        self._joint_plan = 0               # the latest count that has landed: the planning hint (0: none yet -> the bound)
         self.apply(self.init_weights)
 
     # -- stage 1: uni-modal encoders (vl:479-513)
@@ -548,8 +549,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             main.wait_stream(side)
         if host_counts is not None:
             ra, la_max, rb, lb_max = (int(host_counts[k]) for k in ("rows_a", "lmax_a", "rows_b", "lmax_b"))
-            ok = (cnt_a[0] == ra) & (cnt_a[1] == la_max) & (cnt_b[0] == rb) & (cnt_b[1] == lb_max)
-            torch._assert_async(ok, "host_counts do not describe this batch's attention masks")
+            hip.check_counts(cnt_a, cnt_b, (ra, la_max, rb, lb_max))      # device-side: host_counts must describe this batch's masks
         else:
             ra, la_max, rb, lb_max = counts.get()
         xa_p = engine.tap_rows(xa.view(B * La, H), idx_a[:ra])
@@ -610,10 +610,15 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             # sized for its bound (every slot valid): the gather yields zero rows past the count (idx = -1), every layer
             # kernel clamps to the device-side count (workgroups past it return at once) and the launches are planned
             # for the previous step's count, which has long landed.
-            prev, self._joint_rows_seen = self._joint_rows_seen, cj
-            plan = prev.get()[0] if (prev is not None and prev.ready()) else 0
+            # the latest count that has LANDED is the hint (the host may run more than a step ahead of the device: a copy that
+            # is still in flight is simply left for a later step — nothing here waits)
+            pend = self._joint_rows_seen
+            while pend and pend[0].ready():
+                self._joint_plan = pend.pop(0).get()[0]
+            pend.append(cj)
+            del pend[:-8]
             xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j)[0]
-            both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, La + Lb - cut, rows_dev=cnt_j, rows_plan=plan)
+            both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, La + Lb - cut, rows_dev=cnt_j, rows_plan=self._joint_plan)
         else:
             rj, lj_max = cj.get()
             xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j[:rj])[0]

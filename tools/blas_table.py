@@ -41,11 +41,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--ab", action="store_true", help="diagnostic library (MVPTR_LIB=diag): also time the persistent ring "
                                                       "experiment (MVPTR_GEMM_CFG=p, gemm_ntp_kernel)")
+    ap.add_argument("--cfg", default="p", help="with --ab: the MVPTR_GEMM_CFG value of the extra column (p, v4, w4, s128, t256k)")
     args = ap.parse_args()
     H, I = 768, 3072
     flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
     print("%-22s %6s %5s %5s  %9s %8s  %9s %8s  %6s%s" % ("gemm (epilogue)", "M", "N", "K", "ours us", "TF/s", "blasLt us", "TF/s", "ratio",
-                                                           "   P-ring us" if args.ab else ""))
+                                                           ("   %s us" % args.cfg) if args.ab else ""))
     tot_ours = tot_lib = tot_old = 0.0
     for M in [int(v) for v in args.ms.split(",")]:
         x, xi, x3 = rnd(M, H), rnd(M, I), rnd(M, 3 * H)
@@ -67,7 +68,7 @@ def main():
             ours = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
             old = None
             if args.ab:
-                hip.set_knob("MVPTR_GEMM_CFG", "p")
+                hip.set_knob("MVPTR_GEMM_CFG", args.cfg)
                 old = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
                 hip.set_knob("MVPTR_GEMM_CFG", "")
                 tot_old += old
@@ -78,7 +79,7 @@ def main():
             tot_lib += lib
             print("%-22s %6d %5d %5d  %9.1f %8.1f  %9.1f %8.1f  %6.2f%s" % (name, M, N, K, ours, fl / ours / 1e6, lib, fl / lib / 1e6, ours / lib,
                                                                              "   %8.1f" % old if old is not None else ""))
-    print("sum: ours %.1f us, hipBLASLt (no epilogue) %.1f us%s" % (tot_ours, tot_lib, ", persistent ring %.1f us" % tot_old if args.ab else ""))
+    print("sum: ours %.1f us, hipBLASLt (no epilogue) %.1f us%s" % (tot_ours, tot_lib, ", %s %.1f us" % (args.cfg, tot_old) if args.ab else ""))
 
 
 if __name__ == "__main__":

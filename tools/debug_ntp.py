@@ -10,8 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvp_pytorch_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
+CFG = os.environ.get("NTP_CFG", "p")
 if os.environ.get("MVPTR_LIB") == "diag":
-    hip.set_knob("MVPTR_GEMM_CFG", "p")
+    hip.set_knob("MVPTR_GEMM_CFG", CFG)
 
 
 def run(M, N, K):
@@ -47,3 +48,39 @@ def run(M, N, K):
 
 for M, N, K in ((4200, 2304, 768), (256 * 70, 768, 256), (70000, 768, 768)):
     run(M, N, K)
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def epilogues(M, N, K):
+    """every epilogue of the experiment kernel against f32 torch (several tiles per workgroup)"""
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    aux = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    base = a.float() @ b.float().t()
+    errs = {}
+    errs["bias"] = rel(hip.gemm_nt(a, b, hip.EPI_BIAS, bias=bias), base + bias)
+    dq, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+    u = (base + bias).requires_grad_(True)
+    ar = torch.nn.functional.gelu(u)
+    ar.sum().backward()
+    errs["gelu"] = rel(act, ar.detach())
+    errs["dgelu_abs"] = (hip.dgelu_decode(dq) - u.grad).abs().max().item()
+    errs["resid"] = rel(hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux), base + bias + aux.float())
+    errs["add"] = rel(hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux), base + aux.float())
+    gq = hip.dgelu_encode(torch.rand(M, N, generator=g) * 1.25 - 0.125).to(dev)
+    vec = torch.zeros(N, device=dev)
+    errs["gelu_bwd"] = rel(hip.gemm_nt(a, b, hip.EPI_GELU_BWD, aux=gq, vec_out=vec), base * hip.dgelu_decode(gq))
+    errs["colsum"] = rel(vec, (base * hip.dgelu_decode(gq)).sum(0))
+    print("cfg %s M %d N %d K %d:" % (CFG, M, N, K), {k: "%.2e" % v for k, v in errs.items()})
+    assert all(v < 5e-3 for v in errs.values()), errs
+
+
+epilogues(70000, 768, 768)
+epilogues(33100, 2304, 768)
+epilogues(20000, 768, 3072)

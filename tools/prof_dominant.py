@@ -2,7 +2,7 @@
 """Replay of the dominant kernel's per-step launch mix for rocprofv3 passes: the grouped
 weight-gradient launches (gemm_tn_kernel) of the encoder layers — FFN pair (dW_out, dW_i) and
 attention pair (dW_o, dW_qkv + b_qkv) at the three row counts of a configs[1] step — plus the
-second kernel by time (FFN1 forward GEMM with the GELU epilogue).  bench.py times the same mix."""
+gemm_nt_kernel family (the eight forward / data-gradient GEMMs of a layer at the same row counts).  bench.py times the same mix."""
 import os
 import sys
 
@@ -23,7 +23,7 @@ print("rows per launch group:", mix.Ms)
 cold = os.environ.get("PROF_COLD") == "1"      # every launch behind a 768-MB write, as bench.py times them
 flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev) if cold else None
 for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
-    for fn, _ in mix.tn_launches() + mix.nt_launches():
+    for fn in [f for f, _ in mix.tn_launches()] + [f for f, _, _ in mix.nt_all_launches()]:
         if cold:
             flush.fill_(r)
         fn()

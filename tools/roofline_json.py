@@ -62,5 +62,32 @@ for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots
             res[key]["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
                                    "frac_of_peak": flop / us_in / 1e6 / PEAK,
                                    "source": "rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3 --no-extras (timed region + warm-up)"}
+# the gemm_nt_kernel family (every forward / data-gradient GEMM of the encoder layers: 8 shapes x 3 row counts in the replay)
+def nt_mix(Ms):
+    fl, by = [], []
+    for M in Ms:
+        for N, K, outs in ((3 * H, H, 1), (H, H, 2), (I, H, 1.5), (H, I, 2), (I, H, 1.5), (H, I, 2), (H, H, 1), (H, 3 * H, 2)):
+            fl.append(2.0 * M * N * K)
+            by.append(2.0 * M * K + 2.0 * N * K + 2.0 * M * N * outs)
+    return sum(fl) / len(fl), sum(by) / len(by)
+
+
+res["gemm_nt_family"] = {"_what": "gemm_nt_kernel<EPI, 64, 2, 2, 4, 8>: the eight forward / data-gradient GEMMs of an encoder layer with their fused "
+                                  "epilogues, mean over the 24 launches of the replay (8 shapes x 3 row counts); in_step: every gemm_nt_kernel of the "
+                                  "traced training steps with that tile configuration (the layers' 144 launches per step + the region-embedding GEMM)"}
+for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
+    us, calls = avg_us(path, "gemm_nt_kernel")
+    flop, alg = nt_mix(Ms)
+    t = tr.get(key, {}).get("gemm_nt_kernel (all epilogues)", {})
+    ent = {"avg_launch_us": us, "launches_profiled": calls, "flop_per_launch": flop, "achieved_tflops": flop / us / 1e6 if us else None,
+           "frac_of_peak": flop / us / 1e6 / PEAK if us else None, "algorithmic_bytes_per_launch": alg,
+           "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
+           "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
+    if bench_csv[key]:
+        us_in, calls_in = avg_us(bench_csv[key], "64, 2, 2, 4, 8, 0>")
+        if us_in:
+            ent["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
+                              "frac_of_peak": flop / us_in / 1e6 / PEAK}
+    res["gemm_nt_family"][key] = ent
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
