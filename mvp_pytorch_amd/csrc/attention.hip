@@ -116,6 +116,34 @@ __device__ __forceinline__ f32x16 zero16() {
 // row index held in accumulator register r by lane half hh (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
+// Output rows through LDS (round 4).  The accumulators hold an output TRANSPOSED (row on the lane, 4 consecutive
+// columns per register quad), so a direct store instruction wrote 8 bytes per lane = 16 bytes of each of 32 different
+// 128-byte lines, eight instructions per line; measured on the packed joint stack those partial-line stores were 56 of
+// the backward kernel's 196 us (profiles/r04_experiments.txt: the CU's vector memory path is paid per line touched).
+// put_block32 writes a 32-row x 64-column f32 accumulator pair as bf16 into a 4-KiB tile block (rows = the lane's row,
+// the tiles' own chunk swizzle), store_block32 reads it back 16 bytes per lane, 8 lanes per row, and stores whole
+// lines: 4 instructions per block instead of 8, each touching 8 lines instead of 32.  `blk` must be private to the wave.
+__device__ __forceinline__ void put_block32(char* blk, const f32x16 (&acc)[2], float scale, int l31, int hh) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const bf16x4 v = {f2bf(acc[db][4 * t4] * scale), f2bf(acc[db][4 * t4 + 1] * scale),
+                        f2bf(acc[db][4 * t4 + 2] * scale), f2bf(acc[db][4 * t4 + 3] * scale)};
+      *reinterpret_cast<bf16x4*>(blk + tile_off(l31, 4 * db + t4) + 8 * hh) = v;
+    }
+}
+// dst: row 0 of the block in global memory, column 0 of the head; rows_left: rows of the block inside the sequence
+__device__ __forceinline__ void store_block32(const char* blk, __bf16* dst, int64_t ld, int rows_left, int lane) {
+  const int c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(blk + tile_off(row, c));
+    if (row < rows_left) *reinterpret_cast<bf16x8*>(dst + (int64_t)row * ld + 8 * c) = v;
+  }
+}
+
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
 // ------------------------------------------------------------------------------------ forward
@@ -212,16 +240,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tV, lo_, 2 * kb + s, db), pb, o[db], 0, 0, 0);
       }
     }
-    if (q < L) {
-      __bf16* dst = p.ctx + (row0 + q) * H + hd * 64;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          bf16x4 v = {f2bf(o[db][4 * t4]), f2bf(o[db][4 * t4 + 1]), f2bf(o[db][4 * t4 + 2]), f2bf(o[db][4 * t4 + 3])};
-          *reinterpret_cast<bf16x4*>(dst + 32 * db + 8 * t4 + 4 * hh) = v;
-        }
-    }
+    // block qb of the Q tile is this wave's alone (its fragments went into registers above): the transpose buffer
+    put_block32(tQ + qb * 4096, o, 1.0f, l31, hh);
+    store_block32(tQ + qb * 4096, p.ctx + (row0 + 32 * qb) * H + hd * 64, H, L - 32 * qb, lane);
   }
 }
 
@@ -477,22 +498,24 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   stage_tile(tV, base + 2 * H, ldq, L, Lp, wave, lane);
   stage_tile(tD, dob, H, L, Lp, wave, lane);
   for (int i = tid; i < Lp; i += 256) {
-    float mk = -INFINITY, ls = 0.f, dl = 0.f;
-    if (i < L) {
-      mk = (p.mask != nullptr) ? p.mask[row0 + i] : 0.f;
-      ls = p.lse[(int64_t)bh * LT + i];
-      const bf16x8* a = reinterpret_cast<const bf16x8*>(dob + (int64_t)i * H);
-      const bf16x8* c = reinterpret_cast<const bf16x8*>(ob + (int64_t)i * H);
+    maskv[i] = (i < L) ? ((p.mask != nullptr) ? p.mask[row0 + i] : 0.f) : -INFINITY;
+    lsev[i] = (i < L) ? p.lse[(int64_t)bh * LT + i] : 0.f;
+  }
+  // delta[q] = dO[q] . O[q]: 8 lanes per row, 16 bytes each (a wave instruction reads 8 whole lines; one lane per row
+  // touched 64 lines per instruction: 24 us of the joint stack's 196, profiles/r04_experiments.txt)
+  for (int g8 = wave; g8 < (Lp >> 3); g8 += 4) {
+    const int row = 8 * g8 + (lane >> 3), c = lane & 7;
+    float dl = 0.f;
+    if (row < L) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(dob + (int64_t)row * H + 8 * c);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(ob + (int64_t)row * H + 8 * c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const bf16x8 x = a[j], y = c[j];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
-      }
+      for (int e = 0; e < 8; ++e) dl += bf2f(x[e]) * bf2f(y[e]);
     }
-    maskv[i] = mk;
-    lsev[i] = ls;
-    deltav[i] = dl;
+    dl = MVPTR_DPP_ADD(dl, 0xB1);    // quad_perm [1,0,3,2]
+    dl = MVPTR_DPP_ADD(dl, 0x4E);    // quad_perm [2,3,0,1]
+    dl = MVPTR_DPP_ADD(dl, 0x141);   // row_half_mirror: the other quad of the 8 lanes
+    if (c == 0) deltav[row] = dl;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -595,23 +618,15 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   }
   __syncthreads();
   if (owner) {
-    if (key < L) {
-      __bf16* dK = dq_base + (int64_t)key * ldq + H;
-      __bf16* dV = dq_base + (int64_t)key * ldq + 2 * H;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          const int d = 32 * db + 8 * t4 + 4 * hh;
-          bf16x4 a = {f2bf(dk[db][4 * t4] * 0.125f), f2bf(dk[db][4 * t4 + 1] * 0.125f),
-                      f2bf(dk[db][4 * t4 + 2] * 0.125f), f2bf(dk[db][4 * t4 + 3] * 0.125f)};
-          bf16x4 c = {f2bf(dv[db][4 * t4]), f2bf(dv[db][4 * t4 + 1]), f2bf(dv[db][4 * t4 + 2]), f2bf(dv[db][4 * t4 + 3])};
-          *reinterpret_cast<bf16x4*>(dK + d) = a;
-          *reinterpret_cast<bf16x4*>(dV + d) = c;
-        }
-    }
+    // Q is not read after phase 1: block `wave` of its tile is this wave's transpose buffer for dK, dV and dQ
+    char* tb = tQ + wave * 4096;
+    __bf16* out0 = dq_base + (int64_t)(32 * wave) * ldq;
+    put_block32(tb, dk, 0.125f, l31, hh);
+    store_block32(tb, out0 + H, ldq, L - 32 * wave, lane);
+    put_block32(tb, dv, 1.0f, l31, hh);
+    store_block32(tb, out0 + 2 * H, ldq, L - 32 * wave, lane);
     // ---------------- phase 2: query block `wave`; query on lane: dQ^T += K^T · dS^T over all key blocks
-    const int qb = wave, q = key;
+    const int qb = wave;
     const char* ts = (qb >> 1) ? tD : tV;
     f32x16 dq[2] = {zero16(), zero16()};
     for (int kb = 0; kb < nb; ++kb) {
@@ -623,17 +638,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
           dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_o(tK, lo_, 2 * kb + st, db), dsb, dq[db], 0, 0, 0);
       }
     }
-    if (q < L) {
-      __bf16* dQ = dq_base + (int64_t)q * ldq;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          bf16x4 a = {f2bf(dq[db][4 * t4] * 0.125f), f2bf(dq[db][4 * t4 + 1] * 0.125f),
-                      f2bf(dq[db][4 * t4 + 2] * 0.125f), f2bf(dq[db][4 * t4 + 3] * 0.125f)};
-          *reinterpret_cast<bf16x4*>(dQ + 32 * db + 8 * t4 + 4 * hh) = a;
-        }
-    }
+    put_block32(tb, dq, 0.125f, l31, hh);
+    store_block32(tb, out0, ldq, L - 32 * wave, lane);
   }
 #ifdef MVPTR_TIMELINE_BUILD
   {
