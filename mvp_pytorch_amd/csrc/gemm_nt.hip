@@ -51,9 +51,21 @@ struct Cfg {
   static constexpr int NB = BN / ROWS_PER_INSTR / NWAVES;  // B staging instructions per wave
   static constexpr int KS = BK / 32;               // MFMA k-substeps per stage
 };
+// time of a 192-row tile relative to three quarters of a 256-row tile's (launch(): tile height)
+constexpr double kShortTilePenalty = 1.1;
 // chunk swizzles that make the 16x16x32 ds_read_b128 fragment reads conflict free
 __device__ __forceinline__ int swz_row(int row, int chunks) {
   return chunks == 8 ? ((row >> 1) & 7) : ((0x78 >> (((row >> 2) & 3) * 2)) & 3);  // LUT {0,2,3,1}
+}
+
+int nt_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
 }
 
 struct GemmNtArgs {
@@ -1126,15 +1138,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
 #undef NTP_WAIT_BARRIER
 }
 
-int ntp_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
-}
 
 template <int EPI>
 bool ntp_eligible(const GemmNtArgs& a) {
@@ -1168,7 +1171,7 @@ int launch_ntp(GemmNtArgs a, hipStream_t s) {
   if (mvptr_knobs().nt_group[0] > 0 && mvptr_knobs().nt_group[1] <= 0) a.group_n = a.tiles_n;
   // equal shares: tiles / ceil(tiles / CUs) workgroups (a multiple of 8 where that costs no extra round, so that a
   // workgroup's tiles stay on its XCD's part of the tile order)
-  const int ncu = ntp_num_cus();
+  const int ncu = nt_num_cus();
   const int rounds = (nwg + ncu - 1) / ncu;
   int grid = (nwg + rounds - 1) / rounds;
   const int grid8 = (grid + 7) & ~7;
@@ -1239,12 +1242,35 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
     if (env[0] == 'v') return launch_bk<EPI, 32, 3, 2, 2, 8, 0>(a, s);  // "v4": 256x128, FOUR waves of 128x64, two workgroups per CU
     if (env[0] == 's') return launch_bk<EPI, 32, 3, 2, 2, 4, 0>(a, s);  // "s128"
     if (env[0] == 'w') return launch_bk<EPI, 32, 3, 4, 2, 4, 0>(a, s);  // "w4"
+    if (env[0] == 'm' && env[1] == '6') return launch_bk<EPI, 64, 2, 2, 4, 6, 0>(a, s);  // "m6": 192 x 256 tiles (tail split A/B)
+    if (env[0] == 'm' && env[1] == '4') return launch_bk<EPI, 64, 2, 2, 4, 4, 0>(a, s);  // "m4": 128 x 256
+    if (env[0] == 'm' && env[1] == '2') return launch_bk<EPI, 64, 2, 2, 4, 2, 0>(a, s);  // "m2": 64 x 256
     if (env[0] == 't') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);  // "t256k"
     MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
   }
 #endif
   const int Mp = (a.m_plan > 0 && a.m_plan < a.M) ? a.m_plan : a.M;     // rows the configuration is chosen for
   const int64_t tiles256 = (int64_t)((Mp + 255) / 256) * ((a.N + 255) / 256);
+  // Tile height (round 4).  256x256 tiles over the 256 CUs run in rounds: 129 tiles (M = 10 917, N = 768) use half the chip
+  // for one round, 516 (N = 3072) take three rounds for two rounds of work.  192-row tiles (MT_ 6 of the same kernel; 10 %
+  // slower per FLOP: more operand bytes per output) win where they save a round's worth: measured cold at M = 10 917
+  // (profiles/r04_experiments.txt) attention output 45.9 -> 37.0 us, FFN1 100.4 -> 86.1, FFN2 108.1 -> 100.8, Q/K/V dgrad
+  // 80.4 -> 75.4, and Q/K/V forward (387 tiles: 2 rounds either way) 54.8 -> 68.4 — which the rounds model below also says.
+  // Splitting the LAST round off into a second launch of shorter tiles was measured too and is not built: no gain on the
+  // joint stack (444 tiles: 214.6 -> 221.6 us), the second round of a 1.73-round launch already runs faster per tile.
+  if constexpr (EPI <= MVPTR_EPI_ADD) {
+    bool off = false;
+#ifdef MVPTR_DIAG_BUILD
+    off = (mvptr_knobs().nt_exp & 65536) != 0;                           // MVPTR_NT_EXP bit 16: 256-row tiles only (A/B)
+#endif
+    if (!off && tiles256 > 64 && !(a.N <= 768 && a.K <= 768 && tiles256 > 256)) {
+      const int ncu = nt_num_cus();
+      const int64_t tn = (a.N + 255) / 256;
+      const double r256 = (double)((tiles256 + ncu - 1) / ncu);
+      const double r192 = (double)(((int64_t)((Mp + 191) / 192) * tn + ncu - 1) / ncu) * 0.75 * kShortTilePenalty;
+      if (r192 < 0.92 * r256) return launch_bk<EPI, 64, 2, 2, 4, 6, 0>(a, s);
+    }
+  }
   // few-row GEMMs (head transforms on the masked rows: M ~ 3 k, N = 768) would give a 256x256 tile to
   // a quarter of the CUs or fewer: 128x128 tiles, 4 waves, up to three workgroups per CU
   // (35 vs 74 us at M = 3000, N = 768, K = 3072; at M = 11 k the big tile still wins, 74 vs 87 us)
@@ -1367,6 +1393,7 @@ int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, i
   if (lda < K || ldb < K) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: lda/ldb smaller than K");
   if (out0 == nullptr) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: out0 is NULL");
   GemmNtArgs a;
+  memset(&a, 0, sizeof(a));
   a.A = (const __bf16*)A;
   a.B = (const __bf16*)B;
   a.lda = lda;

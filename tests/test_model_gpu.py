@@ -1260,12 +1260,14 @@ def test_sync_free_joint_pass_and_host_counts(dev):
     #  process, which is the intended "fail loudly"; not exercised here for that reason)
 
 
-@pytest.mark.parametrize("bound,rows", [(20000, 9000), (9000, 9000), (3000, 1100)])
-def test_encoder_stack_with_device_side_row_count(dev, bound, rows):
+@pytest.mark.parametrize("bound,rows,plan", [(20000, 9000, 4500), (9000, 9000, 4500), (3000, 1100, 550),
+                                             (44000, 26000, 26000), (44000, 20000, 26000), (44000, 30000, 23000)])
+def test_encoder_stack_with_device_side_row_count(dev, bound, rows, plan):
     """mvptr_layer_desc.rows_dev at BERT-base width: one encoder layer over `rows` packed rows inside buffers sized for
     `bound`, the count living on the device, against the same layer run on exactly `rows` rows — output rows, input
     gradient and every weight gradient (the 256 x 256 GEMM tiles, the weight-gradient M-splits and the LayerNorm
-    kernels all clamp to the device count)."""
+    kernels all clamp to the device count).  The tile height of the GEMMs (gemm_nt.hip launch(): 256 or 192 rows) follows
+    the PLANNED rows; the 44 000-row cases run with as many, fewer and more rows on the device than planned."""
     from mvp_pytorch_amd import modeling
     cfg = dict(gu.BASE_CFG, num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     torch.manual_seed(0)
@@ -1293,7 +1295,7 @@ def test_encoder_stack_with_device_side_row_count(dev, bound, rows):
             cnt = torch.tensor([rows, lmax], dtype=torch.int64, device=dev)
             lb = max(lmax, -(-bound // nseq))       # the bound must fit n_seq x L (the length is an upper bound here too)
             assert lb <= 256
-            y = enc.forward_rows(xin, starts, lens_d, nseq, lb, rows_dev=cnt, rows_plan=rows // 2)
+            y = enc.forward_rows(xin, starts, lens_d, nseq, lb, rows_dev=cnt, rows_plan=plan)
             d = torch.zeros(bound, 768, dtype=torch.bfloat16, device=dev)
             d[:rows] = dy
             y.backward(d)
