@@ -367,7 +367,7 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     # The dominant kernel by total time is the gemm_nt_kernel FAMILY (every forward and data-gradient GEMM of the encoder
     # layers, 144 launches and ~half of the kernel time of a step; VERDICT r03: report it, not only the largest single
     # instantiation); the grouped weight-gradient kernel follows as second_kernel.
-    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI, 64, 2, 2, 4, 8> family: the 8 forward / data-gradient GEMMs of an encoder layer "
+    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI, 64, 2, 2, 4, 8 | 6> family (256 x 256 tiles; 192 x 256 where the tile-height rule picks them): the 8 forward / data-gradient GEMMs of an encoder layer "
                                      "(Q/K/V, attention output, FFN1 + GELU, FFN2 and their data gradients; fused bias / residual / dropout / "
                                      "GELU epilogues) at M = %s rows, 144 launches per step" % " / ".join(str(m) for m in mix.Ms),
                 achieved=round(fam_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",

@@ -1252,19 +1252,23 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const int Mp = (a.m_plan > 0 && a.m_plan < a.M) ? a.m_plan : a.M;     // rows the configuration is chosen for
   const int64_t tiles256 = (int64_t)((Mp + 255) / 256) * ((a.N + 255) / 256);
   // Tile height (round 4).  256x256 tiles over the 256 CUs run in rounds: 129 tiles (M = 10 917, N = 768) use half the chip
-  // for one round, 516 (N = 3072) take three rounds for two rounds of work.  192-row tiles (MT_ 6 of the same kernel; 10 %
-  // slower per FLOP: more operand bytes per output) win where they save a round's worth: measured cold at M = 10 917
+  // for one round, 516 (N = 3072) pay a third round for 4 tiles.  192-row tiles (MT_ 6 of the same kernel; ~10 % slower per
+  // FLOP: more operand bytes per output) are taken where they save most of a round: measured cold at M = 10 917
   // (profiles/r04_experiments.txt) attention output 45.9 -> 37.0 us, FFN1 100.4 -> 86.1, FFN2 108.1 -> 100.8, Q/K/V dgrad
-  // 80.4 -> 75.4, and Q/K/V forward (387 tiles: 2 rounds either way) 54.8 -> 68.4 — which the rounds model below also says.
-  // Splitting the LAST round off into a second launch of shorter tiles was measured too and is not built: no gain on the
-  // joint stack (444 tiles: 214.6 -> 221.6 us), the second round of a 1.73-round launch already runs faster per tile.
+  // 80.4 -> 75.4; one-stream step 29.4 -> 28.6 ms.  Only for a single under-filled round or a last round that is nearly
+  // empty (<= 15 % of the CUs): a launch of 1.4 rounds (M = 30 720, N = 768) looks like a win by the same arithmetic and in
+  // a cold replay (211.8 -> 196.0 us) but LOSES inside the step (single-stream model 16.75 -> 17.5 ms): its second round
+  // already runs faster per tile.  Splitting the last round off into a second launch of shorter tiles was measured too and
+  // is not built (no gain on the joint stack: 444 tiles, 214.6 -> 221.6 us).
   if constexpr (EPI <= MVPTR_EPI_ADD) {
     bool off = false;
 #ifdef MVPTR_DIAG_BUILD
     off = (mvptr_knobs().nt_exp & 65536) != 0;                           // MVPTR_NT_EXP bit 16: 256-row tiles only (A/B)
 #endif
-    if (!off && tiles256 > 64 && !(a.N <= 768 && a.K <= 768 && tiles256 > 256)) {
-      const int ncu = nt_num_cus();
+    const int ncu = nt_num_cus();
+    const int last = (int)(tiles256 % ncu);                               // tiles of the last round
+    const bool wasteful = tiles256 <= ncu || (last > 0 && last * 100 <= ncu * 15);
+    if (!off && tiles256 > 64 && wasteful && !(a.N <= 768 && a.K <= 768 && tiles256 > 256)) {
       const int64_t tn = (a.N + 255) / 256;
       const double r256 = (double)((tiles256 + ncu - 1) / ncu);
       const double r192 = (double)(((int64_t)((Mp + 191) / 192) * tn + ncu - 1) / ncu) * 0.75 * kShortTilePenalty;

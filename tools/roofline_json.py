@@ -20,7 +20,7 @@ def avg_us(path, frag):
     gemm_tn_q_kernel<4, false> / <4, true> — are one row each in the summary)"""
     tot, calls = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if frag in r["Name"]:
+        if any(f in r["Name"] for f in ((frag,) if isinstance(frag, str) else frag)):
             tot += float(r["TotalDurationNs"]) / 1e3
             calls += int(r["Calls"])
     return (tot / calls, calls) if calls else (None, 0)
@@ -72,9 +72,9 @@ def nt_mix(Ms):
     return sum(fl) / len(fl), sum(by) / len(by)
 
 
-res["gemm_nt_family"] = {"_what": "gemm_nt_kernel<EPI, 64, 2, 2, 4, 8>: the eight forward / data-gradient GEMMs of an encoder layer with their fused "
+res["gemm_nt_family"] = {"_what": "gemm_nt_kernel<EPI, 64, 2, 2, 4, 8 | 6> (256 x 256 tiles; 192 x 256 where launch()'s tile-height rule picks them): the eight forward / data-gradient GEMMs of an encoder layer with their fused "
                                   "epilogues, mean over the 24 launches of the replay (8 shapes x 3 row counts); in_step: every gemm_nt_kernel of the "
-                                  "traced training steps with that tile configuration (the layers' 144 launches per step + the region-embedding GEMM)"}
+                                  "traced training steps with those tile configurations (the layers' 144 launches per step + the region-embedding GEMM)"}
 for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
     us, calls = avg_us(path, "gemm_nt_kernel")
     flop, alg = nt_mix(Ms)
@@ -84,7 +84,7 @@ for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots
            "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
            "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
     if bench_csv[key]:
-        us_in, calls_in = avg_us(bench_csv[key], "64, 2, 2, 4, 8, 0>")
+        us_in, calls_in = avg_us(bench_csv[key], ("64, 2, 2, 4, 8, 0>", "64, 2, 2, 4, 6, 0>"))   # 256- and 192-row tiles of the layer GEMMs
         if us_in:
             ent["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
                               "frac_of_peak": flop / us_in / 1e6 / PEAK}
