@@ -578,8 +578,9 @@ def main():
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
     ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
     ap.add_argument("--dp-sparse-rows", action="store_true", help="N > 1: word-table gradient exchanged by looked-up rows (default dense)")
-    ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams as at N = 1")
-    ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream, as multi-rank jobs run by default")
+    ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams whatever the backend (the default over RCCL since round 4; gloo jobs run one stream)")
+    ap.add_argument("--dp-one-stream", action="store_true", help="N > 1: the round-3 policy — multi-rank jobs on one compute stream (A/B)")
+    ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream (what gloo jobs and --dp-one-stream run)")
     ap.add_argument("--no-arena", action="store_true", help="N = 1: gradients through autograd tensors instead of the gradient arena (A/B)")
     ap.add_argument("--count-readbacks", action="store_true",
                     help="A/B: the round-3 step — row counts read back from the device inside the step (no host_counts, joint pass sized exactly)")
@@ -621,6 +622,7 @@ def main():
             dist.init_process_group(backend)
 
     from mvp_pytorch_amd import dp, hip, modeling, train
+    from mvp_pytorch_amd.modeling.modeling_vlbert import _streams_allowed
     from mvp_pytorch_amd.synthetic import synthetic_batch
     hip.load()
     single = args.model == "single"
@@ -630,6 +632,8 @@ def main():
     cls = modeling.BertImgForPreTraining if single else modeling.BiBertImgForPreTraining
     if world > 1 and args.dp_two_streams:
         cfg = dict(cfg, parallel_stacks="always")
+    if world > 1 and args.dp_one_stream:
+        cfg = dict(cfg, parallel_stacks="single_rank")
     if args.one_stream:
         cfg = dict(cfg, parallel_stacks=False)
     if args.count_readbacks:
@@ -642,8 +646,8 @@ def main():
         model.return_prediction_scores = False
     opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
     # Gradient arena at every world size (the kernels accumulate weight gradients straight into the flat
-    # buckets that are all-reduced when N > 1).  Defaults for N > 1: f32 wire, dense exchange, one compute
-    # stream; --dp-bf16-wire / --dp-sparse-rows / --dp-two-streams opt in (bi model: the MLM decoders are
+    # buckets that are all-reduced when N > 1).  Defaults for N > 1: f32 wire, dense exchange, the compute
+    # schedule of N = 1 (two streams over RCCL; one over gloo); --dp-bf16-wire / --dp-sparse-rows opt in (bi model: the MLM decoders are
     # clones of the first 30 522 embedding rows, not tied, so the word table's gradient holds the looked-up
     # rows only, dp.GradSync.note_rows).
     sparse = [model.bert.embeddings.word_embeddings.weight] if (args.dp_sparse_rows and not single) else []
@@ -687,8 +691,8 @@ def main():
     value = world * args.batch / (ms_per_step * 1e-3)
 
     # N > 1: what the ranks saw, what the exchange costs, and a second timed leg with the data-parallel opt-ins:
-    # the driver's plain `bench.py --gpus 8` then measures the conservative defaults (f32 wire, dense word-table exchange, one
-    # compute stream) AND bf16 wire + row-sparse word table + two streams in one run, same fences and step count.
+    # the driver's plain `bench.py --gpus 8` then measures the conservative exchange (f32 wire, dense word-table exchange) AND
+    # bf16 wire + row-sparse word table (+ two streams where the headline ran one) in one run, same fences and step count.
     dp_info = None
     if world > 1:
         import torch.distributed as dist
@@ -697,9 +701,9 @@ def main():
         dp_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(),
                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
                    "defaults": {"wire": "bf16" if args.dp_bf16_wire else "f32", "sparse_word_table": bool(args.dp_sparse_rows),
-                                "two_streams": bool(args.dp_two_streams)},
+                                "two_streams": bool(not single and model.bert.parallel_stacks and _streams_allowed(model.bert.parallel_stacks))},
                    "hot_buckets": sync.n_hot, "buckets": len(sync.buckets), "stalled_steps": sync.stalled_steps}
-        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows and args.dp_two_streams):
+        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows):
             sync.close()
             keep_ps = model.bert.parallel_stacks
             model.bert.parallel_stacks = "always"

@@ -59,17 +59,24 @@ def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
 
 
 def _streams_allowed(setting):
-    """Two-stream execution of the uni-modal stacks (and heads beside the joint stack): always in a
-    single-rank process; in a multi-rank job only with config.parallel_stacks = "always".
-    mvp_pytorch_amd.dp.GradSync makes a bucket wait for every stream that produced one of its gradients
-    before it is handed to the collective (exercised with a one-rank RCCL group in tests/test_dp_gpu.py),
-    but no multi-GPU box was available to time or soak the combination, so multi-rank jobs default to one
-    compute stream.  With gloo the bucketed exchange slows down badly beside a side stream (host-side
-    copies that synchronise the device, tools/dp_gloo_check.py)."""
+    """Two-stream execution of the uni-modal stacks (and heads beside the joint stack).  Policy since round 4:
+      * single-rank process: yes;
+      * multi-rank job over RCCL (backend "nccl"): yes — the same compute schedule at every N, so that a weak-scaling series
+        compares like with like (one stream costs 2.3 ms of the 26.3-ms step at N = 1).  Nothing about the gradient exchange
+        depends on stream timing: the autograd engine walks the backward graph in one fixed CPU-side order on every rank, so
+        the buckets' collectives are issued in the same order everywhere, and mvp_pytorch_amd.dp.GradSync makes a bucket wait
+        for every stream that produced one of its gradients before it is handed to the collective (tests/test_dp_gpu.py:
+        one-rank RCCL group with hooks, bucket launches and two compute streams);
+      * multi-rank job over gloo: no — the bucketed exchange slows down badly beside a side stream (host-side copies that
+        synchronise the device, tools/dp_gloo_check.py);
+      * config.parallel_stacks = "always" forces two streams, "single_rank" restores the round-3 policy (multi-rank jobs on one
+        stream whatever the backend; bench.py --dp-one-stream), False keeps one stream everywhere."""
     if setting == "always":
         return True
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return True
+    return setting != "single_rank" and dist.get_backend() == "nccl"
 
 
 def additive_mask(attention_mask):

@@ -663,3 +663,19 @@ def test_adamw_single_tensor_path_takes_the_clip_coefficient():
     a1, b1 = run(True)
     a2, b2 = run(False)
     assert torch.allclose(a1, a2, atol=1e-7) and torch.allclose(b1, b2, atol=1e-7)
+
+
+def test_stream_policy_by_backend(monkeypatch):
+    """Two compute streams: single rank yes; multi-rank over RCCL yes (same schedule at every N); over gloo no; "always" /
+    "single_rank" / False override (modeling_vlbert._streams_allowed; callers AND it with bool(parallel_stacks))."""
+    import torch.distributed as dist
+    from mvp_pytorch_amd.modeling.modeling_vlbert import _streams_allowed
+    assert _streams_allowed(True) and _streams_allowed("always") and _streams_allowed("single_rank")     # no process group
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 8)
+    monkeypatch.setattr(dist, "get_backend", lambda *a, **k: "nccl")
+    assert _streams_allowed(True) and _streams_allowed("always") and not _streams_allowed("single_rank")
+    monkeypatch.setattr(dist, "get_backend", lambda *a, **k: "gloo")
+    assert not _streams_allowed(True) and _streams_allowed("always") and not _streams_allowed("single_rank")
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 1)
+    assert _streams_allowed(True) and _streams_allowed("single_rank")
