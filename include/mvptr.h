@@ -393,6 +393,27 @@ int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f32, const i
                            int64_t ld_dst, void* dst2, int64_t ld_dst2, int split, int dst_f32, int n, int H,
                            void* stream);
 
+/* Gradient of a multi-tap row gather in one pass over the DESTINATION rows (the backward of several mvptr_gather_rows
+ * calls on one source pair, engine.MultiTapFn): dst[r,:] (bf16) = sum over taps k and positions j with taps[k].idx[j] == r
+ * of taps[k].g[j,:] (bf16, or f32 when g_f32), accumulated in f32, rounded once; rows nobody tapped become zero rows, so
+ * the destination needs no initialisation.  Indices >= rows address row idx - rows of dst2 ([rows2, H]; NULL with
+ * rows2 = 0), negative indices contribute nothing.  The taps are inverted into `work` (>= 2 (rows + rows2 + 1) + sum of n
+ * int32, 8-byte aligned, contents irrelevant: a linked list per destination row); a row's contributions are summed in
+ * ascending (tap, position) order when there are <= 64 of them (result independent of arrival order), in arrival order
+ * beyond.
+ * Replaces the zero-fill + index_add + cast kernels autograd derives for oscar/modeling/modeling_vlbert.py:519,
+ * 544-552,586-590,1231-1234,1245 and modeling_bert.py:471.  H % 4 == 0, H <= 2048, n < 2^24 per tap. */
+#define MVPTR_TAP_MAX 12
+typedef struct mvptr_tap {
+  const void* g;        /* [n, H] rows, leading dimension ld_g elements */
+  int64_t ld_g;
+  const int32_t* idx;   /* [n] destination rows */
+  int n;
+  int g_f32;            /* 1: g is f32, 0: bf16 */
+} mvptr_tap;
+int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, int64_t ld_dst, int rows, void* dst2, int64_t ld_dst2,
+                       int rows2, int H, int32_t* work, int64_t work_elems, void* stream);
+
 /* Index maps of a row-packed pass, built on the device from additive attention masks (valid slot <=> 0).
  * Output sequence s (0 <= s < n_seq) is the concatenation of nseg (1 or 2) segments; segment k covers the slots
  * [col0, col0 + len) of mask row sel[s] (s when sel == NULL) and names the SOURCE row of each valid slot:

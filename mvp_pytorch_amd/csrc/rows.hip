@@ -161,6 +161,105 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const void* src, 
   }
 }
 
+// ---- gradient of the row taps in one pass over the tapped rows (round 4) ------------------------------------------
+// The backward of a multi-tap gather used to be: zero an f32 [rows, H] buffer, one scatter-add launch per tap (f32
+// atomics), cast the buffer to bf16 — 0.9 ms of a 26-ms step in 29 launches, most of it spent on rows nobody tapped
+// (profiles/r04_experiments.txt).  Here the taps are inverted first — one launch threads every entry onto a linked
+// list of its destination row (head + count per row, next per entry) — and one wave per destination row then sums ITS
+// contributions in f32 and writes the bf16 row once (zeros for a row nobody tapped): no f32 buffer, no zero fill of
+// the rows, no cast pass, no atomics on the rows.  A row with one contribution (the common case) costs two dependent
+// loads (head, then the tapped row).  The contributions of a row are summed in ascending (tap, position) order whenever
+// there are at most 64 of them (every case of the pre-training step), so the f32 sums — and the result — do not depend
+// on the order in which the atomics of the list build arrived.
+struct TapSet {
+  mvptr_tap t[MVPTR_TAP_MAX];
+  int base[MVPTR_TAP_MAX + 1];   // entries of tap k are [base[k], base[k+1])
+  int count;
+};
+__device__ __forceinline__ int tap_of_entry(const TapSet& ts, int e) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MVPTR_TAP_MAX; ++i)
+    if (i < ts.count && e >= ts.base[i]) k = i;
+  return k;
+}
+// hc[r] = {entry + 1 at the head of row r's list (0: empty), number of entries}; next[e] = entry + 1 behind e
+__global__ __launch_bounds__(256) void tap_link_kernel(TapSet ts, int R, int32_t* hc, int32_t* next) {
+  const int total = ts.base[ts.count];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int k = tap_of_entry(ts, e);
+    const int r = ts.t[k].idx[e - ts.base[k]];
+    if (r >= 0 && r < R) {
+      next[e] = atomicExch(hc + 2 * r, e + 1);
+      atomicAdd(hc + 2 * r + 1, 1);
+    }
+  }
+}
+// one wave per destination row; lane l owns columns 4 l + 256 i
+__global__ __launch_bounds__(256) void tap_sum_kernel(TapSet ts, int R, int split, const int32_t* hc, const int32_t* next,
+                                                       __bf16* dst, int64_t ld_dst, __bf16* dst2, int64_t ld_dst2, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int2 hn = *reinterpret_cast<const int2*>(hc + 2 * r);
+  const int n = hn.y;
+  __bf16* out = (dst2 != nullptr && r >= split) ? dst2 + (int64_t)(r - split) * ld_dst2 : dst + (int64_t)r * ld_dst;
+  constexpr int MAXI = 8;                       // H <= 2048
+  f32x4 acc[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto add_entry = [&](int e_v) {
+    const int e = __builtin_amdgcn_readfirstlane(e_v);          // the same in every lane: scalar loads of the tap descriptor
+    const int k = tap_of_entry(ts, e);
+    const mvptr_tap& t = ts.t[k];
+    const int64_t row = (int64_t)(e - ts.base[k]) * t.ld_g;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < H) {
+        if (t.g_f32) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)t.g + row + c);
+          acc[i] += v;
+        } else {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>((const __bf16*)t.g + row + c);
+          acc[i] += f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+        }
+      }
+    }
+  };
+  if (n == 1) {
+    add_entry(hn.x - 1);
+  } else if (n > 1 && n <= 64) {
+    // walk the list into the lanes (entry q in lane q), then add in ascending entry order = (tap, position) order
+    int mine = 0x7fffffff, e1 = hn.x;
+    for (int q = 0; q < n; ++q) {
+      if (lane == q) mine = e1 - 1;
+      if (q + 1 < n) e1 = next[e1 - 1];
+    }
+    int rank = 0;
+    for (int q = 0; q < n; ++q) rank += (__shfl(mine, q) < mine) ? 1 : 0;
+    for (int q = 0; q < n; ++q) {
+      const unsigned long long hit = __ballot(lane < n && rank == q);
+      add_entry(__shfl(mine, (int)__ffsll((long long)hit) - 1));
+    }
+  } else if (n > 64) {
+    int e1 = hn.x;
+    for (int q = 0; q < n; ++q) {                 // more than 64 contributions: list (arrival) order
+      const int e = e1 - 1;
+      if (q + 1 < n) e1 = next[e];
+      add_entry(e);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < H) {
+      const bf16x4 o = {f2bf(acc[i][0]), f2bf(acc[i][1]), f2bf(acc[i][2]), f2bf(acc[i][3])};
+      *reinterpret_cast<bf16x4*>(out + c) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, int32_t* pos_out, int32_t* idx_out,
@@ -206,6 +305,43 @@ extern "C" int mvptr_scatter_add_rows(const void* src, int64_t ld_src, int src_f
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, src_f32 ? 1 : 0, idx,
                      dst, ld_dst, dst2, ld_dst2, split, n, H / 2, dst_f32 ? 1 : 0);
   MVPTR_CHECK_LAUNCH("scatter_add_rows");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, int64_t ld_dst, int rows, void* dst2, int64_t ld_dst2,
+                                  int rows2, int H, int32_t* work, int64_t work_elems, void* stream) {
+  if (!taps || ntaps < 1 || ntaps > MVPTR_TAP_MAX) MVPTR_FAIL(MVPTR_BAD_ARG, "tap_rows_bwd: 1..%d taps", MVPTR_TAP_MAX);
+  if (rows <= 0 || rows2 < 0 || H <= 0 || (H & 3) || H > 2048 || (ld_dst & 3) || (dst2 && (ld_dst2 & 3)))
+    MVPTR_FAIL(MVPTR_BAD_SHAPE, "tap_rows_bwd: rows > 0, H a multiple of 4 and <= 2048, leading dimensions multiples of 4");
+  if (!dst || !work || ((uintptr_t)dst & 7) || ((uintptr_t)dst2 & 7) || ((dst2 == nullptr) != (rows2 == 0)))
+    MVPTR_FAIL(MVPTR_BAD_ALIGN, "tap_rows_bwd: NULL / unaligned destination, or dst2 without rows2");
+  TapSet ts = {};
+  ts.count = ntaps;
+  int64_t total = 0;
+  for (int k = 0; k < ntaps; ++k) {
+    const mvptr_tap& t = taps[k];
+    if (!t.g || !t.idx || t.n < 0 || t.n >= (1 << 24) || t.ld_g < H || (t.ld_g & 3) || ((uintptr_t)t.g & (t.g_f32 ? 15 : 7)))
+      MVPTR_FAIL(MVPTR_BAD_ARG, "tap_rows_bwd: tap %d: NULL / unaligned rows, n outside [0, 2^24), or ld_g < H", k);
+    ts.t[k] = t;
+    ts.base[k] = (int)total;
+    total += t.n;
+  }
+  if (total >= (int64_t)0x7fffffff) MVPTR_FAIL(MVPTR_BAD_SHAPE, "tap_rows_bwd: too many entries");
+  ts.base[ntaps] = (int)total;
+  const int R = rows + rows2;
+  if (work_elems < 2 * (int64_t)(R + 1) + total) MVPTR_FAIL(MVPTR_BAD_SHAPE, "tap_rows_bwd: work needs 2 (rows + rows2 + 1) + entries int32");
+  if ((uintptr_t)work & 7) MVPTR_FAIL(MVPTR_BAD_ALIGN, "tap_rows_bwd: work must be 8-byte aligned");
+  int32_t* hc = work;                       // {head, count} per destination row
+  int32_t* next = work + 2 * (R + 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(hc, 0, sizeof(int32_t) * 2 * (size_t)R, s) != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "tap_rows_bwd: memset failed");
+  if (total > 0) {
+    const int g = (total + 255) / 256 > 4096 ? 4096 : (int)((total + 255) / 256);
+    hipLaunchKernelGGL(tap_link_kernel, dim3(g), dim3(256), 0, s, ts, R, hc, next);
+  }
+  hipLaunchKernelGGL(tap_sum_kernel, dim3((R + 3) / 4), dim3(256), 0, s, ts, R, rows, hc, next, (__bf16*)dst, ld_dst, (__bf16*)dst2,
+                     ld_dst2, H);
+  MVPTR_CHECK_LAUNCH("tap_rows_bwd");
   return MVPTR_OK;
 }
 

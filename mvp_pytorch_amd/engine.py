@@ -950,8 +950,9 @@ class MultiTapFn(torch.autograd.Function):
     read src2), idx_k int32 (negative index = zero row).  ALL the rows that later stages read from one stack
     output go through ONE call — the packed joint input gathered from the packed text and visual outputs, [CLS]
     states, masked-LM rows, phrase / region rows of the word-region alignment — so the backward pass builds each
-    buffer's gradient with one zero fill and one scatter-add per consumer (rows may repeat: f32 atomics, rounded to
-    bf16 once) instead of a full-size zero-filled tensor + add per consumer.  Incoming gradients may be bf16 or f32."""
+    buffer's gradient in ONE pass over its rows (hip.tap_rows_bwd: the taps inverted by a counting sort, every row the
+    f32 sum of its contributions rounded to bf16 once, untapped rows zero) instead of a full-size zero-filled tensor +
+    add per consumer.  Incoming gradients may be bf16 or f32."""
 
     @staticmethod
     def forward(ctx, src, src2, *idxs):
@@ -963,18 +964,30 @@ class MultiTapFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         s1, s2 = ctx.shapes
-        dev = ctx.idxs[0].device
-        # f32 accumulation (order-independent to 2^-24), one rounding to bf16 at the end
-        d = torch.zeros(s1, device=dev, dtype=torch.float32)
-        d2 = torch.zeros(s2, device=dev, dtype=torch.float32) if s2 is not None else None
+        # one pass over the destination rows: the taps are inverted on the device and every source row sums its own
+        # contributions in f32 and is written once, rounded once (hip.tap_rows_bwd); rows nobody tapped become zero rows
+        taps = []
         for g, i in zip(gs, ctx.idxs):
-            if g is None:
+            if g is None or i.numel() == 0:
                 continue
             g = g.contiguous()
             if g.dtype not in (torch.bfloat16, torch.float32):
                 g = g.float()
-            hip.scatter_add_rows(g, i, d, d2)
-        return (d.to(torch.bfloat16), d2.to(torch.bfloat16) if d2 is not None else None) + (None,) * len(ctx.idxs)
+            taps.append((g, i))
+        dev = ctx.idxs[0].device
+        if not taps:
+            d = torch.zeros(s1, device=dev, dtype=torch.bfloat16)
+            d2 = torch.zeros(s2, device=dev, dtype=torch.bfloat16) if s2 is not None else None
+        elif len(taps) <= hip.TAP_MAX and s1[1] <= 2048 and s1[1] % 4 == 0:
+            d, d2 = hip.tap_rows_bwd(taps, s1[0], s2[0] if s2 is not None else 0, s1[1])
+        else:
+            # more taps than one call takes (or an odd width): f32 accumulation by atomics, one rounding at the end
+            d = torch.zeros(s1, device=dev, dtype=torch.float32)
+            d2 = torch.zeros(s2, device=dev, dtype=torch.float32) if s2 is not None else None
+            for g, i in taps:
+                hip.scatter_add_rows(g, i, d, d2)
+            d, d2 = d.to(torch.bfloat16), (d2.to(torch.bfloat16) if d2 is not None else None)
+        return (d, d2) + (None,) * len(ctx.idxs)
 
 
 def tap_rows(src, idx, src2=None):

@@ -33,7 +33,7 @@ SYMBOLS = [
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
-    "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts",
+    "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
 ]
 
 
@@ -62,6 +62,13 @@ class TnProblem(Structure):
 class PackSeg(Structure):
     _fields_ = [("mask", c_void_p), ("ld_mask", c_int64), ("sel", c_void_p), ("col0", c_int), ("len", c_int),
                 ("pos", c_void_p), ("ld_pos", c_int64), ("src_seq_stride", c_int64), ("src_base", c_int64)]
+
+
+class Tap(Structure):      # mvptr_tap
+    _fields_ = [("g", c_void_p), ("ld_g", c_int64), ("idx", c_void_p), ("n", c_int), ("g_f32", c_int)]
+
+
+TAP_MAX = 12
 
 
 class LayerGrads(Structure):
@@ -127,6 +134,7 @@ def load():
     lib.mvptr_hard_negative_mine.argtypes = [P, I, I64, P, P, P, P, P, P, P, P]
     lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
     lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
+    lib.mvptr_tap_rows_bwd.argtypes = [POINTER(Tap), I, P, I64, I, P, I64, I, I, P, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
     lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
     lib.mvptr_clip_ce_fwd.argtypes = [P, I, I64, P, P, P, P, P]
@@ -629,6 +637,30 @@ def scatter_add_rows(src, idx, dst, dst2=None):
                                              _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0],
                                              int(dst.dtype == torch.float32), n, H, _stream()))
     return dst
+
+
+def tap_rows_bwd(taps, rows, rows2, H):
+    """Gradient of a multi-tap row gather: taps = [(g [n, H] bf16 / f32 contiguous rows, idx int32 [n])] -> (d bf16 [rows, H],
+    d2 bf16 [rows2, H] or None); d[r] = sum of the g rows whose idx is r (f32 sums, one rounding; untapped rows are zero rows;
+    idx >= rows addresses d2) — mvptr_tap_rows_bwd."""
+    assert 1 <= len(taps) <= TAP_MAX
+    dev = taps[0][0].device
+    arr = (Tap * len(taps))()
+    total = 0
+    keep = []
+    for k, (g, idx) in enumerate(taps):
+        assert g.dim() == 2 and g.shape[1] == H and g.stride(1) == 1 and g.dtype in (torch.bfloat16, torch.float32)
+        assert idx.dtype == torch.int32 and idx.numel() == g.shape[0]
+        idx = idx.contiguous()
+        keep.append(idx)
+        arr[k].g, arr[k].ld_g, arr[k].idx, arr[k].n, arr[k].g_f32 = g.data_ptr(), g.stride(0), idx.data_ptr(), g.shape[0], int(g.dtype == torch.float32)
+        total += g.shape[0]
+    d = torch.empty(rows, H, dtype=torch.bfloat16, device=dev)
+    d2 = torch.empty(rows2, H, dtype=torch.bfloat16, device=dev) if rows2 else None
+    work = torch.empty(2 * (rows + rows2 + 1) + total, dtype=torch.int32, device=dev)
+    _check(load().mvptr_tap_rows_bwd(arr, len(taps), _p(d), d.stride(0), rows, _p(d2), d2.stride(0) if d2 is not None else 0, rows2, H,
+                                     _p(work), work.numel(), _stream()))
+    return d, d2
 
 
 def pack_maps(segs, n_seq, fill_idx=False):

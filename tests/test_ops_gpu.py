@@ -415,6 +415,75 @@ def test_attention_every_block_count_per_head(dev, heads, Lmax):
                     assert (dq_p[sl, cg].cpu().float() - want).norm() < 4e-2 * want.norm() + 0.3, (b, h, part)
 
 
+@pytest.mark.parametrize("rows,rows2,H,ns", [(900, 700, 768, (300, 1200, 64, 5)), (64, 0, 128, (40, 200)), (5000, 3000, 768, (9000, 1)),
+                                            (33, 0, 2048, (10,)), (700, 41, 260, (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 900))])
+def test_tap_rows_bwd_against_index_add(dev, rows, rows2, H, ns):
+    """mvptr_tap_rows_bwd (the backward of engine.MultiTapFn): every destination row = the f32 sum of the rows that tap it,
+    rounded once; bf16 and f32 taps, -1 entries, repeated rows inside a tap and across taps, one row tapped by more than 64
+    entries, untapped rows (must come out as zero rows from uninitialised memory), one and two destinations; twice in a row
+    with the same result bit for bit wherever a row has at most 64 contributions."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(rows + H)
+    R = rows + rows2
+    taps, ref = [], torch.zeros(R, H, dtype=torch.float64)
+    for k, n in enumerate(ns):
+        idx = torch.randint(-1, R, (n,), generator=g, dtype=torch.int32)
+        if k == 1 and n >= 200:
+            idx[:150] = 7                      # one hot row: more than 64 contributions
+        if k == 0:
+            idx[: n // 4] = idx[n // 4: 2 * (n // 4)]     # repeats inside a tap
+        gr = torch.randn(n, H, generator=g)
+        gr = gr if (k % 2) else _bf(gr)        # odd taps f32, even taps bf16
+        ok = idx >= 0
+        ref.index_add_(0, idx[ok].long(), gr[ok].double())
+        taps.append(((gr if (k % 2) else gr.to(torch.bfloat16)).to(dev), idx.to(dev)))
+    # poison the allocator's next blocks so that "untapped rows are zero" is a statement about the kernel
+    junk = torch.full((R + 8, H), float("nan"), dtype=torch.bfloat16, device=dev)
+    del junk
+    d, d2 = hip.tap_rows_bwd(taps, rows, rows2, H)
+    got = torch.cat([d, d2], 0) if rows2 else d
+    assert (d2 is None) == (rows2 == 0)
+    assert torch.isfinite(got.float()).all()
+    want = ref.float()
+    assert ((got.float().cpu() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all()
+    untouched = torch.ones(R, dtype=torch.bool)
+    for _, idx in taps:
+        ic = idx.cpu()
+        untouched[ic[ic >= 0].long()] = False
+    assert untouched.any() and (got[untouched.to(dev)] == 0).all()
+    again, again2 = hip.tap_rows_bwd(taps, rows, rows2, H)
+    got2 = torch.cat([again, again2], 0) if rows2 else again
+    cnt = torch.zeros(R, dtype=torch.long)
+    for _, idx in taps:
+        ic = idx.cpu()
+        cnt.index_add_(0, ic[ic >= 0].long(), torch.ones(int((ic >= 0).sum()), dtype=torch.long))
+    few = (cnt <= 64).to(dev)
+    assert torch.equal(got[few], got2[few])
+
+
+def test_multi_tap_fn_gradients(dev):
+    """engine.MultiTapFn end to end: three taps of a two-buffer source (one with -1 slots, two read through .float(): autograd
+    hands their gradients back in the taps' own bf16) against torch.index_select autograd on the concatenated buffers."""
+    from mvp_pytorch_amd import engine
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a, b = _bf(torch.randn(500, 768, generator=g)), _bf(torch.randn(300, 768, generator=g))
+    i1 = torch.randint(0, 800, (256,), generator=g, dtype=torch.int32)
+    i2 = torch.randint(-1, 800, (1000,), generator=g, dtype=torch.int32)
+    i3 = torch.arange(0, 800, 7, dtype=torch.int32)
+    w = [torch.randn(n, 768, generator=g) for n in (256, 1000, i3.numel())]
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    outs = engine.MultiTapFn.apply(ad, bd, i1.to(dev), i2.to(dev), i3.to(dev))
+    loss = (outs[0].float() * w[0].to(dev)).sum() + (outs[1] * _bf(w[1]).to(dev)).sum() + (outs[2].float() * w[2].to(dev)).sum()
+    loss.backward()
+    ref = torch.cat([a, b], 0).double().requires_grad_(True)
+    z = torch.zeros(1, 768, dtype=torch.double)
+    pick = lambda i: torch.cat([ref, z], 0).index_select(0, torch.where(i >= 0, i, torch.full_like(i, 800)).long())   # noqa: E731
+    (pick(i1) * _bf(w[0]).double()).sum().add((pick(i2) * _bf(w[1]).double()).sum()).add((pick(i3) * _bf(w[2]).double()).sum()).backward()
+    got = torch.cat([ad.grad, bd.grad], 0).float().cpu()
+    assert ad.grad.dtype == torch.bfloat16 and _rel(got, ref.grad.float()) < 3e-3
+    assert ((got - ref.grad.float()).abs() <= 2.0 ** -7 * ref.grad.float().abs() + 1e-5).all()
+
+
 @pytest.mark.parametrize("M,H", [(1000, 768), (77, 128), (5, 1024)])
 def test_layernorm(dev, M, H):
     from mvp_pytorch_amd import hip
