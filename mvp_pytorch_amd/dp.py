@@ -68,6 +68,25 @@ import torch.distributed as dist
 from . import engine
 
 
+_CONTROL_GROUPS = {}     # data group -> host-side (gloo) group of the same ranks, made once per process
+
+
+def _control_group(group):
+    """A gloo group over the ranks of `group` for the few host-side integers a step exchanges (the used-parameter bitmap).
+    Over RCCL that exchange used to ride the data communicator: a pageable host-to-device copy, an all-reduce queued behind
+    every gradient bucket and a `.tolist()` — i.e. the host waited for the whole backward pass and all collectives before it
+    could queue the clip and AdamW, every step (dp.py:373,395), and a multi-rank job lost the step of lead a
+    single-rank one has.  The bitmap is host knowledge (which hooks fired), so it is exchanged host to host while the
+    device is still busy with the backward pass.  Collective: every rank of the default group must construct its GradSync
+    (same order), as with dist.new_group."""
+    if dist.get_backend(group) == "gloo":
+        return group
+    if group not in _CONTROL_GROUPS:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _CONTROL_GROUPS[group] = dist.new_group(ranks=ranks, backend="gloo")
+    return _CONTROL_GROUPS[group]
+
+
 class GradSync:
     def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype=torch.float32, sparse_rows=(),
                  force_collectives=False, demote_after=8, check_mixed_use=False):
@@ -90,6 +109,7 @@ class GradSync:
         self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
+        self._ctl = _control_group(process_group) if self.exchange else None      # host-side exchange of the used-parameter bitmap
         self.comm_dtype = torch.float32 if comm_dtype in (None, "auto") else comm_dtype
         self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
         self._idle = {}           # hot parameter -> consecutive steps without a gradient on any rank
@@ -390,9 +410,10 @@ class GradSync:
         # which parameters produced a gradient on ANY rank (DDP's used-parameter bitmap): those keep
         # the averaged gradient on every rank, the others keep grad = None everywhere, so replicas
         # apply identical updates even when a shard skipped a head
-        dev = self.buckets[0]["flat"].device
-        used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32).to(dev)
-        used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        # (host to host over the control group: the device and its queue of collectives are not involved, nothing here waits
+        # for the backward pass)
+        used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32)
+        dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self._ctl)
         for b in self.buckets:
             b["work"].wait()
             if b["union"] is not None:
@@ -412,7 +433,6 @@ class GradSync:
             if not self._avg:
                 b["flat"].mul_(1.0 / self.world)
             b["wire"] = None
-        used_work.wait()
         used = used.tolist()
         for p, u in zip(self.params, used):
             if not u:
