@@ -267,6 +267,17 @@ int mvptr_gemm_tn_multi_rows(const mvptr_tn_problem* problems, int count, void* 
 int mvptr_layernorm_fwd_rows(const void* z, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int M,
                              int H, int rows_per_group, int group_stride, int row_offset, const mvptr_dropout* drop, const int* rows_dev,
                              void* stream);
+// LayerNorm backward whose partial-sum finalize is deferred (an encoder layer finalizes its two LayerNorms in one launch)
+struct mvptr_ln_pending {
+  const float* partial;
+  int nblk;
+  float *dgamma, *dbeta, *dbias;
+};
+int mvptr_layernorm_bwd_partial(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz, void* dd,
+                                float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_group, int group_stride, int row_offset,
+                                const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes,
+                                const int* rows_dev, mvptr_ln_pending* pending, void* stream);
+int mvptr_layernorm_bwd_finalize2(const mvptr_ln_pending* a, const mvptr_ln_pending* b, int H, void* stream);
 int mvptr_layernorm_bwd_rows(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz, void* dd,
                              float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_group, int group_stride, int row_offset,
                              const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes,

@@ -116,7 +116,7 @@ extern "C" int64_t mvptr_layer_workspace_bytes(const mvptr_layer_desc* d) {
   // until the grouped weight-gradient launch at the end of the layer) + LayerNorm partials
   (void)W;
   return 5 * al256(M * H * 2) + al256(M * d->I * 2) + al256(M * 3 * H * 2) +
-         al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H)) + al256(wgrad_slab_bytes((int)M, (int)H, d->I));
+         2 * al256(mvptr_layernorm_bwd_ws_bytes((int)M, (int)H)) + al256(wgrad_slab_bytes((int)M, (int)H, d->I));
 }
 
 extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
@@ -172,7 +172,8 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   char* bufQ = bufU + al256((int64_t)M * I * 2);        // dqkv [M, 3H]
   char* lnws = bufQ + al256((int64_t)M * 3 * H * 2);
   const int64_t lnws_bytes = mvptr_layernorm_bwd_ws_bytes(M, H);
-  char* slabws = lnws + al256(lnws_bytes);              // per-split partial tiles of the weight-gradient launches (few-row stacks)
+  char* lnws1 = lnws + al256(lnws_bytes);               // second LayerNorm's partials: both are finalized in one launch
+  char* slabws = lnws1 + al256(lnws_bytes);             // per-split partial tiles of the weight-gradient launches (few-row stacks)
   const int64_t slabws_bytes = wgrad_slab_bytes(M, H, I);
   const mvptr_dropout dr_attn = site_drop(d, 0, d->p_attn16);
   const mvptr_dropout dr_o = site_drop(d, 1, d->p_hidden16);
@@ -200,9 +201,10 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   // output.LayerNorm / output.dense
   const int* rd = d->rows_dev;     // device-side row count of a row-packed pass (NULL: M rows)
   const int Mp = d->M_plan;
-  RUN(mvptr_layernorm_bwd_rows(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
-                               g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
-                               hdrop ? &dr_out : nullptr, lnws, lnws_bytes, rd, stream));
+  mvptr_ln_pending pend2, pend1;
+  RUN(mvptr_layernorm_bwd_partial(dy, s.z2, s.mean2, s.rstd2, w->ln2_g, bufA, hdrop ? bufB : nullptr,
+                                  g->ln2_g, g->ln2_b, g->b_out, M, H, M, 0, 0, nullptr,
+                                  hdrop ? &dr_out : nullptr, lnws, lnws_bytes, rd, &pend2, stream));
   const char* d2 = hdrop ? bufB : bufA;
   if (g->w_out) add_wgrad(d2, H, s.a, I, H, I, g->w_out, nullptr);
   RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
@@ -215,9 +217,10 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   RUN(mvptr_gemm_nt_rows(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
                          nullptr, nullptr, rd, Mp, stream));
   // attention.output.LayerNorm / dense
-  RUN(mvptr_layernorm_bwd_rows(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
-                               g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
-                               hdrop ? &dr_o : nullptr, lnws, lnws_bytes, rd, stream));
+  RUN(mvptr_layernorm_bwd_partial(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
+                                  g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
+                                  hdrop ? &dr_o : nullptr, lnws1, lnws_bytes, rd, &pend1, stream));
+  RUN(mvptr_layernorm_bwd_finalize2(&pend2, &pend1, H, stream));     // gamma / beta / bias gradients of both LayerNorms
   const char* d1 = hdrop ? bufE : bufD;
   if (g->w_o) add_wgrad(d1, H, s.ctx, H, H, H, g->w_o, nullptr);
   RUN(mvptr_gemm_nt_rows(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,

@@ -199,14 +199,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
   }
 }
 
-// second stage: out[q][col] += sum over blocks of partial[blk][q][col]
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* partial, int nblk, int H,
-                                                               float* dgamma, float* dbeta,
-                                                               float* dbias) {
+// second stage: out[q][col] += sum over blocks of partial[blk][q][col]; blockIdx.z picks one of up to two LayerNorms
+// (an encoder layer finalizes both of its LayerNorm backward passes in one launch: 18 fewer launches per step)
+struct LnFinal {
+  const float* partial;
+  int nblk;
+  float *dgamma, *dbeta, *dbias;
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(LnFinal f0, LnFinal f1, int H) {
+  const LnFinal& f = blockIdx.z ? f1 : f0;
+  const float* partial = f.partial;
+  const int nblk = f.nblk;
   const int i = blockIdx.x * 256 + threadIdx.x;  // over 3*H
   if (i >= 3 * H) return;
   const int q = i / H, col = i - q * H;
-  float* dst = (q == 0) ? dgamma : (q == 1 ? dbeta : dbias);
+  float* dst = (q == 0) ? f.dgamma : (q == 1 ? f.dbeta : f.dbias);
   if (dst == nullptr) return;
   // blockIdx.y slices the partial rows; 32 slices -> 32 adds per address, no contention to speak of
   const int per = (nblk + gridDim.y - 1) / gridDim.y;
@@ -786,6 +793,16 @@ int mvptr_layernorm_bwd_rows(const void* dy, const void* z, const float* mean, c
                              float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_group, int group_stride, int row_offset,
                              const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes,
                              const int* rows_dev, void* stream) {
+  return mvptr_layernorm_bwd_partial(dy, z, mean, rstd, gamma, dz, dd, dgamma, dbeta, dbias, M, H, rows_per_group, group_stride, row_offset,
+                                     y_drop, dense_drop, ws, ws_bytes, rows_dev, nullptr, stream);
+}
+
+// `pending` != NULL: the partial rows stay in `ws` and the caller finalizes them later (mvptr_layernorm_bwd_finalize2, with another
+// LayerNorm's); NULL: finalized here
+int mvptr_layernorm_bwd_partial(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz, void* dd,
+                                float* dgamma, float* dbeta, float* dbias, int M, int H, int rows_per_group, int group_stride, int row_offset,
+                                const mvptr_dropout* y_drop, const mvptr_dropout* dense_drop, void* ws, int64_t ws_bytes,
+                                const int* rows_dev, mvptr_ln_pending* pending, void* stream) {
   if (M <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: M must be > 0");
   if ((H & 7) || H > 1024 || H <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "layernorm_bwd: H=%d must be a multiple of 8, <= 1024", H);
   if (rows_per_group <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "layernorm_bwd: rows_per_group must be > 0");
@@ -811,9 +828,25 @@ int mvptr_layernorm_bwd_rows(const void* dy, const void* z, const float* mean, c
                        row_offset, make_dropdev(y_drop), make_dropdev(dense_drop), rows_dev);
   }
   MVPTR_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32), dim3(256), 0,
-                     (hipStream_t)stream, (const float*)ws, grid, H, dgamma, dbeta, dbias);
+  if (pending != nullptr) {
+    pending->partial = (const float*)ws;
+    pending->nblk = grid;
+    pending->dgamma = dgamma;
+    pending->dbeta = dbeta;
+    pending->dbias = dbias;
+    return MVPTR_OK;
+  }
+  const LnFinal f{(const float*)ws, grid, dgamma, dbeta, dbias};
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32, 1), dim3(256), 0, (hipStream_t)stream, f, f, H);
   MVPTR_CHECK_LAUNCH("layernorm_bwd_finalize");
+  return MVPTR_OK;
+}
+
+int mvptr_layernorm_bwd_finalize2(const mvptr_ln_pending* a, const mvptr_ln_pending* b, int H, void* stream) {
+  const LnFinal f0{a->partial, a->nblk, a->dgamma, a->dbeta, a->dbias};
+  const LnFinal f1{b->partial, b->nblk, b->dgamma, b->dbeta, b->dbias};
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((3 * H + 255) / 256, 32, 2), dim3(256), 0, (hipStream_t)stream, f0, f1, H);
+  MVPTR_CHECK_LAUNCH("layernorm_bwd_finalize2");
   return MVPTR_OK;
 }
 
