@@ -615,6 +615,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node by contract: the host-side control group of dp.GradSync (gloo: the used-parameter bitmap) talks over the
+        # loopback interface instead of whatever the container's hostname resolves to (it may not resolve at all)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         backend = os.environ.get("MVPTR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
