@@ -706,24 +706,32 @@ def main():
                    "defaults": {"wire": "bf16" if args.dp_bf16_wire else "f32", "sparse_word_table": bool(args.dp_sparse_rows),
                                 "two_streams": bool(not single and model.bert.parallel_stacks and _streams_allowed(model.bert.parallel_stacks))},
                    "hot_buckets": sync.n_hot, "buckets": len(sync.buckets), "stalled_steps": sync.stalled_steps}
-        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows):
-            sync.close()
-            keep_ps = model.bert.parallel_stacks
-            model.bert.parallel_stacks = "always"
-            sync = dp.GradSync(model, sparse_rows=[model.bert.embeddings.word_embeddings.weight], comm_dtype=torch.bfloat16)
-            opt_ms, _ = timed(batch, 3, args.steps)
-            dp_info["dp_optins"] = {"ms_per_step": round(opt_ms, 2), "value": round(world * args.batch / (opt_ms * 1e-3), 1), "steps": args.steps,
-                                    "options": "bf16 wire + row-sparse word-table exchange + two compute streams", "stalled_steps": sync.stalled_steps}
-            sync.close()
-            model.bert.parallel_stacks = keep_ps
-            sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
         # exposed communication = the headline step minus the same step without any collective (replicas diverge from here
-        # on: timing only, nothing after this reads the weights' values)
+        # on: timing only, nothing after this reads the weights' values).  Measured before the opt-in leg: it needs no
+        # collective, so it cannot be lost to one.
         sync.exchange = False
         noex_ms, _ = timed(batch, 2, args.steps)
         sync.exchange = True
         dp_info["exposed_comm_ms"] = round(ms_per_step - noex_ms, 2)
         dp_info["ms_per_step_without_exchange"] = round(noex_ms, 2)
+        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows):
+            keep_ps = model.bert.parallel_stacks
+            try:
+                sync.close()
+                model.bert.parallel_stacks = "always"
+                sync = dp.GradSync(model, sparse_rows=[model.bert.embeddings.word_embeddings.weight], comm_dtype=torch.bfloat16)
+                opt_ms, _ = timed(batch, 3, args.steps)
+                dp_info["dp_optins"] = {"ms_per_step": round(opt_ms, 2), "value": round(world * args.batch / (opt_ms * 1e-3), 1), "steps": args.steps,
+                                        "options": "bf16 wire + row-sparse word-table exchange + two compute streams", "stalled_steps": sync.stalled_steps}
+            except Exception as e:      # an opt-in that fails on its first multi-GPU run must not cost the headline its line
+                dp_info["dp_optins"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            finally:
+                model.bert.parallel_stacks = keep_ps
+            try:
+                sync.close()
+                sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
+            except Exception as e:
+                dp_info["restore_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
     # The same step with every token / region slot valid ("256 x (70 tok + 50 region)", nothing to skip),
     # timed exactly like the headline: K steps between the same fences.  Reported beside `value` because
