@@ -688,6 +688,7 @@ extern "C" int mvptr_attention_fwd_packed(const void* qkv, const float* mask_add
   int rc = check_common("attention_fwd", qkv, B, L, heads);
   if (rc) return rc;
   if (!ctx) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL ctx");
+  if ((uintptr_t)ctx & 15) MVPTR_FAIL(MVPTR_BAD_ALIGN, "attention_fwd: ctx must be 16-byte aligned (rows leave as 16-byte pieces)");
   if ((seq_start == nullptr) != (seq_len == nullptr)) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: seq_start and seq_len go together");
   if (!mask_add && !seq_len) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask (only allowed in packed mode)");
   AttnArgs a{};
@@ -726,7 +727,8 @@ extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add
   if (!ctx || !dctx || !lse || !dqkv) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL argument");
   if ((seq_start == nullptr) != (seq_len == nullptr)) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: seq_start and seq_len go together");
   if (!mask_add && !seq_len) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_bwd: NULL mask (only allowed in packed mode)");
-  if (((uintptr_t)dctx & 15) || ((uintptr_t)ctx & 15)) MVPTR_FAIL(MVPTR_BAD_ALIGN, "attention_bwd: ctx/dctx must be 16-byte aligned");
+  if (((uintptr_t)dctx & 15) || ((uintptr_t)ctx & 15) || ((uintptr_t)dqkv & 15))
+    MVPTR_FAIL(MVPTR_BAD_ALIGN, "attention_bwd: ctx / dctx / dqkv must be 16-byte aligned");
   AttnArgs a{};
   a.qkv = (const __bf16*)qkv;
   a.mask = mask_add;
