@@ -140,7 +140,8 @@ int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* str
  * dropout, PV, merge heads).  qkv: bf16 [B*L, 3*H] (Q | K | V, head-major inside each),
  * mask_add: f32 [B, L] additive mask (0 / -10000) broadcast over heads and queries,
  * ctx: bf16 [B*L, H], lse: f32 [B, heads, L] (row log-sum-exp, saved for backward; may be
- * NULL in inference).  head_dim must be 64, L <= 256.
+ * NULL in inference).  head_dim must be 64, L <= 256; qkv, ctx (and dctx, dqkv in backward) 16-byte aligned (rows move
+ * as 16-byte pieces).
  * drop: dropout on the probabilities, element index = ((b*heads + h)*L + q)*Lp + key with
  * Lp = L rounded up to a multiple of 32 (adjacent keys of a query form the hash pairs). */
 int mvptr_attention_fwd(const void* qkv, const float* mask_add, void* ctx, float* lse, int B,
