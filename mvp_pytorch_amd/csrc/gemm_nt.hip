@@ -322,6 +322,18 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       uint8_t* dp = reinterpret_cast<uint8_t*>(p.out0) + (int64_t)m * p.ldc + n;
       const u32x2 dq = {dgelu_pack4(dg[0], dg[1], dg[2], dg[3]), dgelu_pack4(dg[4], dg[5], dg[6], dg[7])};
       if (nfull && p.vec_out_ok) {
+#ifdef MVPTR_DIAG_BUILD
+        if (p.stash_temporal >= 2) {
+          // A/B of the cache policy of these half-line (64 bytes per row and wave) stores: 2 = sc1, 3 = sc0 sc1, 4 = nt through
+          // the same buffer-store path (MVPTR_NT_EXP bits 19-21)
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.out0, 0xfffffff0u);          // one descriptor, per-lane byte offsets
+          const uint32_t vo = (uint32_t)((int64_t)m * p.ldc + n);
+          const int aux = p.stash_temporal == 2 ? 16 : (p.stash_temporal == 3 ? 17 : 2);
+          if (aux == 16) __builtin_amdgcn_raw_buffer_store_b64(dq, rs, vo, 0, 16);
+          else if (aux == 17) __builtin_amdgcn_raw_buffer_store_b64(dq, rs, vo, 0, 17);
+          else __builtin_amdgcn_raw_buffer_store_b64(dq, rs, vo, 0, 2);
+        } else
+#endif
         if (!p.stash_temporal) __builtin_nontemporal_store(dq, reinterpret_cast<u32x2*>(dp));
         else *reinterpret_cast<u32x2*>(dp) = dq;
       } else {
@@ -1425,6 +1437,7 @@ int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, i
   a.part_ld = a.n_store = 0;
   const MvptrKnobs& kn = mvptr_knobs();
   a.stash_temporal = (kn.nt_exp & 512) ? 1 : 0;
+  if ((kn.nt_exp >> 19) & 7) a.stash_temporal = 1 + ((kn.nt_exp >> 19) & 7);      // bits 19-21: 1 = sc1, 2 = sc0 sc1, 3 = nt (buffer store)
   a.no_epi = (kn.nt_exp & 1024) ? 1 : 0;
   a.store_mode = (kn.nt_exp >> 13) & 7;
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
