@@ -349,6 +349,15 @@ int mvptr_sgemm_small(const void* A, int64_t lda, int a_bf16, int trans_a, const
 int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_t* labels, int M, int V, float* loss,
                         float* dlogits, void* stream);
 
+/* Head glue (round 4).  mvptr_masked_mean: out[0] = sum(loss_row[0..M)) / max(count, 1), out[1] = max(count, 1), count = rows
+ * with label >= 0 — the mean of the fused decoder + cross-entropy's per-row losses (CrossEntropyLoss(ignore_index=-1),
+ * oscar/modeling/modeling_vlbert.py:1247-1251; unscored rows carry loss_row = 0); one workgroup, fixed reduction tree.
+ * mvptr_dgelu_mul: out[m, n] = bf16(dy[m, n] * gelu'(u)[m, n]) for n < N, 0 for N <= n < Npad, gelu' decoded from the 8-bit
+ * stash of MVPTR_EPI_BIAS_GELU (the GELU backward of a head transform, modeling_bert.py:142-148 under autograd). */
+int mvptr_masked_mean(const float* loss_row, const int64_t* labels, int M, float* out, void* stream);
+int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, void* out, int64_t ld_o, int M, int N, int Npad,
+                    void* stream);
+
 /* g = y / max(||y||_2, eps) per row, inv_norm[r] = 1 / max(||y||, eps): F.normalize(p=2, dim=-1) of
  * oscar/modeling/modeling_vlbert.py:525-526; backward dy = (dg - g (g . dg)) * inv_norm. */
 int mvptr_l2norm_fwd(const float* y, float* g, float* inv_norm, int rows, int H, float eps, void* stream);

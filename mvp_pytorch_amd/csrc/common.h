@@ -179,9 +179,9 @@ __device__ __forceinline__ uint32_t dgelu_pack4(float g0, float g1, float g2, fl
   const uint32_t p23 = __builtin_amdgcn_perm(f3, f2, 0x0c0c0400u);
   return p01 | (p23 << 16);
 }
-__device__ __forceinline__ float dgelu_unpack(uint32_t w, int i) {
-  return fmaf((float)((w >> (8 * i)) & 0xffu), 1.0f / MVPTR_DGELU_SCALE, -MVPTR_DGELU_ZERO / MVPTR_DGELU_SCALE);
-}
+// (q - 26) is exact and 200 * (1 / 200.f) rounds to 1: the grid points 0 and 1 decode EXACTLY (one fma would leave 1.9e-9 at 0)
+__device__ __forceinline__ float dgelu_decode1(uint32_t q) { return ((float)q - MVPTR_DGELU_ZERO) * (1.0f / MVPTR_DGELU_SCALE); }
+__device__ __forceinline__ float dgelu_unpack(uint32_t w, int i) { return dgelu_decode1((w >> (8 * i)) & 0xffu); }
 
 // Sum over the 64 lanes, result in every lane: four DPP steps inside each 16-lane row (quad
 // swaps, half-row mirror, row mirror) and four v_readlane for the rows — no LDS crossbar

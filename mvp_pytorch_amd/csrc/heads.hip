@@ -377,6 +377,78 @@ extern "C" int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Two pieces of head glue that were chains of tiny torch kernels (round 4: 6 + 8 launches per MLM head and step):
+//  * masked mean of the per-row losses of the fused decoder + cross-entropy:  out[0] = sum(loss_row) / max(count, 1),
+//    out[1] = max(count, 1), count = rows with label >= 0 (CrossEntropyLoss(ignore_index=-1) of vl:1247-1251: rows the
+//    kernels did not score carry loss_row = 0).  One workgroup, fixed tree: bitwise reproducible.
+//  * d(gelu) -> du of a head transform: out = bf16(dy * gelu'(u)), gelu'(u) decoded from the 8-bit stash the forward
+//    epilogue wrote (common.h); columns N .. Npad of out (operand padding of the next GEMM) are zeroed.
+namespace {
+__global__ __launch_bounds__(1024) void masked_mean_kernel(const float* loss_row, const int64_t* labels, int M, float* out) {
+  __shared__ float red[1024];
+  __shared__ int cnt[1024];
+  float s = 0.f;
+  int c = 0;
+  for (int m = threadIdx.x; m < M; m += 1024) {
+    s += loss_row[m];
+    c += labels[m] >= 0 ? 1 : 0;
+  }
+  red[threadIdx.x] = s;
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      cnt[threadIdx.x] += cnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float n = (float)max(cnt[0], 1);
+    out[0] = red[0] / n;
+    out[1] = n;
+  }
+}
+__global__ __launch_bounds__(256) void dgelu_mul_kernel(const __bf16* dy, int64_t ld_dy, const uint8_t* stash, int64_t ld_s, __bf16* out,
+                                                         int64_t ld_o, int M, int N, int Npad) {
+  const int quads = Npad >> 2;
+  const int64_t total = (int64_t)M * quads;
+  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int m = (int)(e / quads), n = (int)(e - (int64_t)m * quads) * 4;
+    bf16x4 o = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (n + k < N) {
+        const float g = dgelu_decode1(stash[(int64_t)m * ld_s + n + k]);
+        o[k] = f2bf(bf2f(dy[(int64_t)m * ld_dy + n + k]) * g);
+      }
+    *reinterpret_cast<bf16x4*>(out + (int64_t)m * ld_o + n) = o;
+  }
+}
+}  // namespace
+
+extern "C" int mvptr_masked_mean(const float* loss_row, const int64_t* labels, int M, float* out, void* stream) {
+  if (M <= 0 || !loss_row || !labels || !out) MVPTR_FAIL(MVPTR_BAD_ARG, "masked_mean: bad argument");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_row, labels, M, out);
+  MVPTR_CHECK_LAUNCH("masked_mean");
+  return MVPTR_OK;
+}
+
+extern "C" int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, void* out, int64_t ld_o, int M, int N,
+                               int Npad, void* stream) {
+  if (M <= 0 || N <= 0 || Npad < N || (Npad & 3) || ld_dy < N || ld_s < N || ld_o < Npad || (ld_o & 3) || !dy || !stash || !out ||
+      ((uintptr_t)out & 7))
+    MVPTR_FAIL(MVPTR_BAD_ARG, "dgelu_mul: bad shape / alignment (Npad %% 4 == 0, ld_o >= Npad, out 8-byte aligned)");
+  const int64_t total = (int64_t)M * (Npad >> 2);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, ld_dy, (const uint8_t*)stash, ld_s,
+                     (__bf16*)out, ld_o, M, N, Npad);
+  MVPTR_CHECK_LAUNCH("dgelu_mul");
+  return MVPTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // In-batch hard negatives (oscar/modeling/modeling_vlbert.py:529-566, hn_mod = 'hard'): per text the most similar
 // OTHER image, per image the most similar other text (argmax of sim - 2 I along rows / columns), then the two halves of
 // a random permutation decide which side of each hard pair is replaced:

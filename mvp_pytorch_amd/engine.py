@@ -824,11 +824,11 @@ class LinearFn(GradAwareFunction):
             pad[:, :N] = dy2
             dy2 = pad
         if u is not None:
-            # dy2 is d(gelu(u)); u holds gelu'(u) saved by the forward epilogue as 8-bit fixed point (head-sized rows:
-            # a torch multiply is enough here, the encoder layers use the fused GEMM epilogue)
-            du = torch.zeros((dy2.shape[0], Np), device=dev, dtype=torch.bfloat16)
-            du[:, :N] = (dy2[:, :N].float() * hip.dgelu_decode(u[:, :N])).to(torch.bfloat16)
-            dy2 = du
+            # dy2 is d(gelu(u)); u holds gelu'(u) saved by the forward epilogue as 8-bit fixed point: one launch (the encoder
+            # layers have the multiply in their GEMM epilogue; here the producer of dy2 is a LayerNorm backward)
+            if dy2.dtype != torch.bfloat16:
+                dy2 = dy2.to(torch.bfloat16)
+            dy2 = hip.dgelu_mul(dy2[:, :N], u, Np)
         dx = hip.gemm_nt(dy2, wt, hip.EPI_ADD, n=K) if ctx.needs[0] else None
         dw, dw_d = None, False
         if ctx.needs[1]:
@@ -887,14 +887,14 @@ class DecoderCEFn(GradAwareFunction):
         cache.weight_copies(weight)
         h = h.contiguous()
         labels = labels.contiguous()
-        nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32)
+        nvalid = (labels >= 0).sum().clamp(min=1).to(torch.float32) if want_scores else None
         ctx.needs = (h.requires_grad, weight.requires_grad, bias.requires_grad)
         ctx.ps = (weight, bias)
         note_uses(ctx, (weight, bias), 1)
         if not want_scores:
             b32 = _f32(bias)
             loss_row, lse = hip.decoder_ce_fwd(h, cache.t["w"], b32, labels, V)
-            loss = loss_row.sum() / nvalid
+            loss, nvalid = hip.masked_mean(loss_row, labels)       # sum / max(#labels >= 0, 1) in one launch
             ctx.save = (h, None, labels, lse, nvalid, cache, V, Vp, b32)
             out_logits = torch.zeros((0, V), device=h.device, dtype=torch.float32)
             ctx.mark_non_differentiable(out_logits)

@@ -34,6 +34,7 @@ SYMBOLS = [
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
     "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
+    "mvptr_masked_mean", "mvptr_dgelu_mul",
 ]
 
 
@@ -134,6 +135,8 @@ def load():
     lib.mvptr_hard_negative_mine.argtypes = [P, I, I64, P, P, P, P, P, P, P, P]
     lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
     lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
+    lib.mvptr_masked_mean.argtypes = [P, P, I, P, P]
+    lib.mvptr_dgelu_mul.argtypes = [P, I64, P, I64, P, I64, I, I, I, P]
     lib.mvptr_tap_rows_bwd.argtypes = [POINTER(Tap), I, P, I64, I, P, I64, I, I, P, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
     lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
@@ -637,6 +640,22 @@ def scatter_add_rows(src, idx, dst, dst2=None):
                                              _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0],
                                              int(dst.dtype == torch.float32), n, H, _stream()))
     return dst
+
+
+def masked_mean(loss_row, labels):
+    """(mean of loss_row over the rows with label >= 0 (0-dim f32), max(count, 1) (0-dim f32)) — mvptr_masked_mean."""
+    out = torch.empty(2, dtype=torch.float32, device=loss_row.device)
+    _check(load().mvptr_masked_mean(_p(loss_row), _p(labels), loss_row.numel(), _p(out), _stream()))
+    return out[0], out[1]
+
+
+def dgelu_mul(dy, stash, Npad=None):
+    """bf16 [M, Npad] = dy * gelu'(u) decoded from the 8-bit stash (columns N .. Npad zero) — mvptr_dgelu_mul."""
+    M, N = dy.shape
+    Npad = N if Npad is None else Npad
+    out = torch.empty((M, Npad), dtype=torch.bfloat16, device=dy.device)
+    _check(load().mvptr_dgelu_mul(_p(dy), dy.stride(0), _p(stash), stash.stride(0), _p(out), out.stride(0), M, N, Npad, _stream()))
+    return out
 
 
 def tap_rows_bwd(taps, rows, rows2, H):

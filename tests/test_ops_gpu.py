@@ -484,6 +484,30 @@ def test_multi_tap_fn_gradients(dev):
     assert ((got - ref.grad.float()).abs() <= 2.0 ** -7 * ref.grad.float().abs() + 1e-5).all()
 
 
+def test_head_glue_kernels(dev):
+    """mvptr_masked_mean (mean of the decoder-CE row losses over the rows with label >= 0) and mvptr_dgelu_mul (GELU backward
+    of a head transform from the 8-bit stash, pad columns zeroed) against the torch expressions they replace."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for M in (1, 37, 2900, 5000):
+        labels = torch.randint(-1, 30522, (M,), generator=g)
+        labels[torch.rand(M, generator=g) < 0.4] = -1
+        loss_row = torch.rand(M, generator=g) * (labels >= 0).float()
+        loss, n = hip.masked_mean(loss_row.to(dev), labels.to(dev))
+        want_n = max(int((labels >= 0).sum()), 1)
+        assert float(n) == float(want_n)
+        assert abs(float(loss) - float(loss_row.double().sum()) / want_n) < 1e-5 * max(1.0, float(loss_row.sum()) / want_n)
+    none = torch.full((9,), -1, dtype=torch.int64)
+    loss, n = hip.masked_mean(torch.zeros(9, device=dev), none.to(dev))
+    assert float(loss) == 0.0 and float(n) == 1.0
+    for M, N, Npad in ((2900, 768, 768), (33, 100, 104), (5, 8, 8)):
+        dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+        gq = hip.dgelu_encode(torch.rand(M, N, generator=g) * 1.25 - 0.125).to(dev)
+        out = hip.dgelu_mul(dy, gq, Npad)
+        want = (dy.float() * hip.dgelu_decode(gq)).to(torch.bfloat16)
+        assert out.shape == (M, Npad) and (out[:, N:] == 0).all() and torch.equal(out[:, :N], want)
+
+
 @pytest.mark.parametrize("M,H", [(1000, 768), (77, 128), (5, 1024)])
 def test_layernorm(dev, M, H):
     from mvp_pytorch_amd import hip
