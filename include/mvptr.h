@@ -424,6 +424,13 @@ typedef struct mvptr_tap {
 int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, int64_t ld_dst, int rows, void* dst2, int64_t ld_dst2,
                        int rows2, int H, int32_t* work, int64_t work_elems, void* stream);
 
+/* Scored rows of a masked-LM head in one launch: the slots (b, l) of labels[B, L] with label > -1, ascending, as
+ * out_labels[k] = the label and out_rows[k] = pos[b * ld_pos + l] (int32 row map of the packed buffer; NULL: the flat slot
+ * index).  Exactly n_out entries are written (surplus cut, shortfall padded with label -1 / row -1).  Replaces the
+ * masked_select chains of oscar/modeling/modeling_vlbert.py:1231-1234,1245. */
+int mvptr_compact_scored(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L, int n_out,
+                         int64_t* out_labels, int32_t* out_rows, void* stream);
+
 /* Index maps of a row-packed pass, built on the device from additive attention masks (valid slot <=> 0).
  * Output sequence s (0 <= s < n_seq) is the concatenation of nseg (1 or 2) segments; segment k covers the slots
  * [col0, col0 + len) of mask row sel[s] (s when sel == NULL) and names the SOURCE row of each valid slot:

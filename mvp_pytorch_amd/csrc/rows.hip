@@ -346,6 +346,60 @@ extern "C" int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, i
 }
 
 
+// Scored rows of a masked-LM head in one launch: the positions e of labels[B, L] (row-major) with label > -1, in ascending
+// order, as out_labels[k] = labels[e] and out_rows[k] = pos[b * ld_pos + l] (the packed row of slot (b, l); pos NULL: e
+// itself).  Exactly n_out entries are written: a surplus is cut, a shortfall padded with label -1 / row -1 (a zero row the
+// loss ignores).  Replaces `keep = labels > -1; idx = nonzero_static(keep, size); labels.index_select(idx);
+// pos.reshape(-1).index_select(idx)` — 7 small launches per head (oscar/modeling/modeling_vlbert.py:1231-1234,1245).
+namespace {
+__global__ __launch_bounds__(1024) void compact_scored_kernel(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L,
+                                                               int n_out, int64_t* out_labels, int32_t* out_rows) {
+  __shared__ int scan[1024];
+  const int tid = threadIdx.x, total = B * L;
+  const int per = (total + 1023) / 1024;
+  const int e0 = min(tid * per, total), e1 = min(e0 + per, total);
+  int c = 0;
+  for (int e = e0; e < e1; ++e) c += labels[e] > -1 ? 1 : 0;
+  scan[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (tid >= o) ? scan[tid - o] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  int k = scan[tid] - c;
+  const int found = scan[1023];
+  for (int e = e0; e < e1; ++e) {
+    const int64_t lab = labels[e];
+    if (lab > -1) {
+      if (k < n_out) {
+        out_labels[k] = lab;
+        const int b = e / L;
+        out_rows[k] = pos ? pos[(int64_t)b * ld_pos + (e - b * L)] : e;
+      }
+      ++k;
+    }
+  }
+  for (int j = found + tid; j < n_out; j += 1024) {
+    out_labels[j] = -1;
+    out_rows[j] = -1;
+  }
+}
+}  // namespace
+
+extern "C" int mvptr_compact_scored(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L, int n_out,
+                                    int64_t* out_labels, int32_t* out_rows, void* stream) {
+  if (B <= 0 || L <= 0 || n_out < 0 || (int64_t)B * L >= (int64_t)1 << 30 || !labels || (n_out > 0 && (!out_labels || !out_rows)) ||
+      (pos && ld_pos < L))
+    MVPTR_FAIL(MVPTR_BAD_ARG, "compact_scored: bad argument");
+  if (n_out == 0) return MVPTR_OK;
+  hipLaunchKernelGGL(compact_scored_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, pos, ld_pos, B, L, n_out, out_labels,
+                     out_rows);
+  MVPTR_CHECK_LAUNCH("compact_scored");
+  return MVPTR_OK;
+}
+
 // Host-provided counts against the device's (sync-free training step: the input-only counts of a batch come from where
 // the batch was built; the pack maps count them again on the device).  A mismatch is a caller bug that would silently
 // truncate or over-read the packed rows: trap.

@@ -152,6 +152,31 @@ def next_seed():
         return (_seed_counter[0] ^ (base << 20)) & 0xFFFFFFFFFFFFFFFF
 
 
+_ARANGES = {}
+
+
+def arange(n, device, dtype=torch.long, step=1, floor_div=1):
+    """(torch.arange(n) // floor_div) * step on `device`, made once per (device, n, dtype, step, floor_div) and shared: position
+    ids, [CLS] row indices, pseudo-labels of the contrastive loss, index vectors of the WRA draws, the 0 / 1 labels of the
+    matched / hard pairs (floor_div = n over 2 n entries) were a dozen tiny launches per step.  READ-ONLY for the callers
+    (every use in this package indexes with it or feeds it to an out-of-place op)."""
+    d = torch.device(device)
+    key = (d.type, d.index if d.index is not None or d.type != "cuda" else torch.cuda.current_device(), int(n), dtype, int(step),
+           int(floor_div))
+    t = _ARANGES.get(key)
+    if t is None:
+        with _state_lock:
+            t = _ARANGES.get(key)
+            if t is None:
+                t = torch.arange(int(n), device=d, dtype=dtype)
+                if floor_div != 1:
+                    t = torch.div(t, int(floor_div), rounding_mode="floor")
+                if step != 1:
+                    t = t * step
+                _ARANGES[key] = t
+    return t
+
+
 def _dev_key(device):
     d = torch.device(device)
     if d.type != "cuda":

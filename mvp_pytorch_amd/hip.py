@@ -34,7 +34,7 @@ SYMBOLS = [
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
     "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
-    "mvptr_masked_mean", "mvptr_dgelu_mul",
+    "mvptr_masked_mean", "mvptr_dgelu_mul", "mvptr_compact_scored",
 ]
 
 
@@ -136,6 +136,7 @@ def load():
     lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
     lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
     lib.mvptr_masked_mean.argtypes = [P, P, I, P, P]
+    lib.mvptr_compact_scored.argtypes = [P, P, I64, I, I, I, P, P, P]
     lib.mvptr_dgelu_mul.argtypes = [P, I64, P, I64, P, I64, I, I, I, P]
     lib.mvptr_tap_rows_bwd.argtypes = [POINTER(Tap), I, P, I64, I, P, I64, I, I, P, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
@@ -640,6 +641,18 @@ def scatter_add_rows(src, idx, dst, dst2=None):
                                              _p(dst2), dst2.stride(0) if dst2 is not None else 0, dst.shape[0],
                                              int(dst.dtype == torch.float32), n, H, _stream()))
     return dst
+
+
+def compact_scored(labels, pos, n_out):
+    """labels int64 [B, L] (contiguous), pos int32 [*, ld] row map (its first B rows / L columns are read; None: flat slot index)
+    -> (labels of the slots with label > -1 in ascending slot order int64 [n_out], their rows int32 [n_out]) — mvptr_compact_scored."""
+    B, L = labels.shape
+    assert labels.dtype == torch.int64 and labels.is_contiguous()
+    assert pos is None or (pos.dtype == torch.int32 and pos.stride(-1) == 1 and pos.shape[0] >= B and pos.shape[1] >= L)
+    ol = torch.empty(n_out, dtype=torch.int64, device=labels.device)
+    orow = torch.empty(n_out, dtype=torch.int32, device=labels.device)
+    _check(load().mvptr_compact_scored(_p(labels), _p(pos), pos.stride(0) if pos is not None else 0, B, L, int(n_out), _p(ol), _p(orow), _stream()))
+    return ol, orow
 
 
 def masked_mean(loss_row, labels):

@@ -88,7 +88,7 @@ def embed_inputs(emb, input_ids, token_type_ids, position_ids, img_feats, owner,
     dict common to the embedding calls of one forward pass (see InputEmbedFn.backward)."""
     L = input_ids.size(1)
     if position_ids is None:
-        position_ids = torch.arange(L, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
+        position_ids = engine.arange(L, input_ids.device).unsqueeze(0).expand_as(input_ids)
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
     cache = emb.__dict__.setdefault("_img_cache", engine.WeightCache())
@@ -185,7 +185,7 @@ class BertPooler(nn.Module):
     def forward(self, hidden_states):
         if hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and hidden_states.is_contiguous() and hidden_states.dim() == 3:
             B, L, H = hidden_states.shape
-            rows = torch.arange(B, device=hidden_states.device, dtype=torch.int32) * L
+            rows = engine.arange(B, hidden_states.device, torch.int32, step=L)
             return self.forward_rows(engine.tap_rows(hidden_states.view(B * L, H), rows))
         return self.forward_rows(hidden_states[:, 0])
 

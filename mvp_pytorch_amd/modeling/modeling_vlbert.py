@@ -393,7 +393,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         """[CLS] rows of a [B, L, H] sequence tensor, tapped by row index when it is a contiguous bf16 device buffer."""
         if seq.is_cuda and seq.dtype == torch.bfloat16 and seq.is_contiguous():
             B, L, H = seq.shape
-            return engine.tap_rows(seq.view(B * L, H), torch.arange(B, device=seq.device, dtype=torch.int32) * L)
+            return engine.tap_rows(seq.view(B * L, H), engine.arange(B, seq.device, torch.int32, step=L))
         return seq[:, 0, :]
 
     def _project(self, cls_rows, proj):
@@ -439,7 +439,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             hard_img, hard_txt = self.mine_hard_negatives(sim_mat, hn_mod, logit)
             dice = torch.randperm(n, device=dev)
             first, second = dice[: n // 2], dice[n // 2:]
-            ar = torch.arange(n, device=dev)
+            ar = engine.arange(n, dev)
             # rows of the hard batch: (text i, image hard_img[i]) for i in first,
             #                         (text hard_txt[j], image j)  for j in second       (vl:544-566)
             hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
@@ -593,7 +593,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             hard_img, hard_txt = self.mine_hard_negatives(sim_mat.detach(), hn_mod, logit)
             dice = torch.randperm(n, device=dev)
             first, second = dice[: n // 2], dice[n // 2:]
-            ar = torch.arange(n, device=dev)
+            ar = engine.arange(n, dev)
             hard_txt_full = torch.cat([ar.index_select(0, first), hard_txt.index_select(0, second)], 0)
             hard_img_full = torch.cat([hard_img.index_select(0, first), ar.index_select(0, second)], 0)
             sel_txt, sel_img = torch.cat([ar, hard_txt_full]), torch.cat([ar, hard_img_full])
@@ -791,7 +791,7 @@ def _segment_top3_mean(sims, row_owner, col_start, col_count, picks, n):
     column range [col_start, col_start+col_count) of each row (t2i_sim, vl:1543-1550)."""
     dev = sims.device
     rmax = int(col_count.max().item()) if col_count.numel() else 0
-    ar = torch.arange(max(rmax, 3), device=dev)
+    ar = engine.arange(max(rmax, 3), dev)
     cols = col_start[:, None] + ar[None, :]
     valid = ar[None, :] < col_count[:, None]
     vals = sims.gather(1, cols.clamp(max=sims.shape[1] - 1)).masked_fill(~valid, float("-inf"))
@@ -842,10 +842,10 @@ def wra_sample_on_device(seq, phrase_index, img_index, text_len, draws=None, max
     p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
     if max_phrases:
         torch._assert_async(((p1 - p0) <= Pw).all(), "a sample has more phrases than config.max_phrases")
-    ar_p = torch.arange(Pw, device=dev)
+    ar_p = engine.arange(Pw, dev)
     rows_p = (p0[:, None] + ar_p[None, :]).clamp(max=Lj - 1)                              # [B, Pw]
     valid_p = ar_p[None, :] < (p1 - p0)[:, None]
-    ar_r = torch.arange(Rw, device=dev)
+    ar_r = engine.arange(Rw, dev)
     rows_r = (i0[:, None] + ar_r[None, :]).clamp(max=Lj - 1)                              # [B, Rw]
     valid_r = ar_r[None, :] < (i1 - i0)[:, None]
     txt_n = F.normalize(seq.gather(1, rows_p[:, :, None].expand(-1, -1, H)).float(), p=2, dim=-1)
@@ -853,7 +853,7 @@ def wra_sample_on_device(seq, phrase_index, img_index, text_len, draws=None, max
     if draws is None:
         pos_pick = torch.randint(0, 3, (B, Pw), device=dev)
         neg_pick = torch.randint(0, 3, (B, Pw), device=dev)
-        neg_img = (torch.arange(B, device=dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
+        neg_img = (engine.arange(B, dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
     else:
         pos_pick, neg_pick, neg_img = (d.to(dev) for d in draws)
     cnt = valid_p.sum(1).clamp(min=1).to(txt_n.dtype)
@@ -878,7 +878,7 @@ def _wra_from_rows(txt_n, reg_n, valid_p, valid_r, draws=None):
     if draws is None:
         pos_pick = torch.randint(0, 3, (B, Pw), device=dev)
         neg_pick = torch.randint(0, 3, (B, Pw), device=dev)
-        neg_img = (torch.arange(B, device=dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
+        neg_img = (engine.arange(B, dev) + 1 + torch.randint(0, max(B - 1, 1), (B,), device=dev)) % B
     else:
         pos_pick, neg_pick, neg_img = (d.to(dev) for d in draws)
     cnt = valid_p.sum(1).clamp(min=1).to(txt_n.dtype)
@@ -900,7 +900,7 @@ def t2i_sim(sim_matrix):
         return torch.zeros((), dtype=sim_matrix.dtype, device=sim_matrix.device)
     f_sim = sim_matrix.topk(3, dim=1)[0]
     rand_index = torch.randint(0, 3, (f_sim.shape[0],)).to(f_sim.device)
-    return f_sim[torch.arange(f_sim.shape[0], device=f_sim.device), rand_index].mean()
+    return f_sim[engine.arange(f_sim.shape[0], f_sim.device), rand_index].mean()
 
 
 def get_pos_sims(sequence_output, text_index, img_index):
@@ -1000,18 +1000,18 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         Same losses as forward() (tests/test_model_gpu.py::test_packed_pipeline_equals_general_path)."""
         dev = input_ids_a.device
         n, La = input_ids_a.shape
-        keep_a, keep_b = (masked_lm_labels_a > -1).reshape(-1), (masked_lm_labels_b > -1).reshape(-1)
+        from .. import hip
         if host_counts is not None:
             n_scored = (int(host_counts["scored_a"]), int(host_counts["scored_b"]))
         else:
-            scored = engine.AsyncCounts([keep_a.sum(), keep_b.sum()])
+            scored = engine.AsyncCounts([(masked_lm_labels_a > -1).sum(), (masked_lm_labels_b > -1).sum()])
             n_scored = None
         early = {}
 
         def uni_taps(pos_a, pos_b):
-            ib = torch.nonzero_static(keep_b, size=(n_scored or scored.get())[1]).view(-1)
-            early["labels_b"] = masked_lm_labels_b.reshape(-1).index_select(0, ib)
-            return [], [pos_b.view(-1).index_select(0, ib)]      # masked tag rows of the packed visual output
+            # labels and packed rows of the scored tag slots, ascending, in one launch (mvptr_compact_scored)
+            early["labels_b"], rows_b = hip.compact_scored(masked_lm_labels_b.contiguous(), pos_b, (n_scored or scored.get())[1])
+            return [], [rows_b]      # masked tag rows of the packed visual output
 
         def uni_heads(taps_txt, taps_vis, sim_mat):
             early["vis_mlm"], _ = self.half_mlm.loss_and_scores(taps_vis[0], early["labels_b"], want_scores=False)
@@ -1031,9 +1031,8 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         both, pos_j = out["both"], out["pos_j"]
         Lj = pos_j.shape[1]
         # rows of the packed joint output the heads read: [CLS] of the 2n sequences, scored text rows, phrase / region rows
-        ia = torch.nonzero_static(keep_a, size=(n_scored or scored.get())[0]).view(-1)           # flat positions in [n, La]
-        labels_a = masked_lm_labels_a.reshape(-1).index_select(0, ia)
-        rows_mlm = pos_j[:n, :La].reshape(-1).index_select(0, ia)
+        # scored text slots of the n matched pairs: their labels and their rows in the packed joint output (pos_j[:n, :La])
+        labels_a, rows_mlm = hip.compact_scored(masked_lm_labels_a.contiguous(), pos_j, (n_scored or scored.get())[0])
         idxs = [pos_j[:, 0].contiguous(), rows_mlm]
         wra = phrase_index is not None
         if wra:
@@ -1046,7 +1045,6 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
             # device (no host sync) and the kernel clamps the drawn rank (csrc/wra.hip)
             torch._assert_async(((img_index[:, 1] - img_index[:, 0]) >= 3).all(),
                                 "word-region alignment needs >= 3 valid regions per image (topk(3), vl:1547)")
-            from .. import hip
             rows_p, rows_r = hip.wra_rows(pos_j, phrase_index, img_index, n, Pw, Rw)
             idxs += [rows_p.view(-1), rows_r.view(-1)]
         taps = engine.MultiTapFn.apply(both, None, *idxs)
@@ -1055,7 +1053,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         def small_heads():
             pooled = bb.pooler.forward_rows(taps[0])                     # [2n, H]: matched then hard pairs
             score = engine.SmallLinearFn.apply(pooled, self.cls.seq_relationship.weight, self.cls.seq_relationship.bias, None, False)
-            label = torch.cat([torch.zeros(n, dtype=torch.long, device=dev), torch.ones(n, dtype=torch.long, device=dev)])
+            label = engine.arange(2 * n, dev, torch.long, floor_div=n)     # n zeros (matched pairs) then n ones (hard pairs), cached
             late["itm"] = engine.CeMeanFn.apply(score.view(-1, self.num_seq_relations), label)
             if qa_ans is not None:
                 late["qa"] = CrossEntropyLoss(ignore_index=-1)(self.qa_head(pooled[:n]), qa_ans)
@@ -1065,7 +1063,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 # per sample) from the device generator, in wra_sample_on_device's order
                 pos_pick = torch.randint(0, 3, (n, Pw), device=dev)
                 neg_pick = torch.randint(0, 3, (n, Pw), device=dev)
-                neg_img = (torch.arange(n, device=dev) + 1 + torch.randint(0, max(n - 1, 1), (n,), device=dev)) % n
+                neg_img = (engine.arange(n, dev) + 1 + torch.randint(0, max(n - 1, 1), (n,), device=dev)) % n
                 late["wra"] = engine.WraLossFn.apply(taps[2].view(n, Pw, H), taps[3].view(n, Rw, H), phrase_index, img_index,
                                                      pos_pick, neg_pick, neg_img)
 
@@ -1137,7 +1135,7 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
             vis_rows, vis_labels = _masked_rows(vis_out, masked_lm_labels_b, ib)
             early["vis_mlm"], _ = self.half_mlm.loss_and_scores(vis_rows, vis_labels, want_scores=False)
             logits = sim_mat * self.logit_scale.exp()
-            pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
+            pseudo = engine.arange(sim_mat.shape[0], sim_mat.device)
             early["retrieval"] = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
 
         outputs, single, hard_indexes = self.bert(
@@ -1294,7 +1292,7 @@ class BiImageBertForRetrieval(BertPreTrainedModel):
         sim_mat = single[2]
         ce_loss = CrossEntropyLoss(ignore_index=-1)
         logits = sim_mat * self.logit_scale.exp()
-        pseudo = torch.arange(sim_mat.shape[0], device=sim_mat.device)
+        pseudo = engine.arange(sim_mat.shape[0], sim_mat.device)
         retrieval_loss = (ce_loss(logits, pseudo) + ce_loss(logits.t(), pseudo)) / 2
         _, pooled, _, hard_pooled = outputs
         score = self.classifier(self.dropout(torch.cat([pooled, hard_pooled], dim=0)))

@@ -484,6 +484,31 @@ def test_multi_tap_fn_gradients(dev):
     assert ((got - ref.grad.float()).abs() <= 2.0 ** -7 * ref.grad.float().abs() + 1e-5).all()
 
 
+def test_compact_scored_rows(dev):
+    """mvptr_compact_scored against the chain it replaces (labels > -1 -> nonzero -> two index_selects), with a row map wider
+    and taller than the label matrix (the packed joint map), without one, with a surplus and with a shortfall of scored slots."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for B, L, ld, rows in ((256, 75, 125, 512), (7, 20, 20, 7), (1, 5, 9, 3), (300, 70, 70, 300)):
+        labels = torch.randint(0, 30522, (B, L), generator=g)
+        labels[torch.rand(B, L, generator=g) < 0.85] = -1
+        pos = torch.randint(-1, 40000, (rows, ld), generator=g, dtype=torch.int32)
+        keep = (labels > -1).reshape(-1)
+        idx = torch.nonzero(keep).reshape(-1)
+        want_l = labels.reshape(-1)[idx]
+        want_r = pos[:B, :L].reshape(-1)[idx]
+        n = idx.numel()
+        ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n)
+        assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), want_r)
+        ol, orow = hip.compact_scored(labels.to(dev), None, n)
+        assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), idx.to(torch.int32))
+        if n > 2:
+            ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n - 2)            # surplus cut
+            assert torch.equal(ol.cpu(), want_l[:n - 2]) and torch.equal(orow.cpu(), want_r[:n - 2])
+        ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n + 5)                # shortfall padded with -1 / -1
+        assert torch.equal(ol.cpu()[:n], want_l) and (ol.cpu()[n:] == -1).all() and (orow.cpu()[n:] == -1).all()
+
+
 def test_head_glue_kernels(dev):
     """mvptr_masked_mean (mean of the decoder-CE row losses over the rows with label >= 0) and mvptr_dgelu_mul (GELU backward
     of a head transform from the 8-bit stash, pad columns zeroed) against the torch expressions they replace."""
