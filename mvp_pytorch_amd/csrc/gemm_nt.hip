@@ -542,6 +542,15 @@ void gemm_nt_kernel(GemmNtArgs p) {
     for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][0]);
 #pragma unroll
     for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][0]);
+    // SCHED 1 (diagnostic A/B, MVPTR_GEMM_CFG=f): the fragments of the second k-substep are requested here too, so the LDS
+    // streams all 24 reads of the stage while the first 32 MFMAs run, instead of stalling on 12 reads between the two halves
+    bf16x8 xf1[SCHED == 1 ? MT : 1], wf1[SCHED == 1 ? 4 : 1];
+    if constexpr (SCHED == 1 && KS == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][1]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf1[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][1]);
+    }
     if (kt + STAGES - 1 < nk) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
@@ -559,10 +568,17 @@ void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks > 0) {
+        if constexpr (SCHED == 1 && KS == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][ks]);
+          for (int i = 0; i < 4; ++i) wf[i] = wf1[i];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][ks]);
+          for (int i = 0; i < MT; ++i) xf[i] = xf1[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(lb + fw[i][ks]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(la + fx[i][ks]);
+        }
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1257,6 +1273,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
     if (env[0] == 'm' && env[1] == '6') return launch_bk<EPI, 64, 2, 2, 4, 6, 0>(a, s);  // "m6": 192 x 256 tiles (tail split A/B)
     if (env[0] == 'm' && env[1] == '4') return launch_bk<EPI, 64, 2, 2, 4, 4, 0>(a, s);  // "m4": 128 x 256
     if (env[0] == 'm' && env[1] == '2') return launch_bk<EPI, 64, 2, 2, 4, 2, 0>(a, s);  // "m2": 64 x 256
+    if (env[0] == 'f') return launch_bk<EPI, 64, 2, 2, 4, 8, 1>(a, s);  // "f": all fragment reads of a stage up front (SCHED 1)
     if (env[0] == 't') return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);  // "t256k"
     MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt: unknown MVPTR_GEMM_CFG '%s'", env);
   }
