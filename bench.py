@@ -582,6 +582,8 @@ def main():
     ap.add_argument("--dp-one-stream", action="store_true", help="N > 1: the round-3 policy — multi-rank jobs on one compute stream (A/B)")
     ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream (what gloo jobs and --dp-one-stream run)")
     ap.add_argument("--no-arena", action="store_true", help="N = 1: gradients through autograd tensors instead of the gradient arena (A/B)")
+    ap.add_argument("--wgrad-per-layer", action="store_true",
+                    help="A/B: two grouped weight-gradient launches per encoder layer (rounds 1-4) instead of one balanced launch per stack (round 5)")
     ap.add_argument("--count-readbacks", action="store_true",
                     help="A/B: the round-3 step — row counts read back from the device inside the step (no host_counts, joint pass sized exactly)")
     ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
@@ -641,6 +643,9 @@ def main():
         cfg = dict(cfg, parallel_stacks=False)
     if args.count_readbacks:
         cfg = dict(cfg, sync_free_joint=False)
+    if args.wgrad_per_layer:
+        from mvp_pytorch_amd import engine as _engine
+        _engine.DEFER_WGRAD = False
     model = cls(modeling.make_config(cfg)).to(dev)
     model.train()
     if single:

@@ -42,7 +42,7 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 4
+#define MVPTR_ABI_VERSION 5
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
@@ -110,6 +110,7 @@ int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M,
  * share a launch (at most MVPTR_TN_MAX_GROUP each), so the atomic write-out of one problem overlaps
  * the MFMA loop of the next instead of ending every launch with an idle tail. */
 #define MVPTR_TN_MAX_GROUP 4
+#define MVPTR_TN_STACK_MAX 32
 typedef struct {
   const void* A;   /* dY bf16 [M, lda] */
   int64_t lda;
@@ -131,6 +132,19 @@ int mvptr_gemm_tn_multi(const mvptr_tn_problem* problems, int count, void* strea
  * write-out has no such requirement). */
 int mvptr_gemm_tn_multi_ws(const mvptr_tn_problem* problems, int count, void* ws, int64_t ws_bytes, void* stream);
 int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* problems, int count);
+
+/* Every weight gradient of an encoder STACK in one balanced launch (ABI 5).  The caller keeps the operands (dY, X) of all
+ * layers alive until the stack's backward pass is done and hands over the whole list; all problems share M (and rows_dev: a
+ * device int32 with the rows actually present, or NULL).  T = the problems' 256 x 256 output tiles, G = one workgroup per
+ * CU (max_workgroups > 0: at most that many — a multi-rank job leaves a few CUs to RCCL's kernels): workgroup g sweeps ALL
+ * token rows of tile r * G + g in round r < T / G (one contributor per tile, nothing to combine) and the T mod G tiles left
+ * over are cut into G equal runs of 32-row steps: every workgroup does the same number of steps (no wave quantisation, at
+ * most two partial tiles per workgroup; per-layer launches wrote 66 MB of per-split partial tiles for 35 MB of result at the
+ * packed row counts of the text / visual stacks).  Write-out: f32 atomics into dW / colsum (accumulated; full-round tiles have
+ * one contributor, so only the left-over tiles' sums depend on arrival order).  Lists longer than MVPTR_TN_STACK_MAX go out
+ * as several launches.  Same operation per problem as mvptr_gemm_tn (modeling_bert.py:348,395,408, modeling_vlbert.py:71-73
+ * under autograd). */
+int mvptr_gemm_tn_stack(const mvptr_tn_problem* problems, int count, const int* rows_dev, int max_workgroups, void* stream);
 
 /* Column sums: out[n] += sum_m X[m,n] (X bf16 [M, ldx]); bias gradients. */
 int mvptr_colsum(const void* X, int64_t ldx, int M, int N, float* out, void* stream);
@@ -578,6 +592,14 @@ int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights
                             const void* x, const float* mask_add, const void* saved,
                             const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
                             int64_t ws_bytes, void* stream);
+/* The same without the weight-gradient launches (ABI 5): the layer's (up to four) weight-gradient problems are written to
+ * wgrads[0 .. *n_wgrads) for a later mvptr_gemm_tn_stack over all layers of the stack.  Their dY operands live in ws, so
+ * every layer needs a workspace of its OWN that stays untouched until that launch has run (the X operands are x and the
+ * activation stash); the bias gradients of intermediate.dense and of Q/K/V ride on the deferred problems (colsum). */
+int mvptr_encoder_layer_bwd_defer(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                  const void* x, const float* mask_add, const void* saved,
+                                  const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
+                                  int64_t ws_bytes, mvptr_tn_problem* wgrads, int* n_wgrads, void* stream);
 
 /* Measurement helper (never on the product path): reads `bytes` (a multiple of 4096) of `src` exactly
  * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,

@@ -12,6 +12,8 @@
 // instruction covers two 128-B row segments (one 32x32 accumulator register).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
+#include <stddef.h>
 #include <type_traits>
 #include <utility>
 
@@ -611,6 +613,335 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_q_kernel(GemmTnGroup grp) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: every weight gradient of an encoder STACK in one balanced launch ("SK").
+//
+// The per-layer launches above cut M into splits so that (tiles x splits) fills the chip; every split writes its own
+// 256 x 256 f32 partial tile (atomics, or slabs + a reduce kernel): at the packed row counts of the text / visual stacks that
+// write-out was 66 MB per launch against 35 MB of result and a quarter of the launch time.  Here the caller keeps the
+// operands (dY, X) of ALL layers alive until the stack's backward pass is done and hands over the whole list (up to
+// MVPTR_TN_STACK_MAX problems that share M): T = sum of the problems' 256 x 256 output tiles, G workgroups (one per CU, each
+// keeps its CU).  Workgroup g sweeps ALL token rows of tile r * G + g in round r = 0 .. T / G - 1 (one contributor per tile:
+// nothing to combine), and the T mod G tiles that are left over are cut into G equal runs of 32-row steps (a run may span a
+// tile boundary), so every workgroup does the same number of steps: no wave quantisation, no idle tail, at most two
+// partial tiles per workgroup.  The next segment's first stages are requested before the finished tile is written out
+// (f32 atomics; the accumulators stay live meanwhile), so the write-out runs under the operand fill.  The workgroups of
+// an XCD take 32 consecutive tiles of a round — a compact block of one problem's (tn, tk) grid, longer dimension outside —
+// and start them at row 0 together: the dY / X panels they share come once from HBM and otherwise from the XCD's L2.
+// Main loop = gemm_tn_q_kernel's (4 waves of 128 x 128, rotated 32-row stages, hand-counted LDS-DMA ring).
+struct TnSkProb {      // 64 bytes
+  const __bf16* A;
+  const __bf16* B;
+  float* dW;
+  float* colsum;
+  int lda, ldb, ldw;   // elements
+  int N, K;
+  int tiles_n, tiles_k;
+  int tile_base;       // first linear tile index of this problem
+};
+struct TnSkArgs {
+  int count, tiles_total, M, pad_;
+  const int* rows_dev;
+  TnSkProb prob[MVPTR_TN_STACK_MAX];
+};
+static_assert(sizeof(TnSkProb) == 64, "TnSkProb layout");
+static_assert(sizeof(TnSkArgs) <= 4096, "kernel arguments must fit the kernarg segment");
+
+template <int STAGES>
+__global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
+  constexpr int TM_ = 32;
+  constexpr int SUB_B = TM_ * 256;
+  constexpr int STAGE_B = 4 * SUB_B;
+  constexpr int NI = 4, LPS = 8;
+  constexpr int TKW = 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int g = xcd_remap(blockIdx.x, G);
+  const int Mv = rows_clamped(args.M, args.rows_dev);
+  const int spt = (Mv + TM_ - 1) / TM_;     // 32-row steps of one tile's sweep
+  if (spt <= 0) return;
+  const int T = args.tiles_total;
+  const int R = T / G, rem = T - R * G;
+  // the problem table is read from the kernel-argument segment with scalar loads (a dynamically indexed by-value array
+  // would be copied to scratch and fetched on the vector path: every buffer descriptor would then need a waterfall loop)
+  typedef const __attribute__((address_space(4))) char* kchar_p;
+  typedef const __attribute__((address_space(4))) TnSkProb* kprob_p;
+  const kprob_p tab = (kprob_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TnSkArgs, prob));
+  const int count = args.count;
+  const uint32_t lds0 = lds_addr(lds);
+
+  const int wn = wave >> 1, wk = wave & 1;
+  const int gq = lane >> 4, i16 = lane & 15;
+  const int h = gq >> 1, cb = gq & 1;
+  const int q = i16 >> 2, pp = i16 & 3;
+  uint32_t ta[4][2], tb[4][2];
+#pragma unroll
+  for (int hl = 0; hl < 2; ++hl) {
+    const int row = 8 * h + 4 * hl + q;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ch = b * 4 + 2 * cb + (pp >> 1);
+      const uint32_t o = row * 256 + ((ch ^ swz256(row)) << 4) + 8 * (pp & 1);
+      ta[b][hl] = (uint32_t)wn * SUB_B + o;
+      tb[b][hl] = (uint32_t)(2 + wk) * SUB_B + o;
+    }
+  }
+
+  f32x16 acc[4][4];
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  auto read_frags = [&](const char* base, bf16x8(&fa)[4], bf16x8(&fb)[4]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fa[b] = tr_frag(base, ta[b][0], ta[b][1]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fb[b] = tr_frag(base, tb[b][0], tb[b][1]);
+  };
+  auto read_pair = [&](const char* base, int j, bf16x8(&fa)[4], bf16x8(&fb)[4]) {
+    if (j < 2) {
+      fb[2 * j] = tr_frag(base, tb[2 * j][0], tb[2 * j][1]);
+      fb[2 * j + 1] = tr_frag(base, tb[2 * j + 1][0], tb[2 * j + 1][1]);
+    } else {
+      fa[2 * j - 4] = tr_frag(base, ta[2 * j - 4][0], ta[2 * j - 4][1]);
+      fa[2 * j - 3] = tr_frag(base, ta[2 * j - 3][0], ta[2 * j - 3][1]);
+    }
+  };
+  auto mma_row = [&](int nb, const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto bias_tag) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nb], fb[kb], acc[nb][kb], 0, 0, 0);
+    if constexpr (decltype(bias_tag)::value) {
+      const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
+        bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
+      }
+    }
+  };
+
+  // tile t -> its problem (scalar scan of the table) and coordinates
+  auto decode = [&](int t, TnSkProb& p, int& tn, int& tk) {
+    int pi = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (int i = 1; i < count; ++i)
+      if (t >= tab[i].tile_base) pi = i;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    p.A = tab[pi].A;
+    p.B = tab[pi].B;
+    p.dW = tab[pi].dW;
+    p.colsum = tab[pi].colsum;
+    p.lda = tab[pi].lda;
+    p.ldb = tab[pi].ldb;
+    p.ldw = tab[pi].ldw;
+    p.N = tab[pi].N;
+    p.K = tab[pi].K;
+    p.tiles_n = tab[pi].tiles_n;
+    p.tiles_k = tab[pi].tiles_k;
+    p.tile_base = tab[pi].tile_base;
+    const int tl = t - p.tile_base;
+    if (p.tiles_n < p.tiles_k) {
+      tk = tl / p.tiles_n;
+      tn = tl - tk * p.tiles_n;
+    } else {
+      tn = tl / p.tiles_k;
+      tk = tl - tn * p.tiles_k;
+    }
+  };
+  // The finished segment whose accumulators still wait for their write-out (it goes out behind the next segment's first
+  // loads): only its tile index stays live across the loops, everything else is derived again from the table.
+  int pend_t = -1;
+  auto write_out = [&]() {
+    TnSkProb p;
+    int tn, tk;
+    decode(pend_t, p, tn, tk);
+    // f32 buffer atomics: ONE per-lane offset register (+ its column-masked copies), the row of every instruction is a
+    // scalar offset — no per-row address registers (the pointer form of gemm_tn_q_kernel needs 250 VGPRs for them).  One
+    // accumulator register = two 128-byte row segments per wave instruction.  Rows past N fall outside the descriptor,
+    // columns past K are masked per lane.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int l31 = lane_e & 31, hh = lane_e >> 5;
+    const int nrow0 = tn * TN_ + wn * 128, kcol0 = tk * TKW + wk * 128;
+    const int nleft = p.N - nrow0, kleft = p.K - kcol0;
+    const uint32_t bytes = (nleft > 0 && kleft > 0) ? (uint32_t)(((int64_t)(nleft - 1) * p.ldw + min(kleft, 128)) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc_uniform(p.dW + (int64_t)nrow0 * p.ldw + kcol0, bytes);
+    const uint32_t voff0 = (uint32_t)((4 * hh * p.ldw + l31) * 4);
+    uint32_t voff[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) voff[kb] = (kb * 32 + l31 < kleft) ? voff0 + (uint32_t)kb * 128u : MVPTR_OOB;
+    const int row_b = __builtin_amdgcn_readfirstlane(p.ldw * 4);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int soff = (nb * 32 + (r & 3) + 8 * (r >> 2)) * row_b;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[nb][kb][r], rs, voff[kb], soff, 0);
+        __builtin_amdgcn_sched_barrier(0);   // four accumulator reads at a time (hipcc otherwise copies all 256 to VGPRs first and spills)
+      }
+    if (p.colsum != nullptr && tk == 0 && wk == 0) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
+        const int n = nrow0 + nb * 32 + l31;
+        if (hh == 0 && n < p.N) atomicAdd(p.colsum + n, tot);
+      }
+    }
+  };
+
+  // remainder tiles: this workgroup's run of steps [b0, b1) of the (tile, step) list
+  long long b0 = 0, b1 = 0;
+  if (rem > 0) {
+    const long long tot = (long long)rem * spt;
+    b0 = tot * g / G;
+    b1 = tot * (g + 1) / G;
+  }
+  int it = 0;
+  // next segment of this workgroup: tile t, steps [s0, s1); false when there is none left
+  auto next_segment = [&](int& t, int& s0, int& s1) -> bool {
+    if (it < R) {
+      t = it * G + g;
+      s0 = 0;
+      s1 = spt;
+      ++it;
+    } else {
+      if (b0 >= b1) return false;
+      const int ti = (int)(b0 / spt);
+      s0 = (int)(b0 - (long long)ti * spt);
+      s1 = (int)min((long long)spt, (long long)s0 + (b1 - b0));
+      t = R * G + ti;
+      b0 += s1 - s0;
+    }
+    t = __builtin_amdgcn_readfirstlane(t);
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    s1 = __builtin_amdgcn_readfirstlane(s1);
+    return true;
+  };
+  // operand state of the CURRENT segment (set by begin_segment, used by the ring refills of its main loop)
+  u32x4 rsA, rsB;
+  uint32_t offA[NI], offB[NI];
+  uint32_t stepA = 0, stepB = 0;
+  int nsteps = 0;
+  bool do_bias = false;
+  auto stage_piece = [&](int buf, int st, int i) {
+    const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
+    if (i < NI) {
+      const uint32_t va = (offA[i] == MVPTR_OOB) ? MVPTR_OOB : offA[i] + (uint32_t)st * stepA;
+      lds_dma16(rsA, va, la + i * 4096);
+    } else {
+      const int j = i - NI;
+      const uint32_t vb = (offB[j] == MVPTR_OOB) ? MVPTR_OOB : offB[j] + (uint32_t)st * stepB;
+      lds_dma16(rsB, vb, la + 2 * SUB_B + j * 4096);
+    }
+  };
+  // descriptors and per-lane offsets of segment (t, s0, s1), then its first STAGES stages are requested (every wave has
+  // passed the barrier: the ring is free)
+  auto begin_segment = [&](int t, int s0, int s1) {
+    TnSkProb p;
+    int tn, tk;
+    decode(t, p, tn, tk);
+    const int n0 = tn * TN_, k0 = tk * TKW;
+    const int m_begin = s0 * TM_;
+    const int m_end = min(Mv, s1 * TM_);
+    const int rows = m_end - m_begin;
+    nsteps = s1 - s0;
+    const int ncols = min(TN_, p.N - n0);
+    const int kcols = min(TKW, p.K - k0);
+    const int ncols8 = min((ncols + 7) & ~7, p.lda - n0);
+    const int kcols8 = min((kcols + 7) & ~7, p.ldb - k0);
+    rsA = make_rsrc_words(p.A + (int64_t)m_begin * p.lda + n0, (uint32_t)(((int64_t)(rows - 1) * p.lda + ncols8) * 2));
+    rsB = make_rsrc_words(p.B + (int64_t)m_begin * p.ldb + k0, (uint32_t)(((int64_t)(rows - 1) * p.ldb + kcols8) * 2));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = i * 4 + wave;
+      const int row = (j & 7) * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ swz256(row);
+      const int col = (j >> 3) * 128 + ch * 8;
+      offA[i] = (col < ncols) ? (uint32_t)(row * p.lda * 2 + col * 2) : MVPTR_OOB;
+      offB[i] = (col < kcols) ? (uint32_t)(row * p.ldb * 2 + col * 2) : MVPTR_OOB;
+    }
+    stepA = (uint32_t)(TM_ * p.lda * 2);
+    stepB = (uint32_t)(TM_ * p.ldb * 2);
+    do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
+    // every wave is done with the previous segment's ring (its fragment reads were consumed by its last MFMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < STAGES; ++i)
+      if (i < nsteps) {
+#pragma unroll
+        for (int j = 0; j < 2 * NI; ++j) stage_piece(i, i, j);
+      }
+  };
+
+  int t, s0, s1;
+  if (!next_segment(t, s0, s1)) return;
+  begin_segment(t, s0, s1);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bsum[i] = 0.f;
+    // everything issued so far (this segment's first stages; before them the previous tile's atomics) has completed
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    read_frags(lds, fa0, fb0);
+    auto main_loop = [&](auto bias_tag) {
+      int buf = 0;
+      auto step = [&](int st, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* cur = lds + buf * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          read_pair(cur + 4096, j, fa1, fb1);
+          mma_row(j, fa0, fb0, bias_tag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        const bool more = STEADY || st + 1 < nsteps;
+        if (more) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 2) * LPS) : "memory");
+          } else {
+            const int younger = min(STAGES - 2, nsteps - 2 - st);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+        }
+        const char* nxt = lds + nbuf * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (STEADY) {
+            stage_piece(buf, st + STAGES, 2 * j);
+            stage_piece(buf, st + STAGES, 2 * j + 1);
+          }
+          if (more) read_pair(nxt, j, fa0, fb0);
+          mma_row(j, fa1, fb1, bias_tag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = nbuf;
+      };
+      int st = 0;
+      for (; st + STAGES < nsteps; ++st) step(st, std::true_type{});
+      for (; st < nsteps; ++st) step(st, std::false_type{});
+    };
+    if (do_bias) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    // the next segment's first stages are requested in front of this tile's write-out: the atomics run under the fill
+    pend_t = t;
+    const bool more_segments = next_segment(t, s0, s1);
+    if (more_segments) begin_segment(t, s0, s1);
+    write_out();
+    if (!more_segments) break;
+  }
+}
+
 // Sum of the M-splits' slabs of gemm_tn_q_kernel into dW (+=), splits in ascending order: the result does not depend
 // on the order in which workgroups finished (bitwise reproducible, unlike the atomic write-out).  One thread per
 // 16-byte slab position = four rows n..n+3 of one column k; a wave reads 1 KiB contiguous per split and updates
@@ -912,6 +1243,75 @@ extern "C" int64_t mvptr_gemm_tn_ws_bytes(const mvptr_tn_problem* probs, int cou
   int64_t need = 0;
   if (tn_multi(probs, count, nullptr, 0, &need, nullptr) != MVPTR_OK) return -1;
   return need;
+}
+
+// Every weight gradient of an encoder stack in one balanced launch (gemm_tn_sk_kernel).  All problems share M (and the
+// device-side row count, if any); lists longer than MVPTR_TN_STACK_MAX go out as several launches.
+extern "C" int mvptr_gemm_tn_stack(const mvptr_tn_problem* probs, int count, const int* rows_dev, int max_workgroups, void* stream) {
+  if (!probs || count <= 0) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_tn_stack: no problems");
+  for (int i = 0; i < count; ++i) {
+    const int rc = check_problem(probs[i]);
+    if (rc != MVPTR_OK) return rc;
+    if (probs[i].M != probs[0].M) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn_stack: the problems of a stack share M (%d vs %d)", probs[i].M, probs[0].M);
+    if (probs[i].lda >= (int64_t)0x7fffffff / 64 || probs[i].ldb >= (int64_t)0x7fffffff / 64 || probs[i].ldw >= (int64_t)0x7fffffff)
+      MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn_stack: leading dimension too large");
+  }
+  // a workgroup's sweep addresses its rows with 32-bit byte offsets from the segment's first row
+  {
+    int64_t ldmax = 8;
+    for (int i = 0; i < count; ++i) {
+      if (probs[i].lda > ldmax) ldmax = probs[i].lda;
+      if (probs[i].ldb > ldmax) ldmax = probs[i].ldb;
+    }
+    if ((int64_t)probs[0].M * ldmax * 2 >= (int64_t)0x7fffffff)
+      MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_tn_stack: M x leading dimension exceeds 2 GiB of operand bytes (use mvptr_gemm_tn_multi)");
+  }
+  int ncu = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  int G = (max_workgroups > 0 && max_workgroups < ncu) ? max_workgroups : ncu;
+  constexpr int STAGES = 4;
+  const int lds_b = STAGES * 4 * 32 * 256;
+  {   // per call: the attribute belongs to the current device's copy of the kernel
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_sk_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_tn_stack: set LDS size: %s", hipGetErrorString(e));
+  }
+  for (int first = 0; first < count; first += MVPTR_TN_STACK_MAX) {
+    const int n = (count - first < MVPTR_TN_STACK_MAX) ? count - first : MVPTR_TN_STACK_MAX;
+    TnSkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.count = n;
+    a.M = probs[0].M;
+    a.rows_dev = rows_dev;
+    int base = 0;
+    for (int i = 0; i < n; ++i) {
+      const mvptr_tn_problem& q = probs[first + i];
+      TnSkProb& t = a.prob[i];
+      t.A = (const __bf16*)q.A;
+      t.B = (const __bf16*)q.B;
+      t.dW = q.dW;
+      t.colsum = q.colsum;
+      t.lda = (int)q.lda;
+      t.ldb = (int)q.ldb;
+      t.ldw = (int)q.ldw;
+      t.N = q.N;
+      t.K = q.K;
+      t.tiles_n = (q.N + TN_ - 1) / TN_;
+      t.tiles_k = (q.K + 255) / 256;
+      t.tile_base = base;
+      base += t.tiles_n * t.tiles_k;
+    }
+    for (int i = n; i < MVPTR_TN_STACK_MAX; ++i) {
+      a.prob[i] = a.prob[0];
+      a.prob[i].tile_base = 0x7fffffff;
+    }
+    a.tiles_total = base;
+    hipLaunchKernelGGL((gemm_tn_sk_kernel<STAGES>), dim3(G), dim3(256), lds_b, (hipStream_t)stream, a);
+    MVPTR_CHECK_LAUNCH("gemm_tn_stack");
+  }
+  return MVPTR_OK;
 }
 
 extern "C" int mvptr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,

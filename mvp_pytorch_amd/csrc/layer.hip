@@ -150,10 +150,11 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
   return MVPTR_OK;
 }
 
-extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
-                                       const void* x, const float* mask_add, const void* saved,
-                                       const void* dy, void* dx, const mvptr_layer_grads* g,
-                                       void* ws, int64_t ws_bytes, void* stream) {
+namespace {
+// defer_out != NULL: no weight-gradient launches — the problems are appended to defer_out[0 .. *n_defer) instead
+int layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w, const void* x, const float* mask_add, const void* saved,
+              const void* dy, void* dx, const mvptr_layer_grads* g, void* ws, int64_t ws_bytes, mvptr_tn_problem* defer_out,
+              int* n_defer, void* stream) {
   RUN(check_desc("encoder_layer_bwd", d));
   if (!w || !x || !saved || !dy || !dx || !g || !ws || (!mask_add && d->M == 0))
     MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd: NULL argument");
@@ -183,9 +184,11 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
   // atomic write-out of one problem overlaps the MFMA loop of the next.
   mvptr_tn_problem wg[4];
   int nwg = 0;
+  const bool defer = defer_out != nullptr;
+  int ndef = 0;
   auto add_wgrad = [&](const void* dyp, int64_t lda, const void* xp, int64_t ldb, int N, int K, float* dw,
                        float* colsum) {
-    mvptr_tn_problem& q = wg[nwg++];
+    mvptr_tn_problem& q = defer ? defer_out[ndef++] : wg[nwg++];
     q.A = dyp;
     q.lda = lda;
     q.B = xp;
@@ -207,11 +210,14 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
                                   hdrop ? &dr_out : nullptr, lnws, lnws_bytes, rd, &pend2, stream));
   const char* d2 = hdrop ? bufB : bufA;
   if (g->w_out) add_wgrad(d2, H, s.a, I, H, I, g->w_out, nullptr);
+  // bias gradient of intermediate.dense = column sums of dU: in the GELU-backward epilogue, or — deferred — on the weight-gradient
+  // problem that reads dU anyway
+  const bool bi_rides = defer && g->w_i != nullptr;
   RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
-                         I, g->b_i, nullptr, rd, Mp, stream));
+                         I, bi_rides ? nullptr : g->b_i, nullptr, rd, Mp, stream));
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache
-  if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, nullptr);
+  if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, bi_rides ? g->b_i : nullptr);
   if (nwg > 0) RUN(mvptr_gemm_tn_multi_rows(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, rd, Mp, stream));
   nwg = 0;
   RUN(mvptr_gemm_nt_rows(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
@@ -244,5 +250,22 @@ extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_la
     wg[1] = t;
   }
   if (nwg > 0) RUN(mvptr_gemm_tn_multi_rows(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, rd, Mp, stream));
+  if (defer) *n_defer = ndef;
   return MVPTR_OK;
+}
+}  // namespace
+
+extern "C" int mvptr_encoder_layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                       const void* x, const float* mask_add, const void* saved,
+                                       const void* dy, void* dx, const mvptr_layer_grads* g,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+  return layer_bwd(d, w, x, mask_add, saved, dy, dx, g, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int mvptr_encoder_layer_bwd_defer(const mvptr_layer_desc* d, const mvptr_layer_weights* w,
+                                             const void* x, const float* mask_add, const void* saved,
+                                             const void* dy, void* dx, const mvptr_layer_grads* g,
+                                             void* ws, int64_t ws_bytes, mvptr_tn_problem* wgrads, int* n_wgrads, void* stream) {
+  if (!wgrads || !n_wgrads) MVPTR_FAIL(MVPTR_BAD_ARG, "encoder_layer_bwd_defer: wgrads / n_wgrads is NULL");
+  return layer_bwd(d, w, x, mask_add, saved, dy, dx, g, ws, ws_bytes, wgrads, n_wgrads, stream);
 }

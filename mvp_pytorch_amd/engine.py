@@ -161,6 +161,8 @@ def arange(n, device, dtype=torch.long, step=1, floor_div=1):
     matched / hard pairs (floor_div = n over 2 n entries) were a dozen tiny launches per step.  READ-ONLY for the callers
     (every use in this package indexes with it or feeds it to an out-of-place op)."""
     d = torch.device(device)
+    if int(floor_div) <= 0:
+        raise ValueError("engine.arange: floor_div must be positive (got %r)" % (floor_div,))
     key = (d.type, d.index if d.index is not None or d.type != "cuda" else torch.cuda.current_device(), int(n), dtype, int(step),
            int(floor_div))
     t = _ARANGES.get(key)
@@ -168,11 +170,17 @@ def arange(n, device, dtype=torch.long, step=1, floor_div=1):
         with _state_lock:
             t = _ARANGES.get(key)
             if t is None:
-                t = torch.arange(int(n), device=d, dtype=dtype)
-                if floor_div != 1:
-                    t = torch.div(t, int(floor_div), rounding_mode="floor")
-                if step != 1:
-                    t = t * step
+                # made outside inference mode (an entry first created under torch.inference_mode() could not be saved for
+                # backward by a later training step) and complete before any stream may read it: the tensor is created on
+                # whichever stream is current and then shared with the side stream
+                with torch.inference_mode(False), torch.no_grad():
+                    t = torch.arange(int(n), device=d, dtype=dtype)
+                    if floor_div != 1:
+                        t = torch.div(t, int(floor_div), rounding_mode="floor")
+                    if step != 1:
+                        t = t * step
+                if t.is_cuda:
+                    torch.cuda.current_stream(t.device).synchronize()     # once per entry and process
                 _ARANGES[key] = t
     return t
 
@@ -492,6 +500,16 @@ class EncoderMeta:
         # the bound the buffers are sized for and rows_plan the host-side planning hint (mvptr_layer_desc.rows_dev / M_plan)
         self.rows_dev, self.rows_plan = rows_dev, int(rows_plan)
         self.eps, self.training, self.p_hidden, self.p_attn = eps, training, p_hidden, p_attn
+        # weight gradients of the whole stack in ONE balanced launch at the end of its backward pass (mvptr_gemm_tn_stack)
+        # instead of two grouped launches per layer; False restores the per-layer launches
+        self.defer_wgrad = DEFER_WGRAD
+
+
+# Default of EncoderMeta.defer_wgrad (A/B switch: bench.py --wgrad-per-layer, tests).
+DEFER_WGRAD = True
+# CUs the stack-wide weight-gradient launch leaves free (0: it takes every CU).  Its workgroups keep their CU for the whole
+# launch (0.6 - 3 ms): dp.GradSync sets this in multi-rank RCCL jobs so that the collectives' kernels find a CU meanwhile.
+WGRAD_RESERVE_CUS = 0
 
 
 def _thresh(p):
@@ -635,7 +653,14 @@ class EncoderFn(GradAwareFunction):
         H, I = meta.H, meta.I
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         ws_bytes = lib.mvptr_layer_workspace_bytes(ctypes.byref(ctx.descs[0]))
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        # Deferred weight gradients: every layer keeps its dY operands in a workspace of its own and the whole stack's
+        # problems (4 per layer) go out as one balanced launch after the last layer (mvptr_gemm_tn_stack)
+        defer = bool(getattr(meta, "defer_wgrad", False)) and n >= 1
+        ws_step = (ws_bytes + 255) // 256 * 256
+        ws = torch.empty(ws_step * n if defer else ws_bytes, device=dev, dtype=torch.uint8)
+        probs = (hip.TnProblem * (4 * n))() if defer else None
+        n_probs = 0
+        delivered_later = []
         sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
         total = sum(sizes)
         grads = [None] * (16 * n)
@@ -661,10 +686,22 @@ class EncoderFn(GradAwareFunction):
                 o += sz
             (g.w_qkv, g.b_qkv, g.w_o, g.b_o, g.ln1_g, g.ln1_b, g.w_i, g.b_i, g.w_out, g.b_out, g.ln2_g, g.ln2_b) = offs
             dx = torch.empty_like(d_cur)
-            hip._check(lib.mvptr_encoder_layer_bwd(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
-                                                   hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
-                                                   hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream))
-            if direct:
+            if defer:
+                cnt = ctypes.c_int(0)
+                sub = ctypes.cast(ctypes.byref(probs, n_probs * ctypes.sizeof(hip.TnProblem)), ctypes.POINTER(hip.TnProblem))
+                hip._check(lib.mvptr_encoder_layer_bwd_defer(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
+                                                             hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
+                                                             hip._p(d_cur), hip._p(dx), ctypes.byref(g),
+                                                             ctypes.c_void_p(ws.data_ptr() + li * ws_step), ws_bytes, sub,
+                                                             ctypes.byref(cnt), stream))
+                n_probs += cnt.value
+            else:
+                hip._check(lib.mvptr_encoder_layer_bwd(ctypes.byref(ctx.descs[li]), ctypes.byref(meta.packs[li].w),
+                                                       hip._p(ctx.xs[li]), hip._p(ctx.mask), hip._p(ctx.stashes[li]),
+                                                       hip._p(d_cur), hip._p(dx), ctypes.byref(g), hip._p(ws), ws_bytes, stream))
+            if direct and defer:
+                delivered_later.extend(ps)     # complete only after the stack-wide launch below
+            elif direct:
                 for p in ps:
                     sink.delivered(p)
             else:
@@ -681,6 +718,13 @@ class EncoderFn(GradAwareFunction):
                     if p.requires_grad:
                         grads[16 * li + j] = gl[j] if p.dtype == torch.float32 else gl[j].to(p.dtype)
             d_cur = dx
+        if defer and n_probs > 0:
+            rd = meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            max_wg = max(8, ncu - WGRAD_RESERVE_CUS) if WGRAD_RESERVE_CUS > 0 else 0
+            hip._check(lib.mvptr_gemm_tn_stack(probs, n_probs, ctypes.c_void_p(rd) if rd else None, max_wg, stream))
+        for p in delivered_later:
+            sink.delivered(p)
         ctx.stashes = ctx.xs = None
         return (d_cur, None, None) + tuple(grads)
 

@@ -35,6 +35,7 @@ SYMBOLS = [
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
     "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
     "mvptr_masked_mean", "mvptr_dgelu_mul", "mvptr_compact_scored",
+    "mvptr_gemm_tn_stack", "mvptr_encoder_layer_bwd_defer",
 ]
 
 
@@ -157,6 +158,9 @@ def load():
     lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
     lib.mvptr_encoder_layer_bwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64, P]
+    lib.mvptr_encoder_layer_bwd_defer.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, POINTER(LayerGrads), P, I64,
+                                                  POINTER(TnProblem), POINTER(c_int), P]
+    lib.mvptr_gemm_tn_stack.argtypes = [POINTER(TnProblem), I, P, I, P]
     _lib = lib
     return lib
 
@@ -282,6 +286,19 @@ def gemm_tn_multi(problems, slab_workspace=True):
             _check(lib.mvptr_gemm_tn_multi_ws(arr, len(problems), _p(ws), need, _stream()))
             return
     _check(lib.mvptr_gemm_tn_multi(arr, len(problems), _stream()))
+
+
+def gemm_tn_stack(problems, rows_dev=None, max_workgroups=0):
+    """problems: list of (dy, x, dw, colsum-or-None) that share M; every weight gradient in ONE balanced launch
+    (mvptr_gemm_tn_stack).  rows_dev: device int32 tensor with the rows actually present (<= M), or None."""
+    arr = (TnProblem * len(problems))()
+    for q, (dy, x, dw, cs) in zip(arr, problems):
+        assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+        assert x.shape[0] == dy.shape[0] and dw.stride(1) == 1 and dw.shape == (dy.shape[1], x.shape[1])
+        q.A, q.lda, q.B, q.ldb = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        q.M, q.N, q.K = dy.shape[0], dy.shape[1], x.shape[1]
+        q.dW, q.ldw, q.colsum = dw.data_ptr(), dw.stride(0), (cs.data_ptr() if cs is not None else None)
+    _check(load().mvptr_gemm_tn_stack(arr, len(problems), _p(rows_dev), int(max_workgroups), _stream()))
 
 
 def colsum(x, out, n=None):

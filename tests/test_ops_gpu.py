@@ -254,6 +254,49 @@ def test_gemm_tn_slab_write_out_is_exact_and_reproducible(dev, M):
         assert _rel(cs_a, dy.float().sum(0)) < 1e-5 and _rel(cs_c, dy.float().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,layers,max_wg", [(700, 2, 0), (6400, 3, 0), (10917, 6, 0), (3001, 9, 0), (5000, 2, 40), (97, 1, 0)])
+def test_gemm_tn_stack(dev, M, layers, max_wg):
+    """One balanced launch for the weight gradients of a whole stack (mvptr_gemm_tn_stack): whole tiles per workgroup in
+    the full rounds, equal runs of 32-row steps over the left-over tiles.  Checked against f32 products: odd shapes (partial
+    tiles at the N / K edge), lists longer than MVPTR_TN_STACK_MAX (9 layers x 4 + 1 = 37 problems), accumulation into dW,
+    column sums, a workgroup cap, and a device-side row count."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(M + layers)
+    shapes = [(768, 3072, False), (3072, 768, True), (768, 768, False), (2304, 768, True)]
+    probs, refs = [], []
+    for li in range(layers):
+        for N, K, cs in shapes:
+            dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+            x = _bf(torch.randn(M, K, generator=g)).to(dev)
+            init = torch.randn(N, K, generator=g).to(dev)
+            probs.append((dy, x, init.clone(), torch.zeros(N, device=dev) if cs else None))
+            refs.append(init)
+    dy5 = torch.zeros(M, 528, dtype=torch.bfloat16)
+    dy5[:, :520] = _bf(torch.randn(M, 520, generator=g))
+    dy5 = dy5.to(dev)[:, :520]            # lda = 528: row padding behind the 520 columns
+    x5 = _bf(torch.randn(M, 1000, generator=g)).to(dev)
+    probs.append((dy5, x5, torch.zeros(520, 1000, device=dev), torch.zeros(520, device=dev)))
+    refs.append(torch.zeros(520, 1000, device=dev))
+    hip.gemm_tn_stack(probs, max_workgroups=max_wg)
+    for (dy, x, dw, cs), init in zip(probs, refs):
+        assert _rel(dw, init + dy.float().t() @ x.float()) < 1e-5
+        if cs is not None:
+            assert _rel(cs, dy.float().sum(0)) < 1e-5
+    # device-side row count: only the first Mv rows take part
+    Mv = max(1, M - 333)
+    rd = torch.tensor([Mv], device=dev, dtype=torch.int32)
+    probs2 = [(dy, x, torch.zeros_like(dw), torch.zeros_like(cs) if cs is not None else None) for dy, x, dw, cs in probs]
+    hip.gemm_tn_stack(probs2, rows_dev=rd, max_workgroups=max_wg)
+    for dy, x, dw, cs in probs2:
+        assert _rel(dw, dy[:Mv].float().t() @ x[:Mv].float()) < 1e-5
+        if cs is not None:
+            assert _rel(cs, dy[:Mv].float().sum(0)) < 1e-5
+    # problems of one call share M
+    bad = probs[:1] + [(dy5[:50], x5[:50], torch.zeros(520, 1000, device=dev), None)]
+    with pytest.raises(RuntimeError, match="share M"):
+        hip.gemm_tn_stack(bad)
+
+
 def test_gemm_tn_layout_exact(dev):
     from mvp_pytorch_amd import hip
     M, N, K = 64, 128, 128
