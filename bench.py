@@ -386,18 +386,29 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                                    traffic=(t_nt or {}).get("bytes_per_launch")))
 
 
+def _enc_flops(lens, cfg):
+    """Forward FLOPs of one half-depth encoder stack over sequences of the given valid lengths (SURVEY §8d per-token formula)."""
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    nl = cfg["num_hidden_layers"] // 2
+    lens = lens.double()
+    return float((nl * (lens * 2 * (4 * H * H + 2 * H * I) + 4 * lens * lens * H)).sum())
+
+
 def _secondary_legs(dev, steps):
-    """Driver-visible secondary workloads (VERDICT r03 #7; never `value`): BASELINE configs[3] — cached two-stage
-    retrieval re-ranking, README lengths 50 tok + 5 phrases / 30 tags / 50 regions, 1 000 captions x 200 images, top-64
-    re-ranked (the routine of tools/bench_rerank.py) — and configs[4] — one VQA fine-tune step (3129-way BCE head) at
-    the per-GPU batch 64 of "batch 512 over 8 GPUs", lengths 128 + 5 / 30 / 50.  Synthetic data, random-init weights."""
-    import golden_util as gu
-    from mvp_pytorch_amd import modeling, train
+    """Driver-visible secondary workloads (VERDICT r03 #7, r04 #8; never `value`): BASELINE configs[3] — cached two-stage
+    retrieval re-ranking at its COCO-5k shape, 1 000 images x 5 captions, README lengths 50 tok + 5 phrases / 30 tags / 50 regions,
+    the reference's candidate counts (run_retrieval.py:694-826: top-64 images per caption + top-128 captions per image =
+    448 000 pairs) — and configs[4] — one VQA fine-tune step (3129-way BCE head) at the per-GPU batch 64 of "batch 512 over
+    8 GPUs", lengths 128 + 5 / 30 / 50, with the fused global-norm clip of the pre-training step.  Each leg carries the
+    fraction of the bf16 MFMA peak its EXECUTED FLOPs amount to (valid slots only; the full-length figures of SURVEY §8d — 9.12
+    GFLOP per re-ranked pair, 107.3 GFLOP per question — are printed beside them).  Synthetic data, random-init weights."""
+    import golden_util as gu  # noqa: F401
+    from mvp_pytorch_amd import dp, modeling, train
     from mvp_pytorch_amd.synthetic import synthetic_batch
     out = {}
     try:
         torch.manual_seed(0)
-        n_img, caps, topk = 200, 5, 64
+        n_img, caps, topk_i, topk_t = 1000, 5, 64, 128
         dims = dict(B=n_img * caps, T=50, P=5, G=30, R=50)
         cfg = dict(BASE_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, loss_type="ce", num_labels=2)
         model = modeling.BiImageBertForRetrieval(modeling.make_config(cfg)).to(dev).eval()
@@ -413,8 +424,14 @@ def _secondary_legs(dev, steps):
                 for k in text:
                     text[k].append(t[k])
             text = {k: torch.cat(v) for k, v in text.items()}
-            image = model.encode_image(input_ids_b=b["input_ids_b"][rows], img_feats=b["img_feats"][rows], token_type_ids_b=b["segment_ids_b"][rows],
-                                       attention_mask_b=b["input_mask_b"][rows], max_tag_length=dims["G"])
+            image = {k: [] for k in ("seq", "mask", "glob")}
+            for s0 in range(0, n_img, 500):
+                r = rows[s0:s0 + 500]
+                im = model.encode_image(input_ids_b=b["input_ids_b"][r], img_feats=b["img_feats"][r], token_type_ids_b=b["segment_ids_b"][r],
+                                        attention_mask_b=b["input_mask_b"][r], max_tag_length=dims["G"])
+                for k in image:
+                    image[k].append(im[k])
+            image = {k: torch.cat(v) for k, v in image.items()}
             return text, image
 
         encode()
@@ -423,20 +440,29 @@ def _secondary_legs(dev, steps):
         text, image = encode()
         torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
-        cand = model.coarse_scores(text, image).topk(topk, dim=1).indices
-        ti, ii = torch.arange(n_txt, device=dev).repeat_interleave(topk), cand.reshape(-1)
+        sim = model.coarse_scores(text, image)                                   # [5000 captions, 1000 images]
+        cand_i = sim.topk(topk_i, dim=1).indices                                 # text -> image: 64 images per caption
+        cand_t = sim.t().topk(topk_t, dim=1).indices                             # image -> text: 128 captions per image
+        ti = torch.cat([torch.arange(n_txt, device=dev).repeat_interleave(topk_i), cand_t.reshape(-1)])
+        ii = torch.cat([cand_i.reshape(-1), torch.arange(n_img, device=dev).repeat_interleave(topk_t)])
         model.rerank(text, image, ti[:4096], ii[:4096])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         model.rerank(text, image, ti, ii, chunk=4096)
         torch.cuda.synchronize()
         t_rr = time.perf_counter() - t0
+        la = b["input_mask_a"].sum(1)
+        nr = b["input_mask_b"][rows][:, dims["G"]:].sum(1)
+        f_exec = _enc_flops(la[ti] + nr[ii], cfg)
+        f_full = _enc_flops(torch.full((1,), dims["T"] + dims["P"] + dims["R"]), cfg) * ti.numel()
         out["configs3_retrieval_rerank"] = {
             "pairs": int(ti.numel()), "rerank_pairs_per_s": round(ti.numel() / t_rr, 1), "encode_once_s": round(t_enc, 4),
             "end_to_end_pairs_per_s": round(ti.numel() / (t_rr + t_enc), 1),
-            "workload": "BiImageBertForRetrieval BERT-base eval, 1000 captions x 200 images (55 / 80 slots), coarse top-64 -> 64000 pairs "
-                        "re-ranked from cached uni-modal outputs (row-packed)"}
-        del model, text, image
+            "step_frac": round(f_exec / t_rr / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "gflop_per_pair_executed": round(f_exec / ti.numel() / 1e9, 2),
+            "gflop_per_pair_full_length": round(f_full / ti.numel() / 1e9, 2),
+            "workload": "BiImageBertForRetrieval BERT-base eval, configs[3]: 1000 images x 5 captions (55 / 80 slots), coarse top-64 images per caption "
+                        "+ top-128 captions per image = 448000 pairs re-ranked from cached uni-modal outputs (row-packed; forward only)"}
+        del model, text, image, sim
     except Exception as e:   # a secondary leg never takes the headline down
         out["configs3_retrieval_rerank"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:
@@ -445,6 +471,7 @@ def _secondary_legs(dev, steps):
         cfg = dict(BASE_CFG, loss_type="bce", num_labels=3129)
         model = modeling.BiImageBertForVQA(modeling.make_config(cfg)).to(dev).train()
         opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.05, t_total=100000)
+        sync = dp.GradSync(model)          # gradient arena: the fused global-norm clip + AdamW of the pre-training step
         b = synthetic_batch(dims, cfg, 8, device=dev)
         g = torch.Generator().manual_seed(2)
         labels = ((torch.rand(dims["B"], 3129, generator=g) < 0.002).float() * torch.rand(dims["B"], 3129, generator=g)).to(dev)
@@ -454,10 +481,14 @@ def _secondary_legs(dev, steps):
         def vqa_step():
             loss = model(labels=labels, **kw)[0]
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)      # run_vqa.py max_grad_norm
-            opt.step()
+            sync()
+            coef = train.clip_coefficient(model, sync, 1.0)      # run_vqa.py max_grad_norm (line 667), fused into the update
+            if coef is not None:
+                opt.step(grad_scale=coef)
+            else:
+                opt.step()
             sched.step()
-            opt.zero_grad(set_to_none=True)
+            sync.zero_grad()
             return loss
 
         for _ in range(3):
@@ -468,10 +499,22 @@ def _secondary_legs(dev, steps):
             loss = vqa_step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        la, lb = b["input_mask_a"].sum(1), b["input_mask_b"].sum(1)
+        nr20 = b["input_mask_b"][:, 20:].sum(1)      # the VQA script never forwards max_tag_length: the visual slice starts at 20
+        head = 2 * cfg["hidden_size"] * cfg["hidden_size"] + 2 * cfg["hidden_size"] * 3129
+        f_exec = 3 * (_enc_flops(la, cfg) + _enc_flops(lb, cfg) + _enc_flops(la + nr20, cfg) + float(nr20.sum()) * 0 +
+                      float(b["input_mask_b"][:, dims["G"]:].sum()) * 2 * cfg["img_feature_dim"] * cfg["hidden_size"] + dims["B"] * head)
+        one = torch.ones(1)
+        f_full = 3 * (_enc_flops(one * (dims["T"] + dims["P"]), cfg) + _enc_flops(one * (dims["G"] + dims["R"]), cfg) +
+                      _enc_flops(one * (dims["T"] + dims["P"] + dims["G"] + dims["R"] - 20), cfg) +
+                      dims["R"] * 2 * cfg["img_feature_dim"] * cfg["hidden_size"] + head)
         out["configs4_vqa_step"] = {"ms_per_step": round(ms, 2), "questions_per_s": round(dims["B"] / (ms * 1e-3), 1), "steps": steps,
                                     "final_loss": round(float(loss.item()), 4),
-                                    "workload": "BiImageBertForVQA BERT-base train step (fwd + bwd + clip + AdamW), 64 questions/GPU, 128 tok + 5 phrases / "
-                                                "30 tags / 50 regions, 3129-way BCE head, dropout 0.1"}
+                                    "step_frac": round(f_exec / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                    "gflop_per_question_executed": round(f_exec / dims["B"] / 1e9, 1), "gflop_per_question_full_length": round(f_full / 1e9, 1),
+                                    "workload": "BiImageBertForVQA BERT-base train step (fwd + bwd + fused global-norm clip 1.0 + AdamW), 64 questions/GPU, "
+                                                "128 tok + 5 phrases / 30 tags / 50 regions, 3129-way BCE head, dropout 0.1"}
+        sync.close()
     except Exception as e:
         out["configs4_vqa_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
@@ -576,8 +619,11 @@ def main():
     ap.add_argument("--no-dp-optins-leg", action="store_true", help="N > 1: skip the second timed leg with the data-parallel opt-ins")
     ap.add_argument("--model", choices=["bi", "single"], default="bi",
                     help="bi = BiBertImgForPreTraining (what run_pretrain_ml.py trains); single = BertImgForPreTraining")
-    ap.add_argument("--dp-bf16-wire", action="store_true", help="N > 1: gradients rounded to bf16 for the all-reduce (default f32)")
-    ap.add_argument("--dp-sparse-rows", action="store_true", help="N > 1: word-table gradient exchanged by looked-up rows (default dense)")
+    ap.add_argument("--dp-bf16-wire", action="store_true", help=argparse.SUPPRESS)      # the default since round 5 (accepted, no effect)
+    ap.add_argument("--dp-sparse-rows", action="store_true", help=argparse.SUPPRESS)    # the default since round 5 (accepted, no effect)
+    ap.add_argument("--dp-f32-wire", action="store_true", help="N > 1: f32 gradients on the wire (default since round 5: bf16)")
+    ap.add_argument("--dp-dense-rows", action="store_true", help="N > 1: dense exchange of the word-table gradient (default since round 5: looked-up rows)")
+    ap.add_argument("--dp-rs-ag", action="store_true", help="N > 1 over RCCL: reduce-scatter + all-gather per bucket instead of all-reduce")
     ap.add_argument("--dp-two-streams", action="store_true", help="N > 1: text / visual stacks on two HIP streams whatever the backend (the default over RCCL since round 4; gloo jobs run one stream)")
     ap.add_argument("--dp-one-stream", action="store_true", help="N > 1: the round-3 policy — multi-rank jobs on one compute stream (A/B)")
     ap.add_argument("--one-stream", action="store_true", help="A/B at N = 1: everything on one HIP stream (what gloo jobs and --dp-one-stream run)")
@@ -654,14 +700,17 @@ def main():
         model.return_prediction_scores = False
     opt, sched = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000)
     # Gradient arena at every world size (the kernels accumulate weight gradients straight into the flat
-    # buckets that are all-reduced when N > 1).  Defaults for N > 1: f32 wire, dense exchange, the compute
-    # schedule of N = 1 (two streams over RCCL; one over gloo); --dp-bf16-wire / --dp-sparse-rows opt in (bi model: the MLM decoders are
-    # clones of the first 30 522 embedding rows, not tied, so the word table's gradient holds the looked-up
-    # rows only, dp.GradSync.note_rows).
-    sparse = [model.bert.embeddings.word_embeddings.weight] if (args.dp_sparse_rows and not single) else []
+    # buckets that are all-reduced when N > 1).  Defaults for N > 1 since round 5 (dp.default_exchange, covered as the
+    # default by tests/test_dp_gpu.py): bf16 wire + row-sparse word table for the two-stage model (its MLM decoders are clones of
+    # the first 30 522 embedding rows, not tied, so the word table's gradient holds the looked-up rows only), the compute
+    # schedule of N = 1 (two streams over RCCL; one over gloo); --dp-f32-wire / --dp-dense-rows opt out.
+    dflt = dp.default_exchange(model)
+    wire = torch.float32 if args.dp_f32_wire else dflt["comm_dtype"]
+    sparse = [] if args.dp_dense_rows else dflt["sparse_rows"]
+    coll = "rs_ag" if args.dp_rs_ag else "all_reduce"
     sync = None
     if world > 1 or not args.no_arena:
-        sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
+        sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=wire, collective=coll)
 
     def make_batch(fixed):
         b = synthetic_batch(dims, cfg, 1234 + rank, single_stream=single, fixed_length=fixed, device=dev)
@@ -708,33 +757,38 @@ def main():
         dist.all_reduce(ones)
         dp_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(),
                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
-                   "defaults": {"wire": "bf16" if args.dp_bf16_wire else "f32", "sparse_word_table": bool(args.dp_sparse_rows),
-                                "two_streams": bool(not single and model.bert.parallel_stacks and _streams_allowed(model.bert.parallel_stacks))},
+                   "defaults": {"wire": "bf16" if wire == torch.bfloat16 else "f32", "sparse_word_table": bool(sparse),
+                                "two_streams": bool(not single and model.bert.parallel_stacks and _streams_allowed(model.bert.parallel_stacks)),
+                                "collective": coll},
                    "hot_buckets": sync.n_hot, "buckets": len(sync.buckets), "stalled_steps": sync.stalled_steps}
         # exposed communication = the headline step minus the same step without any collective (replicas diverge from here
-        # on: timing only, nothing after this reads the weights' values).  Measured before the opt-in leg: it needs no
+        # on: timing only, nothing after this reads the weights' values).  Measured before the other legs: it needs no
         # collective, so it cannot be lost to one.
         sync.exchange = False
         noex_ms, _ = timed(batch, 2, args.steps)
         sync.exchange = True
         dp_info["exposed_comm_ms"] = round(ms_per_step - noex_ms, 2)
         dp_info["ms_per_step_without_exchange"] = round(noex_ms, 2)
-        if not args.no_dp_optins_leg and not single and not (args.dp_bf16_wire and args.dp_sparse_rows):
-            keep_ps = model.bert.parallel_stacks
+        if not args.no_dp_optins_leg and not single:
+            # further timed legs, same fences and step count: the conservative exchange (f32 wire, dense word table — the
+            # default of rounds 3-4) and, over RCCL, reduce-scatter + all-gather per bucket instead of all-reduce
+            legs = [("dp_conservative", dict(comm_dtype=torch.float32, sparse_rows=[], collective="all_reduce"),
+                     "f32 wire + dense word-table exchange (the default of rounds 3-4)")]
+            if dist.get_backend() == "nccl" and coll != "rs_ag":
+                legs.append(("dp_rs_ag", dict(comm_dtype=wire, sparse_rows=sparse, collective="rs_ag"),
+                             "the headline's options with reduce-scatter + all-gather per bucket"))
+            for key, kw, what in legs:
+                try:
+                    sync.close()
+                    sync = dp.GradSync(model, **kw)
+                    leg_ms, _ = timed(batch, 3, args.steps)
+                    dp_info[key] = {"ms_per_step": round(leg_ms, 2), "value": round(world * args.batch / (leg_ms * 1e-3), 1), "steps": args.steps,
+                                    "options": what, "stalled_steps": sync.stalled_steps}
+                except Exception as e:      # a leg that fails on its first multi-GPU run must not cost the headline its line
+                    dp_info[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             try:
                 sync.close()
-                model.bert.parallel_stacks = "always"
-                sync = dp.GradSync(model, sparse_rows=[model.bert.embeddings.word_embeddings.weight], comm_dtype=torch.bfloat16)
-                opt_ms, _ = timed(batch, 3, args.steps)
-                dp_info["dp_optins"] = {"ms_per_step": round(opt_ms, 2), "value": round(world * args.batch / (opt_ms * 1e-3), 1), "steps": args.steps,
-                                        "options": "bf16 wire + row-sparse word-table exchange + two compute streams", "stalled_steps": sync.stalled_steps}
-            except Exception as e:      # an opt-in that fails on its first multi-GPU run must not cost the headline its line
-                dp_info["dp_optins"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-            finally:
-                model.bert.parallel_stacks = keep_ps
-            try:
-                sync.close()
-                sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=torch.bfloat16 if args.dp_bf16_wire else torch.float32)
+                sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=wire, collective=coll)
             except Exception as e:
                 dp_info["restore_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 

@@ -52,7 +52,10 @@ typedef enum {
   MVPTR_EPI_GELU_BWD = 3,    /* out0(bf16) = acc * g, g decoded from aux(u8) = the saved q(gelu_erf'(u)) ; colsum -> vec_out f32 */
   MVPTR_EPI_ADD = 4,         /* out0(bf16) = acc + aux(bf16)  (aux may be NULL)           */
   MVPTR_EPI_F32 = 5,         /* out0(f32)  = acc + bias                                   */
-  MVPTR_EPI_BIAS_TANH = 6    /* out0(bf16) = tanh(acc + bias)                             */
+  MVPTR_EPI_BIAS_TANH = 6,   /* out0(bf16) = tanh(acc + bias)                             */
+  /* ABI 5: the gelu' stash in bf16 (the format of rounds 1-3) for reference-numerics runs and A/B runs of the 8-bit stash */
+  MVPTR_EPI_BIAS_GELU_BF16 = 7, /* as BIAS_GELU, out0(bf16) = gelu_erf'(u)                */
+  MVPTR_EPI_GELU_BWD_BF16 = 8   /* as GELU_BWD, g = aux(bf16)                             */
 } mvptr_epilogue;
 
 /* Dropout descriptor.  One 32-bit hash serves the element pair (2j, 2j+1):
@@ -369,8 +372,8 @@ int mvptr_ce_mean_small(const float* logits, int64_t ld, const int64_t* labels, 
  * mvptr_dgelu_mul: out[m, n] = bf16(dy[m, n] * gelu'(u)[m, n]) for n < N, 0 for N <= n < Npad, gelu' decoded from the 8-bit
  * stash of MVPTR_EPI_BIAS_GELU (the GELU backward of a head transform, modeling_bert.py:142-148 under autograd). */
 int mvptr_masked_mean(const float* loss_row, const int64_t* labels, int M, float* out, void* stream);
-int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, void* out, int64_t ld_o, int M, int N, int Npad,
-                    void* stream);
+int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, int stash_bf16, void* out, int64_t ld_o, int M, int N,
+                    int Npad, void* stream);
 
 /* g = y / max(||y||_2, eps) per row, inv_norm[r] = 1 / max(||y||, eps): F.normalize(p=2, dim=-1) of
  * oscar/modeling/modeling_vlbert.py:525-526; backward dy = (dg - g (g . dg)) * inv_norm. */
@@ -440,8 +443,9 @@ int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, int64_t ld_d
 
 /* Scored rows of a masked-LM head in one launch: the slots (b, l) of labels[B, L] with label > -1, ascending, as
  * out_labels[k] = the label and out_rows[k] = pos[b * ld_pos + l] (int32 row map of the packed buffer; NULL: the flat slot
- * index).  Exactly n_out entries are written (surplus cut, shortfall padded with label -1 / row -1).  Replaces the
- * masked_select chains of oscar/modeling/modeling_vlbert.py:1231-1234,1245. */
+ * index).  Exactly n_out entries are written: a shortfall is padded with label -1 / row -1 (ignored by the loss); MORE
+ * scored slots than n_out is a caller bug that would silently drop rows from the loss — the kernel prints the two counts and
+ * traps (the process aborts; ABI 5).  Replaces the masked_select chains of oscar/modeling/modeling_vlbert.py:1231-1234,1245. */
 int mvptr_compact_scored(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L, int n_out,
                          int64_t* out_labels, int32_t* out_rows, void* stream);
 
@@ -539,6 +543,10 @@ typedef struct {
   const int* seq_start;
   const int* seq_len;
   const int* rows_dev;
+  /* ABI 5: 0 = gelu'(u) stashed as 8-bit fixed point (1 B per element, |error| <= 0.0025: the default), 1 = as bf16 (2 B per
+   * element: the stash of rounds 1-3) — must be the same in the forward and the backward call of a layer */
+  int stash_bf16;
+  int pad_;
 } mvptr_layer_desc;
 
 typedef struct {

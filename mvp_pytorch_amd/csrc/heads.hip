@@ -409,6 +409,7 @@ __global__ __launch_bounds__(1024) void masked_mean_kernel(const float* loss_row
     out[1] = n;
   }
 }
+template <bool BF16>
 __global__ __launch_bounds__(256) void dgelu_mul_kernel(const __bf16* dy, int64_t ld_dy, const uint8_t* stash, int64_t ld_s, __bf16* out,
                                                          int64_t ld_o, int M, int N, int Npad) {
   const int quads = Npad >> 2;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void dgelu_mul_kernel(const __bf16* dy, int64_
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (n + k < N) {
-        const float g = dgelu_decode1(stash[(int64_t)m * ld_s + n + k]);
+        const float g = BF16 ? bf2f(reinterpret_cast<const __bf16*>(stash)[(int64_t)m * ld_s + n + k]) : dgelu_decode1(stash[(int64_t)m * ld_s + n + k]);
         o[k] = f2bf(bf2f(dy[(int64_t)m * ld_dy + n + k]) * g);
       }
     *reinterpret_cast<bf16x4*>(out + (int64_t)m * ld_o + n) = o;
@@ -434,16 +435,20 @@ extern "C" int mvptr_masked_mean(const float* loss_row, const int64_t* labels, i
   return MVPTR_OK;
 }
 
-extern "C" int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, void* out, int64_t ld_o, int M, int N,
-                               int Npad, void* stream) {
+extern "C" int mvptr_dgelu_mul(const void* dy, int64_t ld_dy, const void* stash, int64_t ld_s, int stash_bf16, void* out, int64_t ld_o, int M,
+                               int N, int Npad, void* stream) {
   if (M <= 0 || N <= 0 || Npad < N || (Npad & 3) || ld_dy < N || ld_s < N || ld_o < Npad || (ld_o & 3) || !dy || !stash || !out ||
       ((uintptr_t)out & 7))
     MVPTR_FAIL(MVPTR_BAD_ARG, "dgelu_mul: bad shape / alignment (Npad %% 4 == 0, ld_o >= Npad, out 8-byte aligned)");
   const int64_t total = (int64_t)M * (Npad >> 2);
   int grid = (int)((total + 255) / 256);
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(dgelu_mul_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, ld_dy, (const uint8_t*)stash, ld_s,
-                     (__bf16*)out, ld_o, M, N, Npad);
+  if (stash_bf16)
+    hipLaunchKernelGGL(dgelu_mul_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, ld_dy, (const uint8_t*)stash,
+                       ld_s, (__bf16*)out, ld_o, M, N, Npad);
+  else
+    hipLaunchKernelGGL(dgelu_mul_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, ld_dy, (const uint8_t*)stash,
+                       ld_s, (__bf16*)out, ld_o, M, N, Npad);
   MVPTR_CHECK_LAUNCH("dgelu_mul");
   return MVPTR_OK;
 }

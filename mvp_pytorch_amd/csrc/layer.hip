@@ -30,7 +30,7 @@ Stash carve(const mvptr_layer_desc* d, void* base) {
   s.ctx = take(M * H * 2);
   s.z1 = take(M * H * 2);
   s.x1 = take(M * H * 2);
-  s.u = take(M * I);          // gelu'(u), 8-bit fixed point (common.h, dgelu_pack4)
+  s.u = take(M * I * (d->stash_bf16 ? 2 : 1));   // gelu'(u): 8-bit fixed point (common.h, dgelu_pack4) or bf16 (desc.stash_bf16)
   s.a = take(M * I * 2);
   s.z2 = take(M * H * 2);
   s.lse = (float*)take((int64_t)d->B * d->heads * d->L * 4);
@@ -141,7 +141,7 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
                          H, nullptr, &dr_o, rd, Mp, stream));
   RUN(mvptr_layernorm_fwd_rows(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
                                nullptr, rd, stream));
-  RUN(mvptr_gemm_nt_rows(s.x1, H, w->w_i, H, M, I, H, MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
+  RUN(mvptr_gemm_nt_rows(s.x1, H, w->w_i, H, M, I, H, d->stash_bf16 ? MVPTR_EPI_BIAS_GELU_BF16 : MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
                          nullptr, nullptr, rd, Mp, stream));
   RUN(mvptr_gemm_nt_rows(s.a, I, w->w_out, I, M, H, I, MVPTR_EPI_BIAS_RESID, w->b_out, s.x1, H, s.z2,
                          nullptr, H, nullptr, &dr_out, rd, Mp, stream));
@@ -213,7 +213,7 @@ int layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w, const voi
   // bias gradient of intermediate.dense = column sums of dU: in the GELU-backward epilogue, or — deferred — on the weight-gradient
   // problem that reads dU anyway
   const bool bi_rides = defer && g->w_i != nullptr;
-  RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
+  RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, d->stash_bf16 ? MVPTR_EPI_GELU_BWD_BF16 : MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
                          I, bi_rides ? nullptr : g->b_i, nullptr, rd, Mp, stream));
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache

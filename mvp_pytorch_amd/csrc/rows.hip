@@ -370,6 +370,12 @@ __global__ __launch_bounds__(1024) void compact_scored_kernel(const int64_t* lab
   }
   int k = scan[tid] - c;
   const int found = scan[1023];
+  if (found > n_out) {
+    // fewer output slots than scored rows: the surplus would silently drop out of the loss (a stale or wrong scored-row count
+    // in host_counts).  More slots than rows is harmless (padded with -1 = ignored) and stays legal.
+    if (tid == 0) printf("mvptr_compact_scored: %d scored rows but only %d output slots (host_counts.scored_* does not describe this batch)\n", found, n_out);
+    __builtin_trap();
+  }
   for (int e = e0; e < e1; ++e) {
     const int64_t lab = labels[e];
     if (lab > -1) {

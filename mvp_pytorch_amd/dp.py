@@ -34,11 +34,13 @@ Design
     predecessors, as DDP does): which hot parameters receive a gradient in a given step can differ
     between ranks (a shard without a masked tag row skips half_mlm), and collectives on one
     communicator must be issued in the same order everywhere; finish() launches whatever is left;
-  * wire format: f32 by default.  `comm_dtype=torch.bfloat16` is an opt-in: each bucket is rounded to
-    bf16 for the wire and the averaged result converted back into the f32 bucket — half the xGMI bytes
-    (0.49 instead of 0.98 GB per step for BiBertImgForPreTraining) at 8 mantissa bits per summand (the
-    reference exchanged fp16 under DeepSpeed);
-  * ROW-SPARSE parameters (`sparse_rows=[...]`, opt-in; the 86 051 x 768 word-embedding table whose
+  * wire format: `comm_dtype=torch.bfloat16` — each bucket is rounded to bf16 for the wire and the
+    averaged result converted back into the f32 bucket: half the xGMI bytes (0.49 instead of 0.98 GB
+    per step for BiBertImgForPreTraining) at 8 mantissa bits per summand (the reference exchanged fp16
+    under DeepSpeed) — is the default of the two-stage models since round 5 (default_exchange); f32 for
+    everything else and on request;
+  * ROW-SPARSE parameters (`sparse_rows=[...]`; default for the two-stage models' untied word table
+    since round 5; the 86 051 x 768 word-embedding table whose
     f32 gradient is 264 MB and is produced LAST, so it cannot overlap the backward pass): each gets a
     bucket of its own; when the step has told the exchange which rows were looked up
     (note_rows(param, ids): token, phrase and tag ids of the rank's shard), the ranks all-gather their
@@ -53,6 +55,15 @@ Design
   * one backward per zero_grad(), or gradient accumulation inside `with sync.no_sync():` for all but
     the last backward — a second backward outside no_sync() would add into buckets that are already
     being reduced and raises.
+  * GLOBAL-NORM CLIP THAT SURVIVES THE OVERLAP (round 5): the recipe clips the global gradient norm
+    (oscar/tmp_config.json, run_pretrain_ml.py:639-640), and the coefficient needs every bucket.  Buckets
+    start on multiples of NORM_CHUNK elements, so the norm's per-chunk partial sums of squares of ONE
+    bucket occupy a fixed run of slots: finish(want_norm=True) queues a bucket's partial sums right
+    behind that bucket's collective (while the later buckets are still on the wire), and after the last
+    one only the one-workgroup coefficient kernel and AdamW remain (`clip_coef`).  Same slots, same
+    values, same summation order as the pass over the whole arena: bit-identical norm;
+  * `collective="rs_ag"` (opt-in, RCCL only): every dense bucket goes out as reduce-scatter +
+    all-gather over its chunk-padded span (SURVEY 8e) instead of one all-reduce; bench.py times both;
 `force_collectives=True` runs the whole exchange (hooks, bucket launches, wire conversion, row union,
 used-parameter bitmap) on a process group of ONE rank: the RCCL code path on a single GPU
 (tests/test_dp_gpu.py).
@@ -67,6 +78,8 @@ import torch.distributed as dist
 
 from . import engine
 
+
+NORM_CHUNK = 16384       # elements per partial sum of the gradient-norm pass (SUMSQ_BLOCK_ELEMS, csrc/optim.hip)
 
 _CONTROL_GROUPS = {}     # data group -> host-side (gloo) group of the same ranks, made once per process
 
@@ -87,10 +100,34 @@ def _control_group(group):
     return _CONTROL_GROUPS[group]
 
 
+def default_exchange(model):
+    """Exchange options a GradSync takes when none are given (round 5).  The two-stage pre-training / fine-tuning models
+    (a `bert.embeddings.word_embeddings` table that no other module shares: their MLM decoders are CLONES of its first
+    30 522 rows, modeling_utils.py:279-282) exchange bf16 on the wire (the reference exchanged fp16 under DeepSpeed,
+    oscar/tmp_config.json:3-9) and the word table by looked-up rows (264 MB of f32 produced last otherwise: it cannot overlap
+    the backward pass) — covered as the default by tests/test_dp_gpu.py::test_two_rank_training_step_keeps_replicas_identical.
+    Anything else (tied tables, plain modules): f32 wire, dense exchange."""
+    emb = getattr(getattr(getattr(model, "bert", None), "embeddings", None), "word_embeddings", None)
+    w = getattr(emb, "weight", None)
+    if w is not None and w.requires_grad and w.dim() == 2:
+        owners = sum(1 for m in model.modules() for q in m._parameters.values() if q is w)
+        if owners == 1:
+            return dict(comm_dtype=torch.bfloat16, sparse_rows=[w])
+    return dict(comm_dtype=torch.float32, sparse_rows=[])
+
+
 class GradSync:
-    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype=torch.float32, sparse_rows=(),
-                 force_collectives=False, demote_after=8, check_mixed_use=False):
+    def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="default", sparse_rows="default",
+                 force_collectives=False, demote_after=8, check_mixed_use=False, collective="all_reduce"):
         self.check_mixed_use = check_mixed_use
+        dflt = default_exchange(model)
+        if isinstance(comm_dtype, str) and comm_dtype == "default":
+            comm_dtype = dflt["comm_dtype"]
+        if isinstance(sparse_rows, str) and sparse_rows == "default":
+            sparse_rows = dflt["sparse_rows"]
+        if collective not in ("all_reduce", "rs_ag"):
+            raise ValueError("GradSync: collective must be 'all_reduce' or 'rs_ag'")
+        self.collective = collective
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if force_collectives and not dist.is_initialized():
@@ -109,6 +146,10 @@ class GradSync:
         self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
+        if collective == "rs_ag" and self.world > 1 and backend != "nccl":
+            raise ValueError("GradSync(collective='rs_ag') needs the RCCL backend (gloo has no reduce_scatter_tensor)")
+        if collective == "rs_ag" and (self.world & (self.world - 1)):
+            raise ValueError("GradSync(collective='rs_ag'): the chunk-padded bucket spans divide evenly over power-of-two world sizes only")
         self._ctl = _control_group(process_group) if self.exchange else None      # host-side exchange of the used-parameter bitmap
         self.comm_dtype = torch.float32 if comm_dtype in (None, "auto") else comm_dtype
         self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
@@ -132,6 +173,10 @@ class GradSync:
         self._build()
         self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         engine.set_grad_sink(self)
+        if self.world > 1 and backend == "nccl" and engine.WGRAD_RESERVE_CUS == 0:
+            # the stack-wide weight-gradient launch (engine.EncoderFn) keeps every CU it gets for 0.6 - 3 ms: leave a few to
+            # the collectives' kernels so that buckets already on the wire keep moving meanwhile
+            engine.WGRAD_RESERVE_CUS = 16
         self.zero_grad()
 
     def close(self):
@@ -184,12 +229,12 @@ class GradSync:
             if cur:
                 self._close(cur, cur_n, hot)
         self.n_hot = sum(1 for b in self.buckets if b["hot"])
-        # one allocation for all buckets (each starting on a 512-byte boundary): zero_grad() is one fill, the norm of
-        # the clip one pass
+        # one allocation for all buckets, each starting on a multiple of NORM_CHUNK elements (64 KiB): zero_grad() is one
+        # fill, and the chunks of the gradient-norm pass never straddle two buckets (per-bucket partial sums, clip_coef)
         total = 0
         for b in self.buckets:
             b["base"] = total
-            total += (b["n"] + 127) & ~127
+            total += (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK * NORM_CHUNK
         dev = self.params[0].device if self.params else torch.device("cpu")
         self._arena = torch.zeros(total, device=dev, dtype=torch.float32)
         for idx, b in enumerate(self.buckets):
@@ -206,6 +251,55 @@ class GradSync:
         """The flat f32 gradient buffers (global-norm clipping reads these instead of ~400 tensors): the whole arena
         as one buffer (the alignment gaps between buckets stay zero)."""
         return [self._arena]
+
+    # ------------------------------------------------------------------ global gradient norm
+    def _norm_scratch(self):
+        n = self._arena.numel() // NORM_CHUNK
+        sc = getattr(self, "_norm_buf", None)
+        if sc is None or sc.numel() != n + 2 or sc.device != self._arena.device:
+            sc = self._norm_buf = torch.zeros(n + 2, device=self._arena.device, dtype=torch.float32)
+        return sc
+
+    def _sumsq_span(self, first_chunk, n_chunks):
+        """Partial sums of squares of arena chunks [first_chunk, +n_chunks) into their slots (written, not accumulated)."""
+        if n_chunks <= 0:
+            return
+        sc = self._norm_scratch()
+        x = self._arena[first_chunk * NORM_CHUNK:(first_chunk + n_chunks) * NORM_CHUNK]
+        if x.is_cuda:
+            from . import hip
+            hip._check(hip.load().mvptr_sumsq_partial(hip._p(x), x.numel(), hip.c_void_p(sc.data_ptr() + 4 * first_chunk), hip._stream()))
+        else:
+            sc[first_chunk:first_chunk + n_chunks] = (x.view(n_chunks, NORM_CHUNK) ** 2).sum(1)
+
+    def _sumsq_bucket(self, b):
+        self._sumsq_span(b["base"] // NORM_CHUNK, (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK)
+        self._norm_done.add(id(b))
+
+    def clip_coef(self, max_norm):
+        """Global 2-norm of all gradients and min(1, max_norm / (norm + 1e-6)) as device scalars -> (norm [1], coef [1])
+        (torch.nn.utils.clip_grad_norm_, run_pretrain_ml.py:639-640; the coefficient multiplies the gradients inside the
+        fused AdamW).  Buckets whose partial sums finish(want_norm=True) already queued behind their collectives are not
+        read again; the rest (everything at world size 1) goes in one pass.  Either way the same chunk sums in the same
+        slots, added in slot order: the result does not depend on which path produced a slot."""
+        sc = self._norm_scratch()
+        n = self._arena.numel() // NORM_CHUNK
+        if len(self._norm_done) < len(self.buckets):
+            if not self._norm_done:
+                self._sumsq_span(0, n)
+            else:
+                for b in self.buckets:
+                    if id(b) not in self._norm_done:
+                        self._sumsq_bucket(b)
+        norm, coef = sc[n:n + 1], sc[n + 1:n + 2]
+        if sc.is_cuda:
+            from . import hip
+            hip._check(hip.load().mvptr_clip_coef(hip._p(sc), n, float(max_norm), hip._p(norm), hip._p(coef), hip._stream()))
+        else:
+            nv = sc[:n].double().sum().sqrt().float()
+            norm.copy_(nv.reshape(1))
+            coef.copy_(torch.clamp(max_norm / (nv + 1e-6), max=1.0).reshape(1))
+        return norm, coef
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
@@ -232,6 +326,7 @@ class GradSync:
         self._hook_skip = {}              # parameter whose next post-accumulate hook repeats a completed direct delivery -> None (or, check_mixed_use, a clone of its .grad then)
         self._rows = {}
         self._next = 0            # buckets [0, _next) have been launched this step
+        self._norm_done = set()   # buckets whose partial sums of squares are in their slots (finish(want_norm=True))
 
     def note_rows(self, param, ids):
         """Tell the exchange which rows of a row-sparse parameter this rank's step looks up (every id
@@ -388,16 +483,30 @@ class GradSync:
             if union is not None:
                 b["union"] = union
                 src = b["flat"].view_as(b["rows_of"]).index_select(0, union)
+        if self.collective == "rs_ag" and src is b["flat"]:
+            # reduce-scatter + all-gather over the bucket's chunk-padded span (the padding is zero and stays zero): every
+            # rank owns 1 / world of it between the two collectives
+            span = self._arena[b["base"]:b["base"] + (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK * NORM_CHUNK]
+            wire = span if self.comm_dtype == torch.float32 else span.to(self.comm_dtype)
+            shard = torch.empty(wire.numel() // self.world, device=wire.device, dtype=wire.dtype)
+            dist.reduce_scatter_tensor(shard, wire, op=op, group=self.group, async_op=True)
+            b["wire"] = wire
+            b["shard"] = shard      # kept alive until the all-gather has run
+            b["work"] = dist.all_gather_into_tensor(wire, shard, group=self.group, async_op=True)   # same communicator: ordered behind the reduce-scatter
+            self._next = idx + 1
+            return
         wire = src if (self.comm_dtype == torch.float32 and src is b["flat"]) else src.to(self.comm_dtype)
         b["wire"] = wire
         b["work"] = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
         self._next = idx + 1
 
-    def __call__(self):
+    def __call__(self, want_norm=False):
         """Finish the step's exchange: launch the buckets that are still waiting (in index order on
         every rank), wait for all of them, scale if the backend summed.  Parameters that received no
         gradient (on any rank) end with grad = None, as under DDP find_unused_parameters
-        (run_pretrain_ml.py:415-418) and as without an arena: the optimizer skips them."""
+        (run_pretrain_ml.py:415-418) and as without an arena: the optimizer skips them.
+        want_norm: the caller will clip by the global norm (clip_coef): queue every bucket's partial sums of squares
+        right behind its collective, so that only the coefficient kernel is left after the last bucket."""
         if not self.exchange:
             for p in self.params:
                 if p not in self._touched:
@@ -425,14 +534,18 @@ class GradSync:
                     red = red * (1.0 / self.world)
                 b["flat"].view_as(b["rows_of"]).index_copy_(0, b["union"], red)
                 b["wire"] = b["union"] = None
+                if want_norm:
+                    self._sumsq_bucket(b)
                 continue
-            if b["wire"] is not b["flat"]:
+            if b["wire"] is not b["flat"] and b["wire"].data_ptr() != b["flat"].data_ptr():
                 if b["wire"].is_cuda:
                     b["wire"].record_stream(torch.cuda.current_stream(b["wire"].device))
-                b["flat"].copy_(b["wire"])          # bf16 -> f32, ordered after the collective by wait()
+                b["flat"].copy_(b["wire"][:b["n"]])          # bf16 -> f32, ordered after the collective by wait()
             if not self._avg:
                 b["flat"].mul_(1.0 / self.world)
-            b["wire"] = None
+            b["wire"] = b["shard"] = None
+            if want_norm:
+                self._sumsq_bucket(b)         # behind THIS bucket's collective; the later buckets are still on the wire
         used = used.tolist()
         for p, u in zip(self.params, used):
             if not u:

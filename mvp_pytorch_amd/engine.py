@@ -503,8 +503,14 @@ class EncoderMeta:
         # weight gradients of the whole stack in ONE balanced launch at the end of its backward pass (mvptr_gemm_tn_stack)
         # instead of two grouped launches per layer; False restores the per-layer launches
         self.defer_wgrad = DEFER_WGRAD
+        # gelu'(u) stash of the FFN: 8-bit fixed point (default) or bf16 (config.gelu_stash = "bf16": the format of rounds 1-3,
+        # for reference-numerics runs and A/B runs; set by the encoder module)
+        self.stash_bf16 = GELU_STASH_BF16
 
 
+# gelu'(u) stash format where no config says otherwise (LinearFn of the head transforms reads it too): False = 8-bit fixed
+# point (|error| <= 0.0025, round 4), True = bf16.  config.gelu_stash = "bf16" | "u8" sets it per model (modeling_utils).
+GELU_STASH_BF16 = False
 # Default of EncoderMeta.defer_wgrad (A/B switch: bench.py --wgrad-per-layer, tests).
 DEFER_WGRAD = True
 # CUs the stack-wide weight-gradient launch leaves free (0: it takes every CU).  Its workgroups keep their CU for the whole
@@ -619,7 +625,8 @@ class EncoderFn(GradAwareFunction):
                               next_seed() if meta.training else 0, meta.rows, min(meta.rows_plan, meta.rows) if meta.rows_dev is not None else 0,
                               meta.seq_start.data_ptr() if meta.rows else None,
                               meta.seq_len.data_ptr() if meta.rows else None,
-                              meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None)
+                              meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None,
+                              1 if getattr(meta, "stash_bf16", False) else 0, 0)
             nbytes = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
             if nbytes < 0:
                 hip._check(-1)
@@ -854,7 +861,7 @@ class InputEmbedFn(GradAwareFunction):
 
 # ---------------------------------------------------------------------------------------------
 class LinearFn(GradAwareFunction):
-    """y = act(x W^T + b) on bf16 rows; act in {None, 'gelu'}; W f32 [N,K] master weight."""
+    """y = act(x W^T + b) on bf16 rows; act in {None, 'gelu', 'gelu16'}; W f32 [N,K] master weight."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, cache):
@@ -865,8 +872,8 @@ class LinearFn(GradAwareFunction):
         cache.weight_copies(weight)
         b = _f32(bias) if bias is not None else None
         N = weight.shape[0]
-        if act == "gelu":
-            u, y = hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS_GELU, bias=b, n=N)
+        if act in ("gelu", "gelu16"):       # "gelu16": gelu'(u) stashed in bf16 instead of 8-bit fixed point (config.gelu_stash)
+            u, y = hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS_GELU_BF16 if (act == "gelu16" or GELU_STASH_BF16) else hip.EPI_BIAS_GELU, bias=b, n=N)
         else:
             u, y = None, hip.gemm_nt(x2, cache.t["w"], hip.EPI_BIAS, bias=b, n=N)
         ctx.save = (x2, u, cache, weight.shape, bias is not None)

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmvptr_hip_%s.so" % os.environ["MVPTR_LIB"] if os.environ.get("MVPTR_LIB") else "libmvptr_hip.so")
 
 # epilogue codes (mvptr_epilogue)
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIAS_TANH = range(7)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIAS_TANH, EPI_BIAS_GELU_BF16, EPI_GELU_BWD_BF16 = range(9)
 
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -47,7 +47,8 @@ class LayerDesc(Structure):
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("heads", c_int), ("I", c_int),
                 ("eps", c_float), ("training", c_int), ("p_hidden16", c_uint32),
                 ("p_attn16", c_uint32), ("seed", c_uint64),
-                ("M", c_int), ("M_plan", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p), ("rows_dev", c_void_p)]
+                ("M", c_int), ("M_plan", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p), ("rows_dev", c_void_p),
+                ("stash_bf16", c_int), ("pad_", c_int)]
 
 
 class LayerWeights(Structure):
@@ -138,7 +139,7 @@ def load():
     lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
     lib.mvptr_masked_mean.argtypes = [P, P, I, P, P]
     lib.mvptr_compact_scored.argtypes = [P, P, I64, I, I, I, P, P, P]
-    lib.mvptr_dgelu_mul.argtypes = [P, I64, P, I64, P, I64, I, I, I, P]
+    lib.mvptr_dgelu_mul.argtypes = [P, I64, P, I64, I, P, I64, I, I, I, P]
     lib.mvptr_tap_rows_bwd.argtypes = [POINTER(Tap), I, P, I64, I, P, I64, I, I, P, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
     lib.mvptr_l2norm_bwd.argtypes = [P, P, P, P, I, I, P]
@@ -220,18 +221,20 @@ def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, v
         # EPI_BIAS_GELU: out = the 8-bit gelu'(u) stash (dgelu_decode), out1 = gelu(u) in bf16
         dt = torch.float32 if epilogue == EPI_F32 else (torch.uint8 if epilogue == EPI_BIAS_GELU else torch.bfloat16)
         out = torch.empty((M, N), device=a.device, dtype=dt)
-    if epilogue == EPI_BIAS_GELU:
-        assert out.dtype == torch.uint8
+    if epilogue in (EPI_BIAS_GELU, EPI_BIAS_GELU_BF16):
+        assert out.dtype == (torch.uint8 if epilogue == EPI_BIAS_GELU else torch.bfloat16)
         if out1 is None:
             out1 = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
         assert out1.stride(0) == out.stride(0)
     if epilogue == EPI_GELU_BWD:
         assert aux is not None and aux.dtype == torch.uint8
+    if epilogue == EPI_GELU_BWD_BF16:
+        assert aux is not None and aux.dtype == torch.bfloat16
     assert out.stride(1) == 1
     _check(load().mvptr_gemm_nt(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, epilogue, _p(bias),
                                 _p(aux), aux.stride(0) if aux is not None else 0, _p(out), _p(out1),
                                 out.stride(0), _p(vec_out), _dp(drop), _stream()))
-    return (out, out1) if epilogue == EPI_BIAS_GELU else out
+    return (out, out1) if epilogue in (EPI_BIAS_GELU, EPI_BIAS_GELU_BF16) else out
 
 
 DGELU_SCALE, DGELU_ZERO = 200.0, 26.0
@@ -680,11 +683,14 @@ def masked_mean(loss_row, labels):
 
 
 def dgelu_mul(dy, stash, Npad=None):
-    """bf16 [M, Npad] = dy * gelu'(u) decoded from the 8-bit stash (columns N .. Npad zero) — mvptr_dgelu_mul."""
+    """bf16 [M, Npad] = dy * gelu'(u) decoded from the stash (uint8: 8-bit fixed point; bfloat16: the bf16 stash; columns
+    N .. Npad zero) — mvptr_dgelu_mul."""
     M, N = dy.shape
     Npad = N if Npad is None else Npad
+    assert stash.dtype in (torch.uint8, torch.bfloat16)
     out = torch.empty((M, Npad), dtype=torch.bfloat16, device=dy.device)
-    _check(load().mvptr_dgelu_mul(_p(dy), dy.stride(0), _p(stash), stash.stride(0), _p(out), out.stride(0), M, N, Npad, _stream()))
+    _check(load().mvptr_dgelu_mul(_p(dy), dy.stride(0), _p(stash), stash.stride(0), 1 if stash.dtype == torch.bfloat16 else 0, _p(out),
+                                  out.stride(0), M, N, Npad, _stream()))
     return out
 
 

@@ -200,9 +200,10 @@ class BertPredictionHeadTransform(nn.Module):
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self._cache = engine.WeightCache()
+        self._act = "gelu16" if str(getattr(config, "gelu_stash", "u8")).lower() == "bf16" else "gelu"   # format of the gelu' stash
 
     def forward(self, hidden_states):
-        h = engine.LinearFn.apply(bf16_rows(hidden_states), self.dense.weight, self.dense.bias, "gelu", self._cache)
+        h = engine.LinearFn.apply(bf16_rows(hidden_states), self.dense.weight, self.dense.bias, self._act, self._cache)
         return self.LayerNorm(h)
 
 

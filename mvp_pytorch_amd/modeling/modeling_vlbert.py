@@ -113,6 +113,9 @@ class CaptionBertEncoder(nn.Module):
         # skip padded rows (see forward): "train" (default) = in training mode only, where nothing but
         # the losses is consumed; True = always; False = never (the reference's padded execution)
         self.unpad = getattr(config, "unpad", "train")
+        # gelu'(u) stash of the FFN: "u8" (default: 8-bit fixed point, |error| <= 0.0025) or "bf16" (rounds 1-3; reference-numerics
+        # runs and A/B runs of the 8-bit stash: tools/soak.py --gelu-stash)
+        self.gelu_stash_bf16 = str(getattr(config, "gelu_stash", "u8")).lower() == "bf16"
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_flat_cache", None)      # .to() / .half() may replace Parameter objects
@@ -182,10 +185,12 @@ class CaptionBertEncoder(nn.Module):
                 starts = (torch.cumsum(lens, 0, dtype=torch.int32) - lens).contiguous()
                 meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
                                           l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
+                meta.stash_bf16 = self.gelu_stash_bf16
                 y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
                 return (engine.UnpackRows.apply(y, idx, B * L).view(B, L, H),)
         meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
+        meta.stash_bf16 = self.gelu_stash_bf16
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
 
@@ -199,6 +204,7 @@ def _run_layers(self, hidden_states, attention_mask, first, count):
     meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
                               l0.output.dropout.p, l0.attention.self.dropout.p, first=first, count=count,
                               all_params=self._flat_params())
+    meta.stash_bf16 = self.gelu_stash_bf16
     y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params()[16 * first:16 * (first + count)])
     return y.view(B, L, H)
 
@@ -216,6 +222,7 @@ def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax, rows_dev=None, 
     meta = engine.EncoderMeta(self._packs.for_device(x_rows.device), n_seq, lmax, Hc, heads, I, eps, self.training,
                               l0.output.dropout.p, l0.attention.self.dropout.p, seq_start=seq_start, seq_len=seq_len,
                               rows=x_rows.shape[0], rows_dev=rows_dev, rows_plan=rows_plan)
+    meta.stash_bf16 = self.gelu_stash_bf16
     return engine.EncoderFn.apply(x_rows, None, meta, *self._flat_params())
 
 
@@ -1117,7 +1124,11 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
                 phrase_mod="sample", host_counts=None):
         """host_counts (optional, not a reference argument): synthetic.host_counts(batch) — the input-only counts a step
         needs on the host (valid rows / longest sequence of both inputs, scored MLM rows), computed where the batch was
-        built, so that the row-packed training step does not read them back from the device."""
+        built, so that the row-packed training step does not read them back from the device.  They MUST describe this
+        batch: the device checks them against the masks and the labels (mvptr_check_counts: rows / longest sequence;
+        mvptr_compact_scored: no more scored rows than slots) and a mismatch TRAPS — on ROCm the process aborts with both sets
+        of numbers printed; train.model_inputs rejects counts that cannot fit the batch's shapes before anything is queued.
+        Recompute them (synthetic.host_counts) whenever a collated batch is edited, or leave the argument out."""
         if (self.packed_pipeline and self.training and masked_lm_labels_a is not None and masked_lm_labels_b is not None and
                 head_mask is None and phrase_mod == "sample" and (phrase_index is None or (img_index is not None and self.wra_on_device)) and
                 self.bert.packed_ok(attention_mask_a, attention_mask_b, input_ids_a)):

@@ -22,6 +22,15 @@ def model_inputs(batch, max_tag_length):
     (run_pretrain_ml.py:528-531); a single-stream batch (input_ids / input_mask / ...) maps to
     BertImgForPreTraining's arguments (run_pretrain_ml.py:533 positional order)."""
     feats = batch.get("img_feats")
+    hc = batch.get("host_counts")
+    if hc is not None and "input_mask_a" in batch:
+        # cheap host-side sanity of counts a caller may have carried over from another batch (the device-side checks —
+        # mvptr_check_counts on rows / longest sequence, mvptr_compact_scored on the scored rows — ABORT the process on a mismatch)
+        ma, mb = batch["input_mask_a"], batch["input_mask_b"]
+        ok = (0 < int(hc["rows_a"]) <= ma.numel() and 0 < int(hc["rows_b"]) <= mb.numel() and 0 < int(hc["lmax_a"]) <= ma.shape[1]
+              and 0 < int(hc["lmax_b"]) <= mb.shape[1] and 0 <= int(hc["scored_a"]) <= ma.numel() and 0 <= int(hc["scored_b"]) <= mb.numel())
+        if not ok:
+            raise ValueError("host_counts %r do not fit this batch (masks %s / %s)" % (dict(hc), tuple(ma.shape), tuple(mb.shape)))
     if "img_feats_bf16" in batch:
         # K-padded bf16 operand produced by the input pipeline (input_pipeline.PretrainBatchStager): the model skips its cast
         fb = batch["img_feats_bf16"]
@@ -44,6 +53,10 @@ def clip_coefficient(model, grad_sync, max_grad_norm):
     rescales 1 GB of gradients, no host sync).  Otherwise torch's clip (rescales in place) -> None."""
     flats = grad_sync.flats() if (grad_sync is not None and hasattr(grad_sync, "flats")) else None
     if flats and flats[0].is_cuda:
+        if hasattr(grad_sync, "clip_coef"):
+            # per-chunk partial sums in fixed slots: the buckets a multi-rank exchange has already summed behind their
+            # collectives (GradSync.__call__(want_norm=True)) are not read again
+            return grad_sync.clip_coef(max_grad_norm)[1]
         from . import hip
         # the partial-sum scratch belongs to the arena it is sized for (one GradSync per model)
         _, coef, grad_sync._clip_scratch = hip.grad_clip_coef(flats, max_grad_norm, getattr(grad_sync, "_clip_scratch", None))
@@ -66,7 +79,10 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
     loss = loss_weight * outputs[0]
     loss.backward()
     if grad_sync is not None:
-        grad_sync()
+        try:
+            grad_sync(want_norm=max_grad_norm > 0)
+        except TypeError:           # a plain callable
+            grad_sync()
     grad_scale = None
     if max_grad_norm > 0:
         grad_scale = clip_coefficient(model, grad_sync, max_grad_norm)

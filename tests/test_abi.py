@@ -63,4 +63,4 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(hip.Dropout) == 16
     assert ctypes.sizeof(hip.LayerWeights) == 16 * 8
     assert ctypes.sizeof(hip.LayerGrads) == 12 * 8
-    assert ctypes.sizeof(hip.LayerDesc) == 80      # ABI 4: + rows_dev (device-side row count); pad_ became M_plan
+    assert ctypes.sizeof(hip.LayerDesc) == 88      # ABI 5: + stash_bf16 (format of the gelu' stash); ABI 4: + rows_dev, pad_ became M_plan

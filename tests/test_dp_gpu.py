@@ -25,8 +25,11 @@ def _worker(rank, world, port, q, sparse):
     model = modeling.BiBertImgForPreTraining(modeling.make_config(cfg)).to(dev)
     model.train()
     opt, sched = train.build_optimizer(model, lr=1e-3, t_total=10)
-    sparse_rows = [model.bert.embeddings.word_embeddings.weight] if sparse else []
-    sync = dp.GradSync(model, bucket_mb=0.25, sparse_rows=sparse_rows)
+    if sparse:      # "default": what GradSync picks for the two-stage model (bf16 wire + row-sparse word table, dp.default_exchange)
+        sync = dp.GradSync(model, bucket_mb=0.25)
+        assert sync.comm_dtype == torch.bfloat16 and len(sync.sparse) == 1
+    else:           # the conservative exchange: f32 wire, dense word table
+        sync = dp.GradSync(model, bucket_mb=0.25, comm_dtype=torch.float32, sparse_rows=[])
     dims = dict(B=4, T=12, P=3, G=6, R=5)
     losses = []
     for step in range(3):
@@ -59,8 +62,9 @@ def _run(sparse):
 
 
 def test_two_rank_training_step_keeps_replicas_identical(dev):
-    """Dense exchange, then the row-sparse exchange of the word-embedding gradient (GradSync.note_rows from
-    train.pretrain_step): replicas identical in both, and both modes give the same parameters."""
+    """The conservative exchange (f32 wire, dense), then GradSync's DEFAULT for the two-stage model (bf16 wire + the
+    row-sparse exchange of the word-embedding gradient, GradSync.note_rows from train.pretrain_step): replicas identical in
+    both, and both modes give the same parameters to the wire's rounding."""
     import numpy as np
     probes = []
     for sparse in (False, True):
@@ -77,7 +81,7 @@ def test_two_rank_training_step_keeps_replicas_identical(dev):
     assert np.allclose(ld, ls, rtol=1e-3)
     for k in pd_:
         close = np.abs(pd_[k] - ps[k]) <= 2.5e-3
-        assert close.mean() > 0.97, (k, float(close.mean()))     # rows outside the union are zero on both ranks: same sums
+        assert close.mean() > 0.90, (k, float(close.mean()))     # rows outside the union are zero on both ranks; bf16 wire: 8 mantissa bits per summand
 
 
 def test_bench_launcher_two_ranks_on_one_gpu(dev):
@@ -104,8 +108,9 @@ def test_bench_launcher_two_ranks_on_one_gpu(dev):
     # communication the step could not hide
     dpi = line["config"]["data_parallel"]
     assert dpi["rccl_ranks_seen"] == 2 and dpi["backend"] == "gloo" and dpi["rccl_version"] is None
-    assert dpi["defaults"] == {"wire": "f32", "sparse_word_table": False, "two_streams": False}
-    assert dpi["dp_optins"]["ms_per_step"] > 0 and dpi["dp_optins"]["steps"] == 2 and dpi["dp_optins"]["stalled_steps"] == 0
+    assert dpi["defaults"] == {"wire": "bf16", "sparse_word_table": True, "two_streams": False, "collective": "all_reduce"}
+    assert dpi["dp_conservative"]["ms_per_step"] > 0 and dpi["dp_conservative"]["steps"] == 2 and dpi["dp_conservative"]["stalled_steps"] == 0
+    assert "dp_rs_ag" not in dpi or "error" in dpi["dp_rs_ag"] or dpi["dp_rs_ag"]["ms_per_step"] > 0     # RCCL only
     assert isinstance(dpi["exposed_comm_ms"], float) and dpi["ms_per_step_without_exchange"] > 0
     assert line["config"]["max_grad_norm"] == 10.0
 
@@ -139,7 +144,9 @@ def _one_rank_worker(mode, port, q):
     if mode == "arena":
         sync = dp.GradSync(model, bucket_mb=0.25)
     elif mode == "rccl":
-        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True)
+        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.float32, sparse_rows=[])
+    elif mode == "rccl_rsag":       # reduce-scatter + all-gather per bucket over its chunk-padded span
+        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.float32, sparse_rows=[], collective="rs_ag")
     elif mode == "rccl_opts":
         sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.bfloat16,
                            sparse_rows=[model.bert.embeddings.word_embeddings.weight])
@@ -159,7 +166,11 @@ def _one_rank_worker(mode, port, q):
         out[0].backward()
         hooks = 0 if sync is None else sync._next          # buckets that went out from hooks, overlapped with backward
         if sync is not None:
-            sync()
+            sync(want_norm=True)
+            if sync.exchange:       # per-bucket partial sums behind the collectives = the pass over the whole arena, bit for bit
+                n1 = sync.clip_coef(10.0)[0].clone()
+                sync._norm_done = set()
+                assert torch.equal(n1, sync.clip_coef(10.0)[0])
         if step == 0:   # gradients of the FIRST step: identical weights in every mode, only the exchange path differs
             grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in model.named_parameters() if n in names and p.grad is not None}
         losses.append(float(out[0]))
@@ -201,7 +212,7 @@ def test_rccl_world1_and_gradient_arena_match_plain_step(dev):
     parameter updates as a step without any GradSync; the gradient arena alone (no process group) likewise."""
     import numpy as np
     ref = _one_rank("plain")
-    for mode in ("arena", "rccl", "rccl_opts"):
+    for mode in ("arena", "rccl", "rccl_rsag", "rccl_opts"):
         got = _one_rank(mode)
         print("one-rank", mode, got[1], got[4])
         assert np.allclose(got[1], ref[1], rtol=2e-4), (mode, got[1], ref[1])

@@ -220,7 +220,18 @@ def _dp_worker(rank, world, port, q, comm_dtype=torch.float32):
         else:
             loss_fn(x, with_head, with_late).backward()
         early.append(sync._next)   # buckets launched from hooks, before finish()
-        sync()
+        # the global-norm clip survives the overlap: with want_norm the partial sums of squares of every bucket are taken
+        # right behind its collective; the coefficient from them equals the one from a pass over the whole arena BIT FOR BIT
+        # (same chunk slots, same order), and both equal the norm of the averaged gradients
+        sync(want_norm=(step % 2 == 0))
+        assert (len(sync._norm_done) == len(sync.buckets)) == (step % 2 == 0)
+        n1, c1 = [t.clone() for t in sync.clip_coef(0.05)]
+        sync._norm_done = set()
+        n2, c2 = [t.clone() for t in sync.clip_coef(0.05)]
+        assert torch.equal(n1, n2) and torch.equal(c1, c2), (step, n1, n2)
+        want = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None))
+        assert abs(float(n1) - float(want)) <= 1e-5 * max(1.0, float(want)), (step, float(n1), float(want))
+        assert abs(float(c1) - min(1.0, 0.05 / (float(want) + 1e-6))) < 1e-5
         results.append([None if p.grad is None else p.grad.detach().clone().numpy() for p in m.parameters()])
         # reference: gradient of the same loss computed locally, to be averaged by the parent
         ref = torch.autograd.grad(loss_fn(x, with_head, with_late), used, allow_unused=True)

@@ -1372,3 +1372,30 @@ def test_deferred_stack_weight_gradients_equal_per_layer(dev, layers, rows, drop
         # rounding per summand apart (measured 1.6e-3)
         tol = 5e-3 if n.endswith("intermediate.dense.bias") else 2e-5
         assert _rel(g1[n], g0[n]) < tol, (n, _rel(g1[n], g0[n]))
+
+
+def test_gelu_stash_formats_agree(dev):
+    """config.gelu_stash = "bf16" (the stash format of rounds 1-3, selectable) against the default 8-bit fixed
+    point on the tiny two-stage training fixture, same weights and inputs, dropout off: identical losses (the forward pass only
+    differs in what it SAVES), gradients equal to what the 8-bit grid allows (|error of gelu'| <= 0.0025 on values of
+    order 0.1 - 1)."""
+    d = gu.load("tiny_bi_pretrain_nophrase")
+    cfg, dims = d["config"], d["dims"]
+    t = lambda k: torch.from_numpy(d["in:" + k]).to(dev)  # noqa: E731
+    outs = {}
+    for fmt in ("u8", "bf16"):
+        model, _ = _build("BiBertImgForPreTraining", dict(cfg, gelu_stash=fmt), int(d["seed"]), dev, train=True, gain=float(d["weight_gain"]))
+        model.wra_on_device = True
+        assert model.bert.txt_encoder.gelu_stash_bf16 == (fmt == "bf16") and model.cls.predictions.transform._act == ("gelu16" if fmt == "bf16" else "gelu")
+        with Replay(d, dev):
+            res = model(masked_lm_labels_a=t("lm_label_ids_a"), masked_lm_labels_b=t("lm_label_ids_b"), max_tag_length=dims["G"], **_bi_inputs(d, dev))
+        res[0].backward()
+        torch.cuda.synchronize()
+        outs[fmt] = ([float(x) for x in res], {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    (l8, g8), (l16, g16) = outs["u8"], outs["bf16"]
+    assert l8 == l16
+    assert set(g8) == set(g16)
+    worst = max((_rel(g8[n], g16[n]), n) for n in g16 if g16[n].norm() > 1e-6 and n not in CLIP_BRANCH and n != "logit_scale" and
+                not n.endswith("attention.self.key.bias"))
+    print("gelu' stash u8 vs bf16: worst gradient rel L2", worst)
+    assert worst[0] < 1.5e-2, worst

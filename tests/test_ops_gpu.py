@@ -85,6 +85,17 @@ def test_gemm_nt_epilogues(dev):
     assert _rel(vec, (base * hip.dgelu_decode(gq)).sum(0)) < 1e-3
     # exact end points of the stash: 0 and 1 survive the round trip
     assert torch.equal(hip.dgelu_decode(hip.dgelu_encode(torch.tensor([0.0, 1.0]))), torch.tensor([0.0, 1.0]))
+    # ABI 5: the same pair with the stash in bf16 (config.gelu_stash = "bf16"): same gelu(u), derivative to bf16 rounding
+    d16, act16 = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU_BF16, bias=bias)
+    assert d16.dtype == torch.bfloat16 and torch.equal(act16, act)
+    assert _rel(d16, uref.grad) < 3e-3 and (d16.float() - uref.grad).abs().max() < 2.0 ** -8 * 1.2
+    g16 = _bf(torch.rand(M, N, generator=g) * 1.25 - 0.125).to(dev)
+    vec16 = torch.zeros(N, device=dev)
+    du16 = hip.gemm_nt(a, b, hip.EPI_GELU_BWD_BF16, aux=g16, vec_out=vec16)
+    assert _rel(du16, base * g16.float()) < 4e-3 and _rel(vec16, (base * g16.float()).sum(0)) < 1e-3
+    dyh = _bf(torch.randn(M, N, generator=g)).to(dev)
+    assert _rel(hip.dgelu_mul(dyh, g16), dyh.float() * g16.float()) < 3e-3
+    assert _rel(hip.dgelu_mul(dyh, gq), dyh.float() * hip.dgelu_decode(gq)) < 3e-3
 
 
 @pytest.mark.parametrize("M,N,K", [(16500, 768, 768), (16700, 2304, 768), (17000, 3072, 768), (16641, 768, 3072), (16900, 768, 2304),
@@ -529,7 +540,7 @@ def test_multi_tap_fn_gradients(dev):
 
 def test_compact_scored_rows(dev):
     """mvptr_compact_scored against the chain it replaces (labels > -1 -> nonzero -> two index_selects), with a row map wider
-    and taller than the label matrix (the packed joint map), without one, with a surplus and with a shortfall of scored slots."""
+    and taller than the label matrix (the packed joint map), without one, and with a shortfall of scored slots."""
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(31)
     for B, L, ld, rows in ((256, 75, 125, 512), (7, 20, 20, 7), (1, 5, 9, 3), (300, 70, 70, 300)):
@@ -545,9 +556,8 @@ def test_compact_scored_rows(dev):
         assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), want_r)
         ol, orow = hip.compact_scored(labels.to(dev), None, n)
         assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), idx.to(torch.int32))
-        if n > 2:
-            ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n - 2)            # surplus cut
-            assert torch.equal(ol.cpu(), want_l[:n - 2]) and torch.equal(orow.cpu(), want_r[:n - 2])
+        # (fewer output slots than scored rows is a caller bug since ABI 5: the kernel traps — on ROCm the process aborts, so
+        #  that case is not exercised here)
         ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n + 5)                # shortfall padded with -1 / -1
         assert torch.equal(ol.cpu()[:n], want_l) and (ol.cpu()[n:] == -1).all() and (orow.cpu()[n:] == -1).all()
 

@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--ab", action="store_true", help="diagnostic library (MVPTR_LIB=diag): also time the persistent ring "
                                                       "experiment (MVPTR_GEMM_CFG=p, gemm_ntp_kernel)")
-    ap.add_argument("--cfg", default="p", help="with --ab: the MVPTR_GEMM_CFG value of the extra column (p, v4, w4, s128, t256k)")
+    ap.add_argument("--cfg", default="p", help="with --ab: the MVPTR_GEMM_CFG value of the extra column (p, v4, w4, s128, t256k, 8)")
+    ap.add_argument("--loop-only", action="store_true", help="with --ab: two more columns, both kernels without their epilogue (MVPTR_NT_EXP bit 10)")
     args = ap.parse_args()
     H, I = 768, 3072
     flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
@@ -67,18 +68,27 @@ def main():
             vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
             ours = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
             old = None
+            loop_txt = ""
             if args.ab:
                 hip.set_knob("MVPTR_GEMM_CFG", args.cfg)
                 old = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
                 hip.set_knob("MVPTR_GEMM_CFG", "")
                 tot_old += old
+                if args.loop_only:
+                    hip.set_knob("MVPTR_NT_EXP", "1024")
+                    l0 = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
+                    hip.set_knob("MVPTR_GEMM_CFG", args.cfg)
+                    l1 = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
+                    hip.set_knob("MVPTR_GEMM_CFG", "")
+                    hip.set_knob("MVPTR_NT_EXP", "0")
+                    loop_txt = "   loop-only %7.1f / %7.1f" % (l0, l1)
             bt = b.t()
             lib = cold_us(lambda: torch.matmul(a, bt, out=out), flush, args.reps)
             fl = 2.0 * M * N * K
             tot_ours += ours
             tot_lib += lib
             print("%-22s %6d %5d %5d  %9.1f %8.1f  %9.1f %8.1f  %6.2f%s" % (name, M, N, K, ours, fl / ours / 1e6, lib, fl / lib / 1e6, ours / lib,
-                                                                             "   %8.1f" % old if old is not None else ""))
+                                                                             ("   %8.1f" % old if old is not None else "") + loop_txt))
     print("sum: ours %.1f us, hipBLASLt (no epilogue) %.1f us%s" % (tot_ours, tot_lib, ", %s %.1f us" % (args.cfg, tot_old) if args.ab else ""))
 
 
