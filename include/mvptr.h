@@ -546,7 +546,10 @@ typedef struct {
   /* ABI 5: 0 = gelu'(u) stashed as 8-bit fixed point (1 B per element, |error| <= 0.0025: the default), 1 = as bf16 (2 B per
    * element: the stash of rounds 1-3) — must be the same in the forward and the backward call of a layer */
   int stash_bf16;
-  int pad_;
+  /* ABI 5: 1 = GEMMs of another stack run beside this layer on a second stream (the text and visual stacks of the two-stage
+   * model): its GEMM tiles keep their full 256-row height — under-filled rounds of the 256 CUs are filled by the other stream.
+   * 0 = the launch has the GPU to itself (joint stack, one-stream jobs): tile height 256 / 224 / 192 / 160 rows by whole CU rounds. */
+  int beside;
 } mvptr_layer_desc;
 
 typedef struct {

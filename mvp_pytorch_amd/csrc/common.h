@@ -108,6 +108,25 @@ __device__ __forceinline__ float drop_apply(const DropDev& d, uint64_t idx, floa
   if (d.thresh16 == 0) return v;
   return (mvptr_rand16(idx, d.seed_lo, d.seed_hi) >= d.thresh16) ? v * d.scale : 0.f;
 }
+// the same hash for pair indices below 2^32 (their high word contributes 0 * 0x9E3779B9 = 0): one integer multiply
+// (quarter rate) and the 64-bit index arithmetic less — bit-identical masks
+__device__ __forceinline__ uint32_t mvptr_pair_hash_lo(uint32_t pair, uint32_t seed_lo, uint32_t seed_hi) {
+  uint32_t x = pair ^ seed_lo;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x += seed_hi;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// dropout of the adjacent elements (2 pair, 2 pair + 1), pair < 2^32
+__device__ __forceinline__ void drop_apply2_lo(const DropDev& d, uint32_t pair, float& v0, float& v1) {
+  if (d.thresh16 == 0) return;
+  const uint32_t h = mvptr_pair_hash_lo(pair, d.seed_lo, d.seed_hi);
+  v0 = ((h & 0xffffu) >= d.thresh16) ? v0 * d.scale : 0.f;
+  v1 = ((h >> 16) >= d.thresh16) ? v1 * d.scale : 0.f;
+}
 // dropout of the adjacent elements (idx_even, idx_even + 1) with one hash
 __device__ __forceinline__ void drop_apply2(const DropDev& d, uint64_t idx_even, float& v0, float& v1) {
   if (d.thresh16 == 0) return;
@@ -261,7 +280,7 @@ __device__ __forceinline__ void lds_dma16_add(const u32x4& rsrc, uint32_t vbase,
 // host never waits for the count.  Internal C++ forms of the public calls with those two extra arguments:
 int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epilogue, const float* bias,
                        const void* aux, int64_t ld_aux, void* out0, void* out1, int64_t ldc, float* vec_out, const mvptr_dropout* drop,
-                       const int* rows_dev, int M_plan, void* stream);
+                       const int* rows_dev, int M_plan, void* stream, int full_height = 0);
 int mvptr_gemm_tn_multi_rows(const mvptr_tn_problem* problems, int count, void* ws, int64_t ws_bytes, const int* rows_dev, int M_plan,
                              void* stream);
 int mvptr_layernorm_fwd_rows(const void* z, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int M,

@@ -492,16 +492,22 @@ int launch_nt8(const GemmNtArgs& a, hipStream_t s) {
   const int64_t tn = a.N / 256;
   static const double kPenalty[9] = {0, 0, 0, 0, 0, 1.10, 1.06, 1.03, 1.0};
   int best = 8;
-  double best_cost = 1e30;
-  for (int mt = 8; mt >= 5; --mt) {
+  double best_cost = 1e30, cost8 = 0.0;
+  for (int mt = 8; mt >= (a.full_height ? 8 : 5); --mt) {
     const int64_t tiles = (int64_t)((Mp + 32 * mt - 1) / (32 * mt)) * tn;
     const double rounds = (double)((tiles + ncu - 1) / ncu);
     const double cost = rounds * mt * kPenalty[mt];
+    if (mt == 8) cost8 = cost;
     if (cost < best_cost - 1e-9) {
       best_cost = cost;
       best = mt;
     }
   }
+  // a partly filled last round runs faster per tile than a full one (fewer CUs share HBM, L2 and the clock), so whole rounds
+  // overstate what a shorter tile saves: it is only taken for a predicted saving of 15 % or more (in-step A/B, gpurun_out/r05g:
+  // 224-row tiles on the joint stack's N = 768 / 2304 GEMMs — predicted -10 % — cost +0.15 ms per step; the 192- / 160-row
+  // tiles of a lone few-row launch — predicted -20 ... -31 % — win 0.4 - 0.5 ms on one-stream steps)
+  if (best != 8 && best_cost > 0.85 * cost8) best = 8;
 #ifdef MVPTR_DIAG_BUILD
   const int force = (mvptr_knobs().nt_exp >> 22) & 15;
   if (force >= 5 && force <= 8) best = force;
@@ -732,7 +738,7 @@ extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t 
 
 int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int epilogue, const float* bias,
                        const void* aux, int64_t ld_aux, void* out0, void* out1, int64_t ldc, float* vec_out, const mvptr_dropout* drop,
-                       const int* rows_dev, int M_plan, void* stream) {
+                       const int* rows_dev, int M_plan, void* stream, int full_height) {
   if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt: M,N,K must be > 0");
   if ((K & 7) || (lda & 7) || (ldb & 7))
     MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%ld ldb=%ld)",
@@ -752,6 +758,7 @@ int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, i
   a.K = K;
   a.rows_dev = rows_dev;
   a.m_plan = M_plan;
+  a.full_height = full_height;
   a.bias = bias;
   a.aux = (const __bf16*)aux;
   a.ld_aux = ld_aux;

@@ -14,6 +14,7 @@ struct GemmNtArgs {
   int M, N, K;
   const int* rows_dev;   // device int32: actual row count <= M (NULL: M); workgroups beyond it return at once
   int m_plan;            // rows the tile configuration is chosen for (<= M; the grid always covers M)
+  int full_height;       // 1: keep 256-row tiles (another stream fills under-filled CU rounds: mvptr_layer_desc.beside)
   const float* bias;
   const __bf16* aux;
   int64_t ld_aux;
@@ -338,7 +339,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       store_bf8(p.out0, m, dg);      // the bf16 stash of rounds 1-3
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-      if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
+      if ((p.N & 1) == 0 && (uint64_t)p.M * (uint64_t)p.N < ((uint64_t)1 << 32)) {
+        // every element index fits 32 bits (all of this model's outputs): 32-bit index arithmetic, two multiplies per hash
+        const uint32_t pr = ((uint32_t)m * (uint32_t)p.N + (uint32_t)n) >> 1;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) drop_apply2_lo(p.drop, pr + (uint32_t)(e >> 1), v[e], v[e + 1]);
+      } else if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
 #pragma unroll
         for (int e = 0; e < 8; e += 2)
           drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);

@@ -134,17 +134,17 @@ extern "C" int mvptr_encoder_layer_fwd(const mvptr_layer_desc* d, const mvptr_la
   const int* rd = d->rows_dev;     // device-side row count of a row-packed pass (NULL: M rows)
   const int Mp = d->M_plan;
   RUN(mvptr_gemm_nt_rows(x, H, w->w_qkv, H, M, 3 * H, H, MVPTR_EPI_BIAS, w->b_qkv, nullptr, 0, s.qkv,
-                         nullptr, 3 * H, nullptr, nullptr, rd, Mp, stream));
+                         nullptr, 3 * H, nullptr, nullptr, rd, Mp, stream, d->beside));
   RUN(mvptr_attention_fwd_packed(s.qkv, mask_add, s.ctx, s.lse, d->seq_start, d->seq_len, d->B, d->L, d->heads,
                                  &dr_attn, stream));
   RUN(mvptr_gemm_nt_rows(s.ctx, H, w->w_o, H, M, H, H, MVPTR_EPI_BIAS_RESID, w->b_o, x, H, s.z1, nullptr,
-                         H, nullptr, &dr_o, rd, Mp, stream));
+                         H, nullptr, &dr_o, rd, Mp, stream, d->beside));
   RUN(mvptr_layernorm_fwd_rows(s.z1, w->ln1_g, w->ln1_b, d->eps, s.x1, s.mean1, s.rstd1, M, H, M, 0, 0,
                                nullptr, rd, stream));
   RUN(mvptr_gemm_nt_rows(s.x1, H, w->w_i, H, M, I, H, d->stash_bf16 ? MVPTR_EPI_BIAS_GELU_BF16 : MVPTR_EPI_BIAS_GELU, w->b_i, nullptr, 0, s.u, s.a, I,
-                         nullptr, nullptr, rd, Mp, stream));
+                         nullptr, nullptr, rd, Mp, stream, d->beside));
   RUN(mvptr_gemm_nt_rows(s.a, I, w->w_out, I, M, H, I, MVPTR_EPI_BIAS_RESID, w->b_out, s.x1, H, s.z2,
-                         nullptr, H, nullptr, &dr_out, rd, Mp, stream));
+                         nullptr, H, nullptr, &dr_out, rd, Mp, stream, d->beside));
   RUN(mvptr_layernorm_fwd_rows(s.z2, w->ln2_g, w->ln2_b, d->eps, y, s.mean2, s.rstd2, M, H, M, 0, 0,
                                nullptr, rd, stream));
   return MVPTR_OK;
@@ -214,14 +214,14 @@ int layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w, const voi
   // problem that reads dU anyway
   const bool bi_rides = defer && g->w_i != nullptr;
   RUN(mvptr_gemm_nt_rows(d2, H, w->w_out_t, H, M, I, H, d->stash_bf16 ? MVPTR_EPI_GELU_BWD_BF16 : MVPTR_EPI_GELU_BWD, nullptr, s.u, I, bufU, nullptr,
-                         I, bi_rides ? nullptr : g->b_i, nullptr, rd, Mp, stream));
+                         I, bi_rides ? nullptr : g->b_i, nullptr, rd, Mp, stream, d->beside));
   // intermediate.dense; the two FFN weight gradients go out together while d2 / dU are still warm
   // in the Infinity Cache
   if (g->w_i) add_wgrad(bufU, I, s.x1, H, I, H, g->w_i, bi_rides ? g->b_i : nullptr);
   if (nwg > 0) RUN(mvptr_gemm_tn_multi_rows(wg, nwg, slabws_bytes ? slabws : nullptr, slabws_bytes, rd, Mp, stream));
   nwg = 0;
   RUN(mvptr_gemm_nt_rows(bufU, I, w->w_i_t, I, M, H, I, MVPTR_EPI_ADD, nullptr, bufA, H, bufC, nullptr, H,
-                         nullptr, nullptr, rd, Mp, stream));
+                         nullptr, nullptr, rd, Mp, stream, d->beside));
   // attention.output.LayerNorm / dense
   RUN(mvptr_layernorm_bwd_partial(bufC, s.z1, s.mean1, s.rstd1, w->ln1_g, bufD, hdrop ? bufE : nullptr,
                                   g->ln1_g, g->ln1_b, g->b_o, M, H, M, 0, 0, nullptr,
@@ -230,7 +230,7 @@ int layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w, const voi
   const char* d1 = hdrop ? bufE : bufD;
   if (g->w_o) add_wgrad(d1, H, s.ctx, H, H, H, g->w_o, nullptr);
   RUN(mvptr_gemm_nt_rows(d1, H, w->w_o_t, H, M, H, H, MVPTR_EPI_ADD, nullptr, nullptr, 0, bufC, nullptr, H,
-                         nullptr, nullptr, rd, Mp, stream));
+                         nullptr, nullptr, rd, Mp, stream, d->beside));
   // attention core
   RUN(mvptr_attention_bwd_packed(s.qkv, mask_add, s.ctx, bufC, s.lse, bufQ, d->seq_start, d->seq_len, d->B,
                                  d->L, d->heads, &dr_attn, stream));
@@ -242,7 +242,7 @@ int layer_bwd(const mvptr_layer_desc* d, const mvptr_layer_weights* w, const voi
     RUN(mvptr_colsum(bufQ, 3 * H, M, 3 * H, g->b_qkv, stream));
   }
   RUN(mvptr_gemm_nt_rows(bufQ, 3 * H, w->w_qkv_t, 3 * H, M, H, 3 * H, MVPTR_EPI_ADD, nullptr, bufD, H, dx,
-                         nullptr, H, nullptr, nullptr, rd, Mp, stream));
+                         nullptr, H, nullptr, nullptr, rd, Mp, stream, d->beside));
   // largest problem first: the exposed atomic write-out at the end of the launch is then the small one's
   if (nwg == 2 && (int64_t)wg[0].N * wg[0].K < (int64_t)wg[1].N * wg[1].K) {
     const mvptr_tn_problem t = wg[0];

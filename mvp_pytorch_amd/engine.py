@@ -506,6 +506,9 @@ class EncoderMeta:
         # gelu'(u) stash of the FFN: 8-bit fixed point (default) or bf16 (config.gelu_stash = "bf16": the format of rounds 1-3,
         # for reference-numerics runs and A/B runs; set by the encoder module)
         self.stash_bf16 = GELU_STASH_BF16
+        # another stack's GEMMs run beside this one on a second stream (the two uni-modal stacks of the two-stage model): the
+        # GEMM tiles keep their full height (mvptr_layer_desc.beside); set by BiBertImgModel
+        self.beside = False
 
 
 # gelu'(u) stash format where no config says otherwise (LinearFn of the head transforms reads it too): False = 8-bit fixed
@@ -626,7 +629,7 @@ class EncoderFn(GradAwareFunction):
                               meta.seq_start.data_ptr() if meta.rows else None,
                               meta.seq_len.data_ptr() if meta.rows else None,
                               meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None,
-                              1 if getattr(meta, "stash_bf16", False) else 0, 0)
+                              1 if getattr(meta, "stash_bf16", False) else 0, 1 if getattr(meta, "beside", False) else 0)
             nbytes = lib.mvptr_layer_saved_bytes(ctypes.byref(d))
             if nbytes < 0:
                 hip._check(-1)

@@ -48,7 +48,7 @@ class LayerDesc(Structure):
                 ("eps", c_float), ("training", c_int), ("p_hidden16", c_uint32),
                 ("p_attn16", c_uint32), ("seed", c_uint64),
                 ("M", c_int), ("M_plan", c_int), ("seq_start", c_void_p), ("seq_len", c_void_p), ("rows_dev", c_void_p),
-                ("stash_bf16", c_int), ("pad_", c_int)]
+                ("stash_bf16", c_int), ("beside", c_int)]
 
 
 class LayerWeights(Structure):

@@ -186,11 +186,13 @@ class CaptionBertEncoder(nn.Module):
                 meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, lmax, Hc, heads, I, eps, self.training, l0.output.dropout.p,
                                           l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
                 meta.stash_bf16 = self.gelu_stash_bf16
+                meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
                 y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
                 return (engine.UnpackRows.apply(y, idx, B * L).view(B, L, H),)
         meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         meta.stash_bf16 = self.gelu_stash_bf16
+        meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
 
@@ -205,6 +207,7 @@ def _run_layers(self, hidden_states, attention_mask, first, count):
                               l0.output.dropout.p, l0.attention.self.dropout.p, first=first, count=count,
                               all_params=self._flat_params())
     meta.stash_bf16 = self.gelu_stash_bf16
+    meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
     y = engine.EncoderFn.apply(x, attention_mask.contiguous(), meta, *self._flat_params()[16 * first:16 * (first + count)])
     return y.view(B, L, H)
 
@@ -223,6 +226,7 @@ def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax, rows_dev=None, 
                               l0.output.dropout.p, l0.attention.self.dropout.p, seq_start=seq_start, seq_len=seq_len,
                               rows=x_rows.shape[0], rows_dev=rows_dev, rows_plan=rows_plan)
     meta.stash_bf16 = self.gelu_stash_bf16
+    meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
     return engine.EncoderFn.apply(x_rows, None, meta, *self._flat_params())
 
 
@@ -333,6 +337,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         mask_a = additive_mask(attention_mask_a)
         mask_b = additive_mask(attention_mask_b)
         two_streams = bool(self.parallel_stacks) and input_ids_a.is_cuda and _streams_allowed(self.parallel_stacks)
+        self.txt_encoder._beside = self.vis_encoder._beside = two_streams      # tile-height hint of their GEMMs (mvptr_layer_desc.beside)
         prefetch = two_streams and self.training and torch.is_grad_enabled() and self.prefetch_weights
         if prefetch:
             # training rebuilds the bf16 weight copies of every stack each forward pass (one ~0.1-ms launch per stack):
@@ -555,6 +560,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         # built) or read back from the device behind the embedding kernels
         counts = None if host_counts is not None else engine.AsyncCounts([cnt_a[0], cnt_a[1], cnt_b[0], cnt_b[1]])
         two_streams = bool(self.parallel_stacks) and _streams_allowed(self.parallel_stacks)
+        self.txt_encoder._beside = self.vis_encoder._beside = two_streams
         main = torch.cuda.current_stream(dev)
         side = engine.side_stream(dev) if two_streams else None
         prefetch = two_streams and torch.is_grad_enabled() and self.prefetch_weights
