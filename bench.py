@@ -228,13 +228,18 @@ class DominantMix:
             nr = int(batch["input_mask_b"][:, dims["G"]:].sum())
             self.Ms = [na, nb, 2 * (na + nr)]
         r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)  # noqa: E731
+        # round 5: ONE balanced weight-gradient launch per encoder stack (mvptr_gemm_tn_stack): all layers' problems, every
+        # layer with operands of its own (6 x 24.6 KB per token row: they come from HBM, as in the step)
+        self.layers = 2 * (cfg["num_hidden_layers"] // 2) if single else cfg["num_hidden_layers"] // 2
         self.tn = []
         for M in self.Ms:
-            d2, a, dU, x1 = r(M, H), r(M, I), r(M, I), r(M, H)
-            d1, ctx, dqkv, x = r(M, H), r(M, H), r(M, 3 * H), r(M, H)
+            probs = []
             z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
-            self.tn.append(([(d2, a, z(H, I), None), (dU, x1, z(I, H), None)], 2.0 * M * 2 * H * I))
-            self.tn.append(([(d1, ctx, z(H, H), None), (dqkv, x, z(3 * H, H), z(3 * H))], 2.0 * M * 4 * H * H))
+            for _ in range(self.layers):
+                d2, a, dU, x1 = r(M, H), r(M, I), r(M, I), r(M, H)
+                d1, ctx, dqkv, x = r(M, H), r(M, H), r(M, 3 * H), r(M, H)
+                probs += [(d2, a, z(H, I), None), (dU, x1, z(I, H), z(I)), (d1, ctx, z(H, H), None), (dqkv, x, z(3 * H, H), z(3 * H))]
+            self.tn.append((probs, 2.0 * M * self.layers * (2 * H * I + 4 * H * H)))
         self.w = r(I, H)
         self.bias = torch.zeros(I, device=dev)
         self.nt = [(r(M, H), torch.empty(M, I, device=dev, dtype=torch.uint8),
@@ -271,7 +276,7 @@ class DominantMix:
         return self._nt_all
 
     def tn_launches(self):
-        return [((lambda probs=probs: self.hip.gemm_tn_multi(probs)), f) for probs, f in self.tn]
+        return [((lambda probs=probs: self.hip.gemm_tn_stack(probs)), f) for probs, f in self.tn]
 
     def nt_launches(self):
         return [((lambda x=x, u=u, a=a: self.hip.gemm_nt(x, self.w, self.hip.EPI_BIAS_GELU, bias=self.bias, out=u, out1=a)), f)
@@ -282,9 +287,8 @@ class DominantMix:
     def tn_bytes(self):
         H, I = self.H, self.I
         per = []
-        for M in self.Ms:
-            per.append(2.0 * M * (H + I) * 2 + 2 * H * I * 4)           # FFN pair: d2, a, dU, x1 ; dW_out, dW_i
-            per.append(2.0 * M * (H + H + 3 * H + H) + 4 * H * H * 4)   # attention pair
+        for M in self.Ms:      # per stack launch: every layer's d2, a, dU, x1, d1, ctx, dqkv, x once; dW_out, dW_i, dW_o, dW_qkv accumulated once
+            per.append(self.layers * (2.0 * M * (2 * (H + I) + 6 * H) + (2 * H * I + 4 * H * H) * 4))
         return sum(per) / len(per)
 
     def nt_bytes(self):
@@ -332,8 +336,7 @@ def _pmc_traffic(kernel, packed=True):
     by tools/runs/r02_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
     WRITE_SIZE, FETCH_SIZE calibrated on a known 1-GiB stream by tools/calib_fetch.py), or None."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(here, n) for n in ("r04_dominant_traffic.json", "r03_dominant_traffic.json", "r02_dominant_traffic.json")
-                 if os.path.exists(os.path.join(here, n))), os.path.join(here, "r04_dominant_traffic.json"))
+    path = os.path.join(here, "r05_dominant_traffic.json")      # made from this round's kernels only (older files describe other kernels)
     try:
         with open(path) as f:
             return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
@@ -357,17 +360,18 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     nt_hot_ms, _ = _time_launches(mix.nt_launches(), 4, cold=False)
     tn_ach = tn_flops / (tn_ms * 1e-3) / 1e12
     nt_ach = nt_flops / (nt_ms * 1e-3) / 1e12
-    t_tn, t_nt, t_fam = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_q_kernel", "gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernel (all epilogues)"))
+    t_tn, t_nt, t_fam = (_pmc_traffic(k, batch is not None) for k in ("gemm_tn_sk_kernel", "gemm_nt8_kernel<EPI_BIAS_GELU>", "gemm_nt8_kernel (all epilogues)"))
     fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
-    tn_entry = dict(kernel="gemm_tn_q_kernel<4> grouped weight gradients (dW[N,K] += dY[M,N]^T X[M,K]; FFN pair and attention pair per layer; "
-                           "256x256 tiles, four waves of 128x128; 36 launches per step)",
+    tn_entry = dict(kernel="gemm_tn_sk_kernel<4>: every weight gradient of an encoder stack in one balanced launch (dW[N,K] += dY[M,N]^T X[M,K]; "
+                           "%d problems per stack = %d layers x (FFN2, FFN1, attention output, Q/K/V); 256x256 tiles, four waves of 128x128, whole tiles per "
+                           "workgroup + equal runs over the left-over tiles; 3 launches per step)" % (4 * mix.layers, mix.layers),
                     achieved=round(tn_ach, 1), frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
                     avg_launch_us_back_to_back=round(tn_hot_ms * 1e3, 1), flop_per_launch=tn_flops,
                     algorithmic_bytes_per_launch=round(mix.tn_bytes()), traffic=(t_tn or {}).get("bytes_per_launch"))
     # The dominant kernel by total time is the gemm_nt_kernel FAMILY (every forward and data-gradient GEMM of the encoder
     # layers, 144 launches and ~half of the kernel time of a step; VERDICT r03: report it, not only the largest single
     # instantiation); the grouped weight-gradient kernel follows as second_kernel.
-    return dict(bound="mfma", kernel="gemm_nt_kernel<EPI, 64, 2, 2, 4, 8 | 6> family (256 x 256 tiles; 192 x 256 where the tile-height rule picks them): the 8 forward / data-gradient GEMMs of an encoder layer "
+    return dict(bound="mfma", kernel="gemm_nt8_kernel<EPI, MT> family (ping-pong loop, 256 x 256 x 64 tiles; 224 / 192 / 160-row tiles where a launch that owns the GPU saves >= 15 %% of its CU rounds): the 8 forward / data-gradient GEMMs of an encoder layer "
                                      "(Q/K/V, attention output, FFN1 + GELU, FFN2 and their data gradients; fused bias / residual / dropout / "
                                      "GELU epilogues) at M = %s rows, 144 launches per step" % " / ".join(str(m) for m in mix.Ms),
                 achieved=round(fam_ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
@@ -376,10 +380,10 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                        "resident operands): avg_launch_us_back_to_back",
                 avg_launch_us_back_to_back=round(fam_hot_ms * 1e3, 1), flop_per_launch=fam_flops, algorithmic_bytes_per_launch=round(fam_bytes),
                 traffic=(t_fam or {}).get("bytes_per_launch"), second_kernel=tn_entry,
-                traffic_source="profiles/r04_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                traffic_source="profiles/r05_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
                                "tools/prof_dominant.py; FETCH_SIZE divided by the factor measured on a known 1-GiB LDS-DMA stream, "
                                "tools/calib_fetch.py)",
-                ffn1_forward=dict(kernel="gemm_nt_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu in bf16 and gelu' as 8-bit fixed point; a member of the family)",
+                ffn1_forward=dict(kernel="gemm_nt8_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu in bf16 and gelu' as 8-bit fixed point; a member of the family)",
                                    achieved=round(nt_ach, 1), frac=round(nt_ach / MFMA_BF16_PEAK_TFLOPS, 4),
                                    avg_launch_us=round(nt_ms * 1e3, 1), avg_launch_us_back_to_back=round(nt_hot_ms * 1e3, 1),
                                    algorithmic_bytes_per_launch=round(mix.nt_bytes()),

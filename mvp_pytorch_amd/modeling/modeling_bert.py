@@ -253,8 +253,16 @@ class HeadLinear(nn.Linear):
 
     def forward(self, x, bias=None):
         b = self.bias if bias is None else bias
-        if x.is_cuda and x.dim() == 2 and self.weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16):
+        if x.is_cuda and self.weight.dtype == torch.float32:
+            # the product path: f32 parameters on a HIP device.  Anything it does not take raises instead of silently running a
+            # torch op; inputs of more than two dimensions are rows of a 2-D problem
+            if x.dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError("HeadLinear: the HIP path takes f32 or bf16 rows, got %s (f32 parameters on a HIP device)" % x.dtype)
+            if x.dim() != 2:
+                return engine.SmallLinearFn.apply(x.reshape(-1, x.shape[-1]), self.weight, b, None, False).reshape(x.shape[:-1] + (self.weight.shape[0],))
             return engine.SmallLinearFn.apply(x, self.weight, b, None, False)
+        # documented torch paths: model.half() inference (fp16 parameters) and CPU tensors (checkpoint
+        # surgery, host-logic tests) — never taken by f32 parameters on a HIP device
         return F.linear(x.to(self.weight.dtype), self.weight, b)
 
 

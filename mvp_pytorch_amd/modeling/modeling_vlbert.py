@@ -52,6 +52,8 @@ def instance_bce_with_logits(logits, labels, reduction="mean", pos_weight=None):
     if (reduction == "mean" and pos_weight is None and logits.is_cuda and logits.dtype == torch.float32 and labels.shape == logits.shape and
             not labels.requires_grad):
         return engine.BceLogitsFn.apply(logits, labels.to(torch.float32))     # mvptr_bce_logits: loss (x classes) + gradient
+    # torch path, on purpose: other reductions / pos_weight (not used by run_vqa.py), fp16 logits of model.half() inference, CPU
+    # tensors
     loss = F.binary_cross_entropy_with_logits(logits, labels, reduction=reduction, pos_weight=pos_weight)
     if reduction == "mean":
         loss = loss * labels.size(1)
@@ -419,6 +421,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         """normalize(cls @ proj) in f32 (vl:525-526; feeds the hard-negative argmax: kept out of bf16)."""
         if cls_rows.is_cuda and proj.dtype == torch.float32:
             return engine.L2NormFn.apply(engine.SmallLinearFn.apply(cls_rows, proj, None, None, True))
+        # documented torch paths only (INTEGRATION.md §1): fp16 parameters of model.half() inference, CPU tensors
         return F.normalize(cls_rows.float() @ proj.float(), p=2, dim=-1)
 
     @staticmethod

@@ -105,8 +105,17 @@ def embeddings(sd, prefix, input_ids, token_type_ids=None, position_ids=None, ep
     return layer_norm(e, sd[prefix + ".LayerNorm.weight"], sd[prefix + ".LayerNorm.bias"], eps)
 
 
-def self_attention(sd, prefix, x, ext_mask, heads):
-    """vl:63-103 (+ transpose_for_scores mb:299-303)."""
+def _apply_drop(t, drop):
+    """nn.Dropout with a given keep mask: drop = (keep 0/1 tensor broadcastable to t, 1 / (1 - p)) or None (identity)."""
+    if drop is None:
+        return t
+    keep, scale = drop
+    return t * keep.to(t.dtype) * scale
+
+
+def self_attention(sd, prefix, x, ext_mask, heads, drop=None):
+    """vl:63-103 (+ transpose_for_scores mb:299-303).  drop: keep mask [B, heads, L, L] + scale of the dropout on the
+    attention probabilities (vl:90), None = identity (the golden fixtures run with dropout 0)."""
     B, L, H = x.shape
     d = H // heads
 
@@ -117,29 +126,32 @@ def self_attention(sd, prefix, x, ext_mask, heads):
     k = split(linear(sd, prefix + ".key", x))
     v = split(linear(sd, prefix + ".value", x))
     scores = q @ k.transpose(-1, -2) / math.sqrt(d) + ext_mask
-    probs = torch.softmax(scores, dim=-1)
+    probs = _apply_drop(torch.softmax(scores, dim=-1), drop)
     ctx = (probs @ v).permute(0, 2, 1, 3).contiguous().view(B, L, H)
     return ctx
 
 
-def encoder_layer(sd, prefix, x, ext_mask, heads, eps):
+def encoder_layer(sd, prefix, x, ext_mask, heads, eps, drops=None):
     """vl:191-199 = attention vl:115-120 (+ BertSelfOutput mb:348-352), BertIntermediate
-    mb:394-397, BertOutput mb:407-411."""
-    ctx = self_attention(sd, prefix + ".attention.self", x, ext_mask, heads)
-    a = linear(sd, prefix + ".attention.output.dense", ctx)
+    mb:394-397, BertOutput mb:407-411.  drops: optional {"attn": ..., "attn_out": ..., "ffn_out": ...} keep masks (+ scale)
+    of the layer's three dropout sites (vl:90, mb:350, mb:409) for tests that replay a kernel's masks; None = identity."""
+    drops = drops or {}
+    ctx = self_attention(sd, prefix + ".attention.self", x, ext_mask, heads, drops.get("attn"))
+    a = _apply_drop(linear(sd, prefix + ".attention.output.dense", ctx), drops.get("attn_out"))
     a = layer_norm(a + x, sd[prefix + ".attention.output.LayerNorm.weight"],
                    sd[prefix + ".attention.output.LayerNorm.bias"], eps)
     i = gelu(linear(sd, prefix + ".intermediate.dense", a))
-    o = linear(sd, prefix + ".output.dense", i)
+    o = _apply_drop(linear(sd, prefix + ".output.dense", i), drops.get("ffn_out"))
     return layer_norm(o + a, sd[prefix + ".output.LayerNorm.weight"],
                       sd[prefix + ".output.LayerNorm.bias"], eps)
 
 
-def encoder(sd, prefix, n_layers, x, ext_mask, heads, eps, return_at_layer=None):
-    """vl:134-178 (single mask, head_mask None, no history states)."""
+def encoder(sd, prefix, n_layers, x, ext_mask, heads, eps, return_at_layer=None, drops=None):
+    """vl:134-178 (single mask, head_mask None, no history states).  drops: optional list of per-layer dropout masks
+    (encoder_layer)."""
     mid = None
     for i in range(n_layers):
-        x = encoder_layer(sd, "%s.layer.%d" % (prefix, i), x, ext_mask, heads, eps)
+        x = encoder_layer(sd, "%s.layer.%d" % (prefix, i), x, ext_mask, heads, eps, None if drops is None else drops[i])
         if return_at_layer is not None and i == return_at_layer:
             mid = x
     return (x, mid) if return_at_layer is not None else x

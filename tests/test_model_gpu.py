@@ -1034,6 +1034,29 @@ def test_configs4_vqa_shape_vs_oracle(dev):
     out = model(labels=labels.to(dev), **kw(bd, 64))
     out[0].backward()
     assert torch.isfinite(model.cls.predictions.decoder.weight.grad).all()
+    # the BACKWARD pass at this shape against the oracle on the 6-question subset (dropout 0): the
+    # 3129-way decoder weight and bias, the head transform, one encoder weight of each stack and the region embedding
+    model.zero_grad(set_to_none=True)
+    out6 = model(labels=labels[:6].to(dev), **kw(bd, 6))
+    out6[0].backward()
+    torch.cuda.synchronize()
+    sdg = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rl, _ = orc.bi_vqa(sdg, cfg, labels=labels[:6], **kw(b, 6))
+    rl.backward()
+    assert abs(out6[0].item() - rl.item()) / rl.item() < LOSS_RTOL
+    names = ["cls.predictions.decoder.weight", "cls.predictions.bias", "cls.predictions.transform.dense.weight",
+             "bert.txt_encoder.layer.5.output.dense.weight", "bert.vis_encoder.layer.0.attention.self.query.weight",
+             "bert.mul_encoder.layer.3.intermediate.dense.weight", "bert.mul_encoder.layer.0.attention.output.dense.weight",
+             "bert.img_embedding.weight"]
+    pd = dict(model.named_parameters())
+    worst = 0.0
+    for n in names:
+        assert pd[n].grad is not None and sdg[n].grad is not None, n
+        e = _rel(pd[n].grad, sdg[n].grad)
+        print("configs[4] gradient", n, "rel L2 vs oracle", e)
+        worst = max(worst, e)
+    check_measured("configs4:vqa_grad", max(worst, 1e-9), 6e-2)
 
 
 # ------------------------------------------------------------------------------ round-3 additions
@@ -1399,3 +1422,89 @@ def test_gelu_stash_formats_agree(dev):
                 not n.endswith("attention.self.key.bias"))
     print("gelu' stash u8 vs bf16: worst gradient rel L2", worst)
     assert worst[0] < 1.5e-2, worst
+
+
+def test_encoder_stack_with_dropout_matches_oracle_with_replayed_masks(dev):
+    """the timed step runs with dropout 0.1, the reference fixtures with dropout 0.  Here a row-packed
+    BERT-base encoder stack (2 layers, sequences of 20 - 110 rows) runs in training mode with dropout 0.1 at its three sites
+    per layer (attention probabilities vl:90, attention-output dense mb:350, FFN-output dense mb:409); the per-layer seeds are
+    pinned, the kernels' own keep masks are materialised with mvptr_dropout_mask (element indices as include/mvptr.h documents
+    them: m * H + n on the packed rows, ((seq * heads + h) * Lmax + q) * Lp + key for the probabilities) and fed to the oracle's
+    encoder: same outputs on the valid rows, same input / weight gradients to bf16 accuracy — i.e. dropout is applied to the
+    right elements with the right scale, in the forward AND the backward pass (regenerated, not stored)."""
+    from mvp_pytorch_amd import engine, hip, modeling
+    layers, heads, H = 2, 12, 768
+    p_drop = 0.1
+    cfg = dict(gu.BASE_CFG, num_hidden_layers=layers, hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop)
+    torch.manual_seed(0)
+    enc = modeling.modeling_vlbert.CaptionBertEncoder(modeling.make_config(cfg)).to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(20, 111, (9,), generator=g)
+    B, lmax, rows = lens.numel(), int(lens.max()), int(lens.sum())
+    starts = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+    x = (torch.randn(rows, H, generator=g) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(rows, H, generator=g) * 0.1).to(torch.bfloat16)
+    seeds = [0x1234567812345678 + 977 * i for i in range(layers)]
+    it = iter(seeds)
+    orig = engine.next_seed
+    engine.next_seed = lambda: next(it)
+    try:
+        xin = x.to(dev).requires_grad_(True)
+        y = enc.forward_rows(xin, starts.to(dev), lens.to(torch.int32).to(dev), B, lmax)
+        y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        engine.next_seed = orig
+
+    # the kernels' masks: layer.hip site_drop(seed, site): site 0 attention probabilities, 1 attention output, 2 FFN output
+    def site(seed, k):
+        d = hip.Dropout()
+        d.seed_lo = ((seed & 0xffffffff) ^ ((0x9E3779B9 * (k + 1)) & 0xffffffff)) & 0xffffffff
+        d.seed_hi = ((seed >> 32) + 0x85EBCA6B * (k + 1)) & 0xffffffff
+        d.thresh16 = int(round(p_drop * 65536.0))
+        d.pad_ = 0
+        return d
+
+    scale = 65536.0 / (65536.0 - int(round(p_drop * 65536.0)))
+    Lp = (lmax + 31) // 32 * 32
+    pad_idx = torch.cat([torch.arange(int(n)) + b * lmax for b, n in enumerate(lens.tolist())])       # packed row -> slot of [B, lmax]
+    drops = []
+    for s in seeds:
+        attn = hip.dropout_mask(site(s, 0), B * heads * lmax * Lp, dev).reshape(B, heads, lmax, Lp)[..., :lmax].float().cpu()
+        dense = []
+        for k in (1, 2):
+            keep_rows = hip.dropout_mask(site(s, k), rows * H, dev).reshape(rows, H).float().cpu()
+            keep = torch.ones(B * lmax, H)
+            keep[pad_idx] = keep_rows
+            dense.append(keep.view(B, lmax, H))
+        drops.append({"attn": (attn, scale), "attn_out": (dense[0], scale), "ffn_out": (dense[1], scale)})
+        assert abs(float(attn.mean()) - 0.9) < 0.01 and abs(float(dense[0].view(-1, H)[pad_idx].mean()) - 0.9) < 0.01
+    # oracle on the padded layout, f32, bf16-rounded weights (what the kernels multiply with)
+    sd = {"enc." + k: v.detach().float().cpu().to(torch.bfloat16).float().requires_grad_(True) if v.dim() == 2 else v.detach().float().cpu().requires_grad_(True)
+          for k, v in enc.state_dict().items()}
+    xp = torch.zeros(B * lmax, H)
+    xp[pad_idx] = x.float()
+    xp = xp.view(B, lmax, H).requires_grad_(True)
+    mask = torch.zeros(B, lmax, dtype=torch.long)
+    for b, n in enumerate(lens.tolist()):
+        mask[b, :n] = 1
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    yo = orc.encoder(sd, "enc", layers, xp, orc.extended_mask(mask), heads, cfg["layer_norm_eps"], drops=drops)
+    dyp = torch.zeros(B * lmax, H)
+    dyp[pad_idx] = dy.float()
+    yo.backward(dyp.view(B, lmax, H))
+    e_y = _rel(y.detach().float().cpu(), yo.detach().view(-1, H)[pad_idx])
+    e_dx = _rel(xin.grad.float().cpu(), xp.grad.view(-1, H)[pad_idx])
+    print("dropout replay: y rel L2 %.4f, dx rel L2 %.4f" % (e_y, e_dx))
+    assert e_y < 8e-3 and e_dx < 2.5e-2, (e_y, e_dx)
+    worst = 0.0
+    for n, p in enc.named_parameters():
+        if n.endswith("attention.self.key.bias"):
+            continue
+        e = _rel(p.grad.float().cpu(), sd["enc." + n].grad)
+        worst = max(worst, e)
+        assert e < 4e-2, (n, e)
+    print("dropout replay: worst weight-gradient rel L2 %.4f" % worst)
+    # and the masks matter: without them the oracle is far away
+    y0 = orc.encoder({k: v.detach() for k, v in sd.items()}, "enc", layers, xp.detach(), orc.extended_mask(mask), heads, cfg["layer_norm_eps"])
+    assert _rel(y.detach().float().cpu(), y0.view(-1, H)[pad_idx]) > 5 * e_y

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
-"""profiles/rNN_roofline.json: the dominant kernel's roofline numbers recomputed from the rocprofv3
-kernel summaries of tools/prof_dominant.py (launch mix of one step) and the PMC traffic file:
+"""profiles/rNN_roofline.json (round 5 kernels): roofline numbers of the two GEMM kernels that lead a step, recomputed from the
+rocprofv3 kernel summaries of tools/prof_dominant.py (replay of one step's launches) and the PMC traffic file:
     roofline_json.py OUT.json MIX_PACKED_STATS.csv MIX_FULL_STATS.csv TRAFFIC.json [BENCH_PACKED_STATS.csv BENCH_FIXED_STATS.csv]
-With the two optional kernel summaries of bench.py's timed region the IN-STEP figures (same kernel between the
-step's other kernels, operands from HBM) are reported beside the replay figures."""
+With the two optional kernel summaries of bench.py's timed region the IN-STEP figures (same kernels between the step's other
+kernels) are reported beside the replay figures."""
 import csv
 import json
 import sys
 
-H, I = 768, 3072
+H, I, LAYERS = 768, 3072, 6
 PEAK = 2500.0
 out, packed_csv, full_csv, traffic = sys.argv[1:5]
 bench_csv = {"row_packed_batch": sys.argv[5] if len(sys.argv) > 5 else None, "all_slots_valid": sys.argv[6] if len(sys.argv) > 6 else None}
@@ -16,8 +16,7 @@ tr = json.load(open(traffic))
 
 
 def avg_us(path, frag):
-    """mean duration and call count over EVERY kernel whose name contains frag (template variants of one kernel —
-    gemm_tn_q_kernel<4, false> / <4, true> — are one row each in the summary)"""
+    """mean duration and call count over EVERY kernel whose name contains frag (template variants are one row each)"""
     tot, calls = 0.0, 0
     for r in csv.DictReader(open(path)):
         if any(f in r["Name"] for f in ((frag,) if isinstance(frag, str) else frag)):
@@ -26,43 +25,13 @@ def avg_us(path, frag):
     return (tot / calls, calls) if calls else (None, 0)
 
 
-def mix(Ms):
-    fl, by = [], []
-    for M in Ms:
-        fl += [2.0 * M * 2 * H * I, 2.0 * M * 4 * H * H]
-        by += [2.0 * M * (H + I) * 2 + 2 * H * I * 4, 2.0 * M * (H + H + 3 * H + H) + 4 * H * H * 4]
+def tn_mix(Ms):
+    """one stack launch per row count: six layers x (FFN2, FFN1, attention output, Q/K/V) weight gradients"""
+    fl = [2.0 * M * LAYERS * (2 * H * I + 4 * H * H) for M in Ms]
+    by = [LAYERS * (2.0 * M * (2 * (H + I) + 6 * H) + (2 * H * I + 4 * H * H) * 4) for M in Ms]
     return sum(fl) / len(fl), sum(by) / len(by)
 
 
-res = {"_what": "gemm_tn_q_kernel<4, slab?> (grouped weight gradients, 36 launches per step; atomic write-out for the joint stack, per-split slabs + tn_reduce_kernel for the text / visual stacks), mean over the step's launch mix; "
-                "duration = rocprofv3 --kernel-trace --stats AverageNs of tools/prof_dominant.py, gemm_tn_q_kernel + the tn_reduce_kernel "
-                "that sums its per-split slabs (one launch = both); FLOPs = 2MNK summed over the "
-                "problems of a launch; algorithmic bytes = operands read once + f32 outputs accumulated once; peak = 2500 TFLOP/s "
-                "dense bf16 MFMA (MI355X_MICROARCH.md)",
-       "peak_tflops": PEAK}
-rows_packed = tr.get("row_packed_batch", {}).get("rows_per_launch_group", [10917, 11143, 37748])
-for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
-    us, calls = avg_us(path, "gemm_tn_q_kernel")
-    us_red, calls_red = avg_us(path, "tn_reduce_kernel")   # second kernel of the same launch (slab write-out)
-    if us and us_red:
-        us += us_red * calls_red / calls
-    flop, alg = mix(Ms)
-    t = tr.get(key, {}).get("gemm_tn_q_kernel", {})
-    res[key] = {"rows_per_launch_group": Ms, "avg_launch_us": us, "of_which_reduce_kernel_us": (us_red * calls_red / calls) if us_red else 0.0,
-                "launches_profiled": calls, "flop_per_launch": flop,
-                "achieved_tflops": flop / us / 1e6 if us else None, "frac_of_peak": flop / us / 1e6 / PEAK if us else None,
-                "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
-                "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
-    if bench_csv[key]:
-        us_in, calls_in = avg_us(bench_csv[key], "gemm_tn_q_kernel")
-        red_in, red_calls = avg_us(bench_csv[key], "tn_reduce_kernel")
-        if us_in and red_in:
-            us_in += red_in * red_calls / calls_in      # the reduce kernel of the slab launches belongs to its launch
-        if us_in:
-            res[key]["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
-                                   "frac_of_peak": flop / us_in / 1e6 / PEAK,
-                                   "source": "rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3 --no-extras (timed region + warm-up)"}
-# the gemm_nt_kernel family (every forward / data-gradient GEMM of the encoder layers: 8 shapes x 3 row counts in the replay)
 def nt_mix(Ms):
     fl, by = [], []
     for M in Ms:
@@ -72,22 +41,32 @@ def nt_mix(Ms):
     return sum(fl) / len(fl), sum(by) / len(by)
 
 
-res["gemm_nt_family"] = {"_what": "gemm_nt_kernel<EPI, 64, 2, 2, 4, 8 | 6> (256 x 256 tiles; 192 x 256 where launch()'s tile-height rule picks them): the eight forward / data-gradient GEMMs of an encoder layer with their fused "
-                                  "epilogues, mean over the 24 launches of the replay (8 shapes x 3 row counts); in_step: every gemm_nt_kernel of the "
-                                  "traced training steps with those tile configurations (the layers' 144 launches per step + the region-embedding GEMM)"}
+rows_packed = tr.get("row_packed_batch", {}).get("rows_per_launch_group", [10917, 11143, 37748])
+res = {"peak_tflops": PEAK,
+       "gemm_nt8_family": {"_what": "gemm_nt8_kernel<EPI, MT> (ping-pong loop, 256 x 256 x 64 tiles, shorter tiles by the CU-rounds rule): the eight forward / "
+                                    "data-gradient GEMMs of an encoder layer with their fused epilogues, mean over the 24 launches of the replay (8 shapes x 3 row "
+                                    "counts; tools/prof_dominant.py under rocprofv3 --kernel-trace --stats); in_step: every gemm_nt8_kernel of the traced training "
+                                    "steps (the layers' 144 launches per step); FLOPs = 2MNK; algorithmic bytes = operands once + every [M, N] matrix the "
+                                    "epilogue moves once (8-bit stash = half); peak = 2500 TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)"},
+       "gemm_tn_stack": {"_what": "gemm_tn_sk_kernel<4>: every weight gradient of an encoder stack in one balanced launch (24 problems = 6 layers x 4; 3 launches "
+                                  "per step, one per stack), mean over the step's three launches; FLOPs = 2MNK summed over the problems; algorithmic bytes = "
+                                  "every operand once + the f32 results accumulated once"}}
 for key, path, Ms in (("row_packed_batch", packed_csv, rows_packed), ("all_slots_valid", full_csv, [19200, 17920, 64000])):
-    us, calls = avg_us(path, "gemm_nt_kernel")
-    flop, alg = nt_mix(Ms)
-    t = tr.get(key, {}).get("gemm_nt_kernel (all epilogues)", {})
-    ent = {"avg_launch_us": us, "launches_profiled": calls, "flop_per_launch": flop, "achieved_tflops": flop / us / 1e6 if us else None,
-           "frac_of_peak": flop / us / 1e6 / PEAK if us else None, "algorithmic_bytes_per_launch": alg,
-           "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
-           "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
-    if bench_csv[key]:
-        us_in, calls_in = avg_us(bench_csv[key], ("64, 2, 2, 4, 8, 0>", "64, 2, 2, 4, 6, 0>"))   # 256- and 192-row tiles of the layer GEMMs
-        if us_in:
-            ent["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
-                              "frac_of_peak": flop / us_in / 1e6 / PEAK}
-    res["gemm_nt_family"][key] = ent
+    for name, frag, mixf, tkey in (("gemm_nt8_family", "gemm_nt8_kernel", nt_mix, "gemm_nt8_kernel (all epilogues)"),
+                                   ("gemm_tn_stack", "gemm_tn_sk_kernel", tn_mix, "gemm_tn_sk_kernel")):
+        us, calls = avg_us(path, frag)
+        flop, alg = mixf(Ms)
+        t = tr.get(key, {}).get(tkey, {})
+        ent = {"rows_per_launch_group": Ms, "avg_launch_us": us, "launches_profiled": calls, "flop_per_launch": flop,
+               "achieved_tflops": flop / us / 1e6 if us else None, "frac_of_peak": flop / us / 1e6 / PEAK if us else None,
+               "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch_pmc": t.get("bytes_per_launch"),
+               "traffic_over_algorithmic": (t.get("bytes_per_launch") / alg) if t.get("bytes_per_launch") else None}
+        if bench_csv[key]:
+            us_in, calls_in = avg_us(bench_csv[key], frag)
+            if us_in:
+                ent["in_step"] = {"avg_launch_us": us_in, "launches_profiled": calls_in, "achieved_tflops": flop / us_in / 1e6,
+                                  "frac_of_peak": flop / us_in / 1e6 / PEAK,
+                                  "source": "rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3 --no-extras (timed region + warm-up)"}
+        res[name][key] = ent
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -41,8 +41,11 @@ res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
 for key, fd, wd in (("row_packed_batch", pf, pw), ("all_slots_valid", ff, fw)):
     fa, wa = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     ent = {}
-    for name, frag in (("gemm_tn_q_kernel", "gemm_tn_q_kernel"), ("gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernelILi1E"), ("gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernel<1,"),
-                       ("gemm_nt_kernel (all epilogues)", "gemm_nt_kernel")):
+    for name, frag in (("gemm_tn_q_kernel", "gemm_tn_q_kernel"), ("gemm_tn_sk_kernel", "gemm_tn_sk_kernel"),
+                       ("gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernelILi1E"), ("gemm_nt_kernel<EPI_BIAS_GELU>", "gemm_nt_kernel<1,"),
+                       ("gemm_nt_kernel (all epilogues)", "gemm_nt_kernel"),
+                       ("gemm_nt8_kernel<EPI_BIAS_GELU>", "gemm_nt8_kernelILi1E"), ("gemm_nt8_kernel<EPI_BIAS_GELU>", "gemm_nt8_kernel<1,"),
+                       ("gemm_nt8_kernel (all epilogues)", "gemm_nt8_kernel")):
         f, w = pick(fa, frag), pick(wa, frag)
         if not f or not w:
             continue
