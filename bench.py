@@ -727,6 +727,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    host_ms = [0.0]
+
     def timed(b, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
         loss = None
@@ -736,6 +738,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
+        host_ms[0] = (time.perf_counter() - t0) / steps * 1e3      # every launch of the K steps is queued: the host's share of a step
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -749,6 +752,7 @@ def main():
     n_text = int((lab_a > -1).sum().item())   # the heads run on the scored rows only
     n_tag = 0 if single else int((batch["lm_label_ids_b"] > -1).sum().item())
     ms_per_step, loss = timed(batch, args.warmup, args.steps)
+    host_enqueue_ms = host_ms[0]
     value = world * args.batch / (ms_per_step * 1e-3)
 
     # N > 1: what the ranks saw, what the exchange costs, and a second timed leg with the data-parallel opt-ins:
@@ -870,6 +874,9 @@ def main():
                                   "variable (SURVEY 8d: tokens U{8..68}, phrases U{0..5}, tags U{3..18}, regions U{10..50})",
                        "valid_slot_fraction": valid, "padded_slots_computed": False,
                        "all_slots_valid": full, "with_input_pipeline": piped, "max_grad_norm": args.max_grad_norm,
+                       # wall time the host needs to queue one step's launches (the timed K steps, before the closing fence):
+                       # the step is GPU-bound while this stays below ms_per_step
+                       "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
                        "data_parallel": dp_info},
             "roofline": roof,
         }

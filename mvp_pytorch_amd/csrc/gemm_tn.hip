@@ -640,7 +640,7 @@ struct TnSkProb {      // 64 bytes
   int tile_base;       // first linear tile index of this problem
 };
 struct TnSkArgs {
-  int count, tiles_total, M, pad_;
+  int count, tiles_total, M, flat_rem;
   const int* rows_dev;
   TnSkProb prob[MVPTR_TN_STACK_MAX];
 };
@@ -791,9 +791,19 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
     }
   };
 
-  // remainder tiles: this workgroup's run of steps [b0, b1) of the (tile, step) list
+  // Remainder tiles (fewer than G): shared out per XCD so that the workgroups of one XCD sweep THE SAME ROWS of neighbouring tiles
+  // at the same time (their operand panels then meet in that XCD's L2, as in the full rounds).  XCD x owns a contiguous run of
+  // n_x remainder tiles and W of the G workgroups.  Phase by phase: S = the smallest divisor of W that is >= W / (tiles left);
+  // the next W / S tiles are each cut into S equal row ranges; workgroup l takes tile l % (W / S), range l / (W / S).  n_x / W of
+  // a tile's sweep per workgroup in total (17 / 32 = 1/2 + 1/32: two phases), every XCD within one S-th of a tile of the others.
+  const int NX = G < 8 ? G : 8;
+  const int xcd = (int)blockIdx.x % NX, lw = (int)blockIdx.x / NX;
+  const int W = G / NX + (xcd < G % NX ? 1 : 0);
+  int n_left = rem / NX + (xcd < rem % NX ? 1 : 0);
+  int cursor = R * G + xcd * (rem / NX) + min(xcd, rem % NX);
+  // diagnostic A/B (MVPTR_NT_EXP bit 11): the round-5a schedule — one run of steps [b0, b1) of the flat (tile, step) list per workgroup
   long long b0 = 0, b1 = 0;
-  if (rem > 0) {
+  if (args.flat_rem && rem > 0) {
     const long long tot = (long long)rem * spt;
     b0 = tot * g / G;
     b1 = tot * (g + 1) / G;
@@ -806,13 +816,27 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
       s0 = 0;
       s1 = spt;
       ++it;
-    } else {
+    } else if (args.flat_rem) {
       if (b0 >= b1) return false;
       const int ti = (int)(b0 / spt);
       s0 = (int)(b0 - (long long)ti * spt);
       s1 = (int)min((long long)spt, (long long)s0 + (b1 - b0));
       t = R * G + ti;
       b0 += s1 - s0;
+    } else {
+      for (;;) {
+        if (n_left <= 0) return false;
+        int S = (W + n_left - 1) / n_left;
+        while (W % S) ++S;
+        const int tp = W / S;
+        const int ti = lw % tp, sp = lw / tp;
+        t = cursor + ti;
+        s0 = (int)((long long)spt * sp / S);
+        s1 = (int)((long long)spt * (sp + 1) / S);
+        cursor += tp;
+        n_left -= tp;
+        if (s1 > s0) break;
+      }
     }
     t = __builtin_amdgcn_readfirstlane(t);
     s0 = __builtin_amdgcn_readfirstlane(s0);
@@ -1308,6 +1332,7 @@ extern "C" int mvptr_gemm_tn_stack(const mvptr_tn_problem* probs, int count, con
       a.prob[i].tile_base = 0x7fffffff;
     }
     a.tiles_total = base;
+    a.flat_rem = (mvptr_knobs().nt_exp & (1 << 11)) ? 1 : 0;      // diagnostic build only (the product's knobs are constants)
     hipLaunchKernelGGL((gemm_tn_sk_kernel<STAGES>), dim3(G), dim3(256), lds_b, (hipStream_t)stream, a);
     MVPTR_CHECK_LAUNCH("gemm_tn_stack");
   }

@@ -46,6 +46,8 @@ MEASURED = {
     # reference's 5-tuple fixtures, 8-bit gelu' stash and sync-free joint pass included
     "tiny_bi_pretrain_nophrase:train_gnorm": 0.0040, "tiny_bi_pretrain_nophrase:train_grad": 0.0178,
     "cfg1_bi_pretrain_nophrase:train_gnorm": 0.0228, "cfg1_bi_pretrain_nophrase:train_grad": 0.0273,
+    # round 5 (profiles/r05_parity_values.txt): backward pass at the configs[4] shape against the oracle (6-question subset)
+    "configs4:vqa_grad": 0.0194,
 }
 
 

@@ -22,13 +22,15 @@ ap.add_argument("--steps", type=int, default=3000)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--window", type=int, default=100)
 ap.add_argument("--pool", type=int, default=48)
+ap.add_argument("--runs", type=int, default=3, help="independent runs per format (their dropout / draw seeds differ: the spread between runs of ONE "
+                                                   "format is the scale against which the difference between the formats is read)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 dims = dict(B=args.batch, T=70, P=5, G=20, R=50)
 pool = [synthetic_batch(dims, bench.BASE_CFG, 5000 + i, device=dev) for i in range(args.pool)]
 
 
-def run(fmt):
+def run(fmt, seed_off=0):
     torch.manual_seed(0)
     engine._seed_counter[0] = 0x5DEECE66D
     model = modeling.BiBertImgForPreTraining(modeling.make_config(dict(bench.BASE_CFG, gelu_stash=fmt))).to(dev).train()
@@ -37,28 +39,30 @@ def run(fmt):
     tot = torch.zeros(args.steps, device=dev)
     t0 = time.time()
     for s in range(args.steps):
-        torch.manual_seed(10_000 + s)          # same hard-negative permutation / WRA draws / dropout seeds in every run
+        torch.manual_seed(10_000 + s + 1_000_003 * seed_off)   # same hard-negative permutation / WRA draws / dropout seeds in both formats of a run
         losses = train.pretrain_step(model, pool[s % len(pool)], opt, sched, max_tag_length=dims["G"], return_losses=True,
                                      grad_sync=sync, max_grad_norm=10.0)
         tot[s] = losses[0]
     torch.cuda.synchronize()
     sync.close()
     curve = tot.view(-1, args.window).mean(1).cpu()
-    print("%-5s %d steps in %.1f s; window means: %s" % (fmt, args.steps, time.time() - t0, " ".join("%.4f" % v for v in curve.tolist())), flush=True)
+    print("%-5s run %d: %d steps in %.1f s; window means: %s" % (fmt, seed_off, args.steps, time.time() - t0, " ".join("%.4f" % v for v in curve.tolist())), flush=True)
     del model, opt, sync
     torch.cuda.empty_cache()
     return curve
 
 
 assert args.steps % args.window == 0
-c16 = run("bf16")
-c8 = run("u8")
-c16b = run("bf16")
-d8 = (c8 - c16).abs()
-dd = (c16b - c16).abs()
-k = max(1, len(c16) // 5)
-print("u8 - bf16    : max |diff of window means| %.4f, mean %.4f, last fifth of the run: %.4f -> relative to the loss %.2e"
-      % (d8.max(), d8.mean(), d8[-k:].mean(), float(d8[-k:].mean() / c16[-k:].mean())))
-print("bf16 - bf16  : max |diff of window means| %.4f, mean %.4f, last fifth of the run: %.4f (run-to-run scale: same format twice)"
-      % (dd.max(), dd.mean(), dd[-k:].mean()))
-print("final window means: bf16 %.4f, u8 %.4f, bf16 again %.4f" % (c16[-1], c8[-1], c16b[-1]))
+curves = {"bf16": [], "u8": []}
+for r in range(args.runs):
+    for fmt in ("bf16", "u8"):
+        curves[fmt].append(run(fmt, r))
+k = max(1, len(curves["u8"][0]) // 5)
+for fmt in ("bf16", "u8"):
+    fin = torch.stack([c[-k:].mean() for c in curves[fmt]])
+    mid = torch.stack([c[len(c) // 2 - 1:len(c) // 2 + 1].mean() for c in curves[fmt]])
+    print("%-5s mean total loss over the last fifth of the run, per run: %s -> mean %.4f, std %.4f; at mid-run: mean %.4f, std %.4f"
+          % (fmt, " ".join("%.4f" % v for v in fin.tolist()), fin.mean(), fin.std(unbiased=True) if len(fin) > 1 else 0.0, mid.mean(),
+             mid.std(unbiased=True) if len(mid) > 1 else 0.0))
+pair = torch.stack([(a[-k:].mean() - b[-k:].mean()) for a, b in zip(curves["u8"], curves["bf16"])])
+print("u8 - bf16 per run (same seeds within a run), last fifth: %s -> mean %.4f" % (" ".join("%+.4f" % v for v in pair.tolist()), pair.mean()))
