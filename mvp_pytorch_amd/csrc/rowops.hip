@@ -307,8 +307,10 @@ __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const fl
   }
 }
 
-template <int J, int RPW>
-__global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, const __bf16* z,
+// One wave keeps TWO sets of RPW rows in registers: the loads of the next set are requested before the current set is reduced and
+// stored (PIPE; round 5: the plain loop left the memory pipe idle while a wave computed, 2.3-2.7 TB/s effective in the step).
+template <int J, int RPW, bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 2 : 4) void ln_bwd_j_kernel(const __bf16* dy, const __bf16* z,
                                                         const float* mean, const float* rstd,
                                                         const float* gamma, __bf16* dz, __bf16* dd,
                                                         float* partial, int M_arg, int rpg, int gstride,
@@ -326,21 +328,25 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, cons
 #pragma unroll
     for (int e = 0; e < 4; ++e) ag[j][e] = ab[j][e] = abias[j][e] = 0.f;
   }
-  for (int r0 = (blockIdx.x * 4 + wave) * RPW; r0 < M; r0 += gridDim.x * 4 * RPW) {
+  struct RowSet {
     bf16x4 a[RPW][J], x[RPW][J];
     float mu[RPW], rs[RPW];
+  };
+  auto load_rows = [&](int r0, RowSet& R) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = min(r0 + i, M - 1);
       const int64_t irow = remap_row(r, rpg, gstride, roff);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        a[i][j] = *reinterpret_cast<const bf16x4*>(dy + irow * H + 256 * j + 4 * lane);
-        x[i][j] = *reinterpret_cast<const bf16x4*>(z + (int64_t)r * H + 256 * j + 4 * lane);
+        R.a[i][j] = *reinterpret_cast<const bf16x4*>(dy + irow * H + 256 * j + 4 * lane);
+        R.x[i][j] = *reinterpret_cast<const bf16x4*>(z + (int64_t)r * H + 256 * j + 4 * lane);
       }
-      mu[i] = ident ? 0.f : mean[r];
-      rs[i] = ident ? 1.f : rstd[r];
+      R.mu[i] = ident ? 0.f : mean[r];
+      R.rs[i] = ident ? 1.f : rstd[r];
     }
+  };
+  auto finish_rows = [&](int r0, const RowSet& R) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int r = r0 + i;
@@ -351,13 +357,13 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, cons
       for (int j = 0; j < J; ++j) {
         float d[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = bf2f(a[i][j][e]);
+        for (int e = 0; e < 4; ++e) d[e] = bf2f(R.a[i][j][e]);
         const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
         drop_apply2(ydrop, idx, d[0], d[1]);
         drop_apply2(ydrop, idx + 2, d[2], d[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[j][e] = (bf2f(x[i][j][e]) - mu[i]) * rs[i];
+          xh[j][e] = (bf2f(R.x[i][j][e]) - R.mu[i]) * R.rs[i];
           g[j][e] = d[e] * gm[j][e];
           s1 += g[j][e];
           s2 += g[j][e] * xh[j][e];
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, cons
       for (int j = 0; j < J; ++j) {
         float t[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = rs[i] * (g[j][e] - c1 - xh[j][e] * c2);
+        for (int e = 0; e < 4; ++e) t[e] = R.rs[i] * (g[j][e] - c1 - xh[j][e] * c2);
         const bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
         *reinterpret_cast<bf16x4*>(dz + (int64_t)r * H + 256 * j + 4 * lane) = o;
         const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
@@ -384,6 +390,28 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_j_kernel(const __bf16* dy, cons
           *reinterpret_cast<bf16x4*>(dd + (int64_t)r * H + 256 * j + 4 * lane) = od;
         }
       }
+    }
+  };
+  const int stride = gridDim.x * 4 * RPW;
+  int r0 = (blockIdx.x * 4 + wave) * RPW;
+  if constexpr (PIPE) {
+    RowSet A, B;
+    if (r0 < M) load_rows(r0, A);
+    while (r0 < M) {
+      const int r1 = r0 + stride;
+      if (r1 < M) load_rows(r1, B);
+      finish_rows(r0, A);
+      if (r1 >= M) break;
+      const int r2 = r1 + stride;
+      if (r2 < M) load_rows(r2, A);
+      finish_rows(r1, B);
+      r0 = r2;
+    }
+  } else {
+    for (; r0 < M; r0 += stride) {
+      RowSet A;
+      load_rows(r0, A);
+      finish_rows(r0, A);
     }
   }
   if (wave > 0) {
@@ -817,10 +845,21 @@ int mvptr_layernorm_bwd_partial(const void* dy, const void* z, const float* mean
     constexpr int RPW = 2;
     int g = (M + 4 * RPW - 1) / (4 * RPW);
     if (g < grid) grid = g;  // every block writes its partial row: the finalize pass reads `grid` of them
-    hipLaunchKernelGGL((ln_bwd_j_kernel<3, RPW>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
-                       (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
-                       make_dropdev(dense_drop), rows_dev);
+    if (mvptr_knobs().nt_exp & (1 << 18))      // diagnostic A/B: the plain load-then-finish loop of rounds 2-4
+      hipLaunchKernelGGL((ln_bwd_j_kernel<3, RPW, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
+                         (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
+                         make_dropdev(dense_drop), rows_dev);
+    else if (mvptr_knobs().nt_exp & (1 << 8))      // diagnostic A/B: four rows per set
+      hipLaunchKernelGGL((ln_bwd_j_kernel<3, 4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
+                         (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
+                         make_dropdev(dense_drop), rows_dev);
+    else
+      hipLaunchKernelGGL((ln_bwd_j_kernel<3, RPW, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                         (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz, (__bf16*)dd,
+                         (float*)ws, M, rows_per_group, group_stride, row_offset, make_dropdev(y_drop),
+                         make_dropdev(dense_drop), rows_dev);
   } else {
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16*)dy, (const __bf16*)z, mean, rstd, gamma, (__bf16*)dz,

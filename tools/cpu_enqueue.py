@@ -36,6 +36,15 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 print("%s: wall %.2f ms/step, host time inside pretrain_step %.2f ms/step (includes waiting at the step's host syncs)"
       % ("fixed" if fixed else "packed", wall / n * 1e3, host / n * 1e3))
+# the same with an EMPTY queue in front of every step (no back-pressure from a full launch queue can hide in the figure)
+solo = []
+for _ in range(8):
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync)
+    solo.append((time.perf_counter() - h0) * 1e3)
+torch.cuda.synchronize()
+print("host time of one step queued behind an empty queue (ms): %s" % [round(v, 2) for v in solo])
 # where the host waits: the row-count read-backs (engine.AsyncCounts.get)
 from mvp_pytorch_amd import engine  # noqa: E402
 waits = []
