@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--loop-only", action="store_true", help="with --ab: two more columns, both kernels without their epilogue (MVPTR_NT_EXP bit 10)")
     args = ap.parse_args()
     H, I = 768, 3072
+    base_exp = int(os.environ.get("MVPTR_NT_EXP", "0") or 0)      # the run's own experiment flags survive the loop-only columns
     flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
     print("%-22s %6s %5s %5s  %9s %8s  %9s %8s  %6s%s" % ("gemm (epilogue)", "M", "N", "K", "ours us", "TF/s", "blasLt us", "TF/s", "ratio",
                                                            ("   %s us" % args.cfg) if args.ab else ""))
@@ -75,12 +76,12 @@ def main():
                 hip.set_knob("MVPTR_GEMM_CFG", "")
                 tot_old += old
                 if args.loop_only:
-                    hip.set_knob("MVPTR_NT_EXP", "1024")
+                    hip.set_knob("MVPTR_NT_EXP", str(base_exp | 1024))
                     l0 = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
                     hip.set_knob("MVPTR_GEMM_CFG", args.cfg)
                     l1 = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush, args.reps)
                     hip.set_knob("MVPTR_GEMM_CFG", "")
-                    hip.set_knob("MVPTR_NT_EXP", "0")
+                    hip.set_knob("MVPTR_NT_EXP", str(base_exp))
                     loop_txt = "   loop-only %7.1f / %7.1f" % (l0, l1)
             bt = b.t()
             lib = cold_us(lambda: torch.matmul(a, bt, out=out), flush, args.reps)
