@@ -7,6 +7,8 @@ P="--kernel-trace --stats --output-format csv"
 rocprofv3 $P -d $O/packed -o packed -- python3 bench.py --steps 10 --warmup 3 --no-extras > $O/bench_packed_under_rocprof.log 2>&1
 rocprofv3 $P -d $O/fixed -o fixed -- python3 bench.py --steps 10 --warmup 3 --no-extras --fixed-length > $O/bench_fixed_under_rocprof.log 2>&1
 rocprofv3 $P -d $O/single -o single -- python3 bench.py --steps 10 --warmup 3 --no-extras --model single > $O/bench_single_under_rocprof.log 2>&1
+# ONE compute stream: no two kernels of the step overlap, so the per-kernel durations are the kernels' own (in-step figures without the overlap)
+rocprofv3 $P -d $O/onestream -o onestream -- python3 bench.py --steps 10 --warmup 3 --no-extras --one-stream > $O/bench_onestream_under_rocprof.log 2>&1
 Q="--kernel-trace --output-format csv"
 rocprofv3 --pmc FETCH_SIZE $Q -d $O/calib_fetch -- python3 tools/calib_fetch.py > $O/calib.log 2>&1
 rocprofv3 --pmc FETCH_SIZE $Q -d $O/pmc_packed_fetch -- python3 tools/prof_dominant.py 2 > $O/pmc.log 2>&1
@@ -33,4 +35,5 @@ python3 tools/gpu_idle.py $O/fixed/fixed_kernel_trace.csv > $O/r05_step_launches
 # keep only the summaries (the traces are tens of MB)
 find $O -name "*kernel_trace.csv" -size +2M -delete
 find $O -name "*counter_collection.csv" -size +8M -delete
+python3 bench.py > $O/r05_bench_default_line.txt 2> $O/bench_default.err
 ls $O; tail -3 $O/bench_packed_under_rocprof.log | cut -c1-300; cat $O/roofline.log | head -70; cat $O/features.log
