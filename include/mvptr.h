@@ -42,7 +42,7 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 5
+#define MVPTR_ABI_VERSION 6
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
@@ -97,6 +97,31 @@ int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M,
  * product of slice z with plain stores — the caller adds the slabs in index order (deterministic, no atomics). */
 int mvptr_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int splits,
                          float* slabs, int64_t ldc, void* stream);
+
+/* LayerNorm folded into the GEMMs on either side of it — north_star's "fused LayerNorm + QKV projection", inference path
+ * (BertLayerNorm of BertSelfOutput / BertOutput, transformers/pytorch_transformers/modeling_bert.py:348-352, 407-411, feeding
+ * oscar/modeling/modeling_vlbert.py:71-73 and modeling_bert.py:394-397 of the next sub-block).  With x = LN(z) =
+ * (z - mean) rstd gamma + beta per row, x W^T + b = rstd (z W'^T - mean c) + d where W' = W with column k scaled by gamma[k],
+ * c[n] = sum_k W'[n, k] and d = W beta + b: the consumer GEMM runs on the PRE-LayerNorm rows z and finishes the LayerNorm in
+ * its epilogue; the producer GEMM writes z and the partial sums of its row statistics.  No LayerNorm launch, no normalised
+ * tensor in HBM.  Forward only: training keeps the LayerNorm kernel, because its OUTPUT is an operand of the weight-gradient
+ * GEMMs (dW = dY^T x) and has to exist in memory anyway.
+ *   mode MVPTR_LN_FOLD_BIAS   out(bf16) = rstd[m] (A B^T - mean[m] colsum[n]) + bias[n]        A = z, B = W', bias = d
+ *   mode MVPTR_LN_FOLD_GELU   out(bf16) = erf-GELU of the same                                  (FFN1; no gelu' stash)
+ *   mode MVPTR_LN_RESID_STATS out(bf16) = z = A B^T + bias + r;  r = aux rows (stats NULL) or LN(aux rows) with stats / gamma /
+ *                             beta (the residual is itself a pre-LayerNorm tensor); row_partials[m, n / 64, 0..1] = (sum, sum
+ *                             of squares) of the stored z over each 64-column strip -> mvptr_ln_stats_finalize
+ * stats: f32 [M, 2] = (mean, rstd) per row.  Shapes: N % 256 == 0, K % 64 == 0, K >= 128 (MVPTR_BAD_SHAPE otherwise: the caller
+ * keeps the unfused path); row_partials: f32 [M, N / 64, 2]. */
+#define MVPTR_LN_FOLD_BIAS 0
+#define MVPTR_LN_FOLD_GELU 1
+#define MVPTR_LN_RESID_STATS 2
+int mvptr_gemm_nt_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int mode, const float* bias,
+                     const void* aux, int64_t ld_aux, const float* stats, const float* colsum, const float* gamma,
+                     const float* beta, void* out, int64_t ldc, float* row_partials, void* stream);
+/* stats[m] = (mean, 1 / sqrt(var + eps)) of row m from the partial sums of MVPTR_LN_RESID_STATS (H = the row length, a multiple
+ * of 64; biased variance as BertLayerNorm, modeling_bert.py:242-246); sums in strip order (reproducible). */
+int mvptr_ln_stats_finalize(const float* row_partials, int M, int H, float eps, float* stats, void* stream);
 
 /* dW[N,K] (+)= A[M,N]^T * B[M,K] ; A = dY (bf16), B = X (bf16), dW f32 (MFMA 32x32x16,
  * transposed LDS reads, split over M with f32 atomics when accumulate != 0 or splits > 1).

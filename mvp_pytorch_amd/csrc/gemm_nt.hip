@@ -729,6 +729,54 @@ extern "C" int mvptr_decoder_ce_bwd(const void* h, int64_t ldh, const void* W, i
   return launch<EPI_CE_BWD>(a, (hipStream_t)stream);
 }
 
+// LayerNorm folded into the neighbouring GEMMs (inference path; gemm_nt_impl.h EPI_FOLD_* / EPI_RESID_LN).  256 x 256 tiles of
+// gemm_nt8_kernel only: N % 256 == 0, K % 64 == 0, K >= 128 (every encoder GEMM of a hidden size that is a multiple of 256).
+extern "C" int mvptr_gemm_nt_ln(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int mode, const float* bias,
+                                const void* aux, int64_t ld_aux, const float* stats, const float* colsum, const float* gamma,
+                                const float* beta, void* out, int64_t ldc, float* row_partials, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt_ln: M, N, K must be > 0");
+  if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt_ln: K, lda, ldb must be multiples of 8 and >= K");
+  if (!A || !B || !out || !bias || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)out & 15) || (ldc & 7) || ldc < N)
+    MVPTR_FAIL(MVPTR_BAD_ALIGN, "gemm_nt_ln: NULL / unaligned pointer or ldc");
+  if (mode < 0 || mode > 2) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt_ln: mode must be MVPTR_LN_FOLD_BIAS, _FOLD_GELU or _RESID_STATS");
+  if (mode != MVPTR_LN_RESID_STATS && (!stats || !colsum)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt_ln: the folded modes need stats and colsum");
+  if (mode == MVPTR_LN_RESID_STATS) {
+    if (!aux || !row_partials || ld_aux < N || (ld_aux & 7) || ((uintptr_t)aux & 15)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt_ln: residual rows / partials missing or unaligned");
+    if (stats && (!gamma || !beta)) MVPTR_FAIL(MVPTR_BAD_ARG, "gemm_nt_ln: a pre-LayerNorm residual needs gamma and beta");
+  }
+  GemmNtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const __bf16*)A;
+  a.B = (const __bf16*)B;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.bias = bias;
+  a.aux = (const __bf16*)aux;
+  a.ld_aux = ld_aux;
+  a.out0 = out;
+  a.ldc = ldc;
+  a.drop = make_dropdev(nullptr);
+  a.vec_out_ok = 1;
+  a.vec_aux_ok = 1;
+  a.vec_bias_ok = (((uintptr_t)bias & 15) == 0) ? 1 : 0;
+  a.splits = 1;
+  a.ln_stats = stats;
+  a.ln_c = colsum;
+  a.ln_gamma = gamma;
+  a.ln_beta = beta;
+  a.part = row_partials;
+  a.part_ld = N / 64;
+  if (!nt8_eligible<MVPTR_EPI_BIAS>(a)) MVPTR_FAIL(MVPTR_BAD_SHAPE, "gemm_nt_ln: needs N %% 256 == 0, K %% 64 == 0, K >= 128 (N = %d, K = %d)", N, K);
+  switch (mode) {
+    case MVPTR_LN_FOLD_BIAS: return launch_nt8_mt<EPI_FOLD_BIAS, 8>(a, (hipStream_t)stream);
+    case MVPTR_LN_FOLD_GELU: return launch_nt8_mt<EPI_FOLD_GELU, 8>(a, (hipStream_t)stream);
+    default: return launch_nt8_mt<EPI_RESID_LN, 8>(a, (hipStream_t)stream);
+  }
+}
+
 extern "C" int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N,
                              int K, int epilogue, const float* bias, const void* aux,
                              int64_t ld_aux, void* out0, void* out1, int64_t ldc, float* vec_out,
@@ -775,6 +823,7 @@ int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, i
   a.lse = a.scale = nullptr;
   a.part = a.lab_logit = nullptr;
   a.part_ld = a.n_store = 0;
+  a.ln_stats = a.ln_c = a.ln_gamma = a.ln_beta = nullptr;
   const MvptrKnobs& kn = mvptr_knobs();
   a.stash_temporal = (kn.nt_exp & 512) ? 1 : 0;
   if ((kn.nt_exp >> 19) & 7) a.stash_temporal = 1 + ((kn.nt_exp >> 19) & 7);      // bits 19-21: 1 = sc1, 2 = sc0 sc1, 3 = nt (buffer store)

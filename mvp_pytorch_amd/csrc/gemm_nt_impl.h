@@ -43,6 +43,11 @@ struct GemmNtArgs {
   float* lab_logit;       // [M] logit at the label (forward)
   int part_ld;
   int n_store;            // columns written by EPI_CE_BWD (N rounded up to the operand padding)
+  // LayerNorm folded into the neighbouring GEMMs of the inference path (mvptr_gemm_nt_ln, EPI_FOLD_* / EPI_RESID_LN below)
+  const float* ln_stats;  // [M, 2] (mean, rstd) of the rows of the pre-LayerNorm operand (A for EPI_FOLD_*, aux for EPI_RESID_LN; NULL: aux is final)
+  const float* ln_c;      // [N] EPI_FOLD_*: column sums of the gamma-scaled weight, c[n] = sum_k W'[n, k]
+  const float* ln_gamma;  // [N] EPI_RESID_LN: weight / bias of the LayerNorm applied to the residual rows on the fly
+  const float* ln_beta;
 };
 
 namespace {
@@ -89,6 +94,14 @@ int nt_num_cus() {
 // library-internal epilogues of the fused decoder + cross-entropy entry points
 constexpr int EPI_CE_PART = 16;  // per row and 64-column wave strip: (max, sum exp(v - max)) of v = acc + bias; logit at the label
 constexpr int EPI_CE_BWD = 17;   // out0(bf16) = (exp(v - lse[m]) - [n == label[m]]) * scale, 0 for unscored rows / pad columns
+// LayerNorm folded into its consumer (inference path; north_star "fused LayerNorm + QKV projection").  With x = LN(z) =
+// (z - mu) rstd gamma + beta per row:  x W^T + b = rstd (z W'^T - mu c) + d,  W' = gamma o W (columns scaled), c = rowsum(W'),
+// d = W beta + b.  The GEMM runs on the PRE-LayerNorm rows z with W'; the epilogue applies the row statistics:
+constexpr int EPI_FOLD_BIAS = 18;  // out0(bf16) = rstd[m] (acc - mean[m] c[n]) + d[n]                       (Q/K/V projection)
+constexpr int EPI_FOLD_GELU = 19;  // out0(bf16) = gelu(the same)                                           (FFN1; no gelu' stash: inference)
+// ... and its producer: the GEMM in front of a LayerNorm writes the pre-LayerNorm rows and their statistics' partial sums,
+constexpr int EPI_RESID_LN = 20;   // z = acc + bias + r, r = aux (ln_stats NULL) or LN(aux) from ln_stats / ln_gamma / ln_beta; out0(bf16) = z;
+                                   // part[m, strip, 0..1] = (sum, sum of squares) of the ROUNDED z over the 64 columns of wave strip n / 64
 
 extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -138,7 +151,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
     }
   };
 
-  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_GELU_BWD_BF16 || EPI == MVPTR_EPI_ADD);
+  constexpr bool kNeedsAux = (EPI == MVPTR_EPI_BIAS_RESID || EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_GELU_BWD_BF16 || EPI == MVPTR_EPI_ADD ||
+                              EPI == EPI_RESID_LN);
+  constexpr bool kFold = (EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_GELU);
+  // per-column vectors of the folded LayerNorm: c (EPI_FOLD_*), gamma / beta of the residual's LayerNorm (EPI_RESID_LN)
+  float lc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lb8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (kFold || EPI == EPI_RESID_LN) {
+    const float* cv = kFold ? p.ln_c : p.ln_gamma;
+    if (cv != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < p.N) {
+          lc8[e] = cv[n + e];
+          if constexpr (EPI == EPI_RESID_LN) lb8[e] = p.ln_beta[n + e];
+        }
+    }
+  }
   const bool has_aux = kNeedsAux && p.aux != nullptr;
 
   // residual / pre-activation rows (aux): the four rows of a 32-row chunk are requested together, ONE CHUNK AHEAD of the
@@ -255,6 +283,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       v[e] = v0[e] + b8[e];
       v[4 + e] = v1[e] + b8[4 + e];
     }
+    if constexpr (kFold) {
+      const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (int64_t)m);      // (mean, rstd) of row m
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = st.y * (v0[e] - st.x * lc8[e]) + b8[e];
+        v[4 + e] = st.y * (v1[e] - st.x * lc8[4 + e]) + b8[4 + e];
+      }
+    }
     if constexpr (EPI == EPI_CE_BWD) {
       const int64_t lab = p.labels[m];
       const bool scored = lab >= 0 && lab < p.N;
@@ -286,8 +322,42 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
         for (int e = 0; e < 8; ++e) a[e] = bf2f(ab[e]);
       }
     }
-    if (EPI == MVPTR_EPI_BIAS) {
+    if (EPI == MVPTR_EPI_BIAS || EPI == EPI_FOLD_BIAS) {
       store_bf8(p.out0, m, v);
+    } else if (EPI == EPI_FOLD_GELU) {
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        f32x2 a2, d2;
+        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
+        g[e] = a2.x;
+        g[e + 1] = a2.y;
+      }
+      store_bf8(p.out0, m, g);
+    } else if (EPI == EPI_RESID_LN) {
+      if (p.ln_stats != nullptr) {      // the residual rows are pre-LayerNorm rows: normalise them here
+        const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (int64_t)m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (a[e] - st.x) * st.y * lc8[e] + lb8[e];
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = bf2f(f2bf(v[e] + a[e]));      // the statistics are those of the rows as stored (what a LayerNorm kernel would read)
+        if (n + e < p.N) {
+          s1 += v[e];
+          s2 += v[e] * v[e];
+        }
+      }
+      store_bf8(p.out0, m, v);
+      // the 8 lanes that share the row (lane bits 0-2) hold the wave strip's 64 columns
+      s1 = MVPTR_DPP_ADD(s1, 0xB1);
+      s2 = MVPTR_DPP_ADD(s2, 0xB1);
+      s1 = MVPTR_DPP_ADD(s1, 0x4E);
+      s2 = MVPTR_DPP_ADD(s2, 0x4E);
+      s1 = MVPTR_DPP_ADD(s1, 0x141);
+      s2 = MVPTR_DPP_ADD(s2, 0x141);
+      if (ch == 0) *reinterpret_cast<f32x2*>(p.part + ((int64_t)m * p.part_ld + ((n0 >> 6) + wn)) * 2) = f32x2{s1, s2};
     } else if (EPI == MVPTR_EPI_BIAS_GELU) {
       float g[8], dg[8];
 #pragma unroll

@@ -440,6 +440,23 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 4) void ln_bwd_j_kernel(const __bf1
   }
 }
 
+// Row statistics of a LayerNorm input from the partial sums its producing GEMM left behind (EPI_RESID_LN: per row and 64-column
+// strip the sum and the sum of squares of the stored values): stats[m] = (mean, rstd).  Sums in strip order: reproducible.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* part, int strips, int M, float inv_h, float eps, float* stats) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const f32x2* pp = reinterpret_cast<const f32x2*>(part) + (int64_t)m * strips;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < strips; ++i) {
+    const f32x2 v = pp[i];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mu = s1 * inv_h;
+  const float var = fmaxf(s2 * inv_h - mu * mu, 0.f);
+  reinterpret_cast<f32x2*>(stats)[m] = f32x2{mu, 1.0f / sqrtf(var + eps)};
+}
+
 // --------------------------------------------------------------------------------- embeddings
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, const int64_t* pids,
                                                          const int64_t* tids, const float* word,
@@ -815,6 +832,14 @@ extern "C" int mvptr_layernorm_bwd(const void* dy, const void* z, const float* m
                                    void* ws, int64_t ws_bytes, void* stream) {
   return mvptr_layernorm_bwd_rows(dy, z, mean, rstd, gamma, dz, dd, dgamma, dbeta, dbias, M, H, rows_per_group, group_stride, row_offset,
                                   y_drop, dense_drop, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int mvptr_ln_stats_finalize(const float* row_partials, int M, int H, float eps, float* stats, void* stream) {
+  if (!row_partials || !stats || M <= 0 || H <= 0 || (H & 63)) MVPTR_FAIL(MVPTR_BAD_ARG, "ln_stats_finalize: NULL argument, M <= 0 or H %% 64 != 0");
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, row_partials, H / 64, M, 1.0f / (float)H,
+                     eps, stats);
+  MVPTR_CHECK_LAUNCH("ln_stats_finalize");
+  return MVPTR_OK;
 }
 
 int mvptr_layernorm_bwd_rows(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma, void* dz, void* dd,

@@ -452,6 +452,31 @@ class EncoderPacks:
         plan.build()
         self.plan = plan
 
+    def fold_tables(self, params):
+        """Operands of the LayerNorm-folded inference path (encoder_infer_folded), per layer: the weight whose input is a LayerNorm
+        output with that LayerNorm's gamma multiplied into its columns (bf16), c = its row sums, d = W beta + b — Q|K|V of layer
+        l >= 1 against LayerNorm 2 of layer l - 1, FFN1 against LayerNorm 1 of its own layer.  Rebuilt when a parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_fold_key", None) != key:
+            bf = torch.bfloat16
+            tabs = []
+            with torch.no_grad():
+                for li in range(len(self.packs)):
+                    (qw, qb, kw, kb, vw, vb, _ow, _ob, g1, b1, iw, ib) = params[16 * li:16 * li + 12]
+                    t = {}
+                    if li > 0:
+                        g_prev, b_prev = params[16 * (li - 1) + 14].float(), params[16 * (li - 1) + 15].float()
+                        w = torch.cat([qw, kw, vw], 0).float()
+                        wf = (w * g_prev[None, :]).to(bf).contiguous()
+                        t["w_qkv"], t["c_qkv"] = wf, wf.float().sum(1).contiguous()
+                        t["d_qkv"] = (w @ b_prev + torch.cat([qb, kb, vb]).float()).contiguous()
+                    w = iw.float()
+                    wf = (w * g1.float()[None, :]).to(bf).contiguous()
+                    t["w_i"], t["c_i"], t["d_i"] = wf, wf.float().sum(1).contiguous(), (w @ b1.float() + ib.float()).contiguous()
+                    tabs.append(t)
+            self._fold, self._fold_key = tabs, key
+        return self._fold
+
     def prefetch(self, params):
         """Rebuild the bf16 copies now, on the current stream; the stack's own refresh in the same forward pass
         then finds them fresh.  Only for the one-launch path (contiguous f32 parameters)."""
@@ -599,6 +624,52 @@ class UnpackRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.index_select(0, ctx.idx), None, None
+
+
+def fold_eligible(meta, params):
+    """the LayerNorm-folded inference path takes whole stacks of contiguous f32 parameters whose GEMMs fit mvptr_gemm_nt_ln"""
+    return (meta.group is not None and meta.segment is None and len(meta.packs) >= 1 and hip.gemm_nt_ln_eligible(meta.H, meta.H) and
+            hip.gemm_nt_ln_eligible(meta.I, meta.H) and hip.gemm_nt_ln_eligible(meta.H, meta.I) and
+            all(p.dtype == torch.float32 and p.is_contiguous() for p in params))
+
+
+@torch.no_grad()
+def encoder_infer_folded(x, mask_add, meta, params):
+    """Forward of a whole encoder stack with every LayerNorm folded into the GEMMs around it (inference only; north_star's "fused
+    LayerNorm + QKV projection", mvptr_gemm_nt_ln): the GEMM in front of a LayerNorm writes the pre-LayerNorm rows z and the partial
+    sums of their statistics, the GEMM behind it (Q|K|V of the next layer, FFN1) multiplies z by the gamma-scaled weight and applies
+    (mean, rstd) in its epilogue; the residual adds normalise their rows on the fly.  Per stack one LayerNorm launch is left (the
+    output) instead of 2 per layer, and no normalised tensor goes through HBM in between.  x: bf16 [rows, H] (row-packed with
+    meta.seq_start / seq_len, or B * L padded rows with mask_add) -> bf16 [rows, H].  Equal to the unfused path up to bf16
+    rounding (the normalised rows are not rounded to bf16 on their way into the GEMM; W' = bf16(gamma o W) instead of bf16(W))."""
+    n = len(meta.packs)
+    meta.group.refresh(params)                  # bf16 working copies current (pk.keep)
+    tabs = meta.group.fold_tables(params)
+    H, heads, eps = meta.H, meta.heads, meta.eps
+    z_prev = st_prev = g_prev = b_prev = None
+    for li in range(n):
+        w_qkv, _, b_qkv, w_o, _, _w_i, _, w_out, _ = meta.packs[li].keep
+        prm = params[16 * li:16 * (li + 1)]
+        ob, g1, b1, pb, g2, b2 = prm[7], prm[8], prm[9], prm[13], prm[14], prm[15]
+        t = tabs[li]
+        if z_prev is None:
+            qkv = hip.gemm_nt(x, w_qkv, hip.EPI_BIAS, bias=b_qkv)
+        else:
+            qkv = hip.gemm_nt_ln(z_prev, t["w_qkv"], hip.LN_FOLD_BIAS, t["d_qkv"], stats=st_prev, colsum=t["c_qkv"])
+        if meta.rows:
+            ctx, _ = hip.attention_fwd_packed(qkv, meta.seq_start, meta.seq_len, meta.B, meta.L, heads, need_lse=False)
+        else:
+            ctx, _ = hip.attention_fwd(qkv, mask_add, meta.B, meta.L, heads, need_lse=False)
+        if z_prev is None:
+            z1, part = hip.gemm_nt_ln(ctx, w_o, hip.LN_RESID_STATS, ob, aux=x)
+        else:
+            z1, part = hip.gemm_nt_ln(ctx, w_o, hip.LN_RESID_STATS, ob, aux=z_prev, stats=st_prev, gamma=g_prev, beta=b_prev)
+        st1 = hip.ln_stats_finalize(part, H, eps)
+        a = hip.gemm_nt_ln(z1, t["w_i"], hip.LN_FOLD_GELU, t["d_i"], stats=st1, colsum=t["c_i"])
+        z2, part = hip.gemm_nt_ln(a, w_out, hip.LN_RESID_STATS, pb, aux=z1, stats=st1, gamma=g1, beta=b1)
+        st_prev = hip.ln_stats_finalize(part, H, eps)
+        z_prev, g_prev, b_prev = z2, g2, b2
+    return hip.layernorm_fwd(z_prev, g_prev, b_prev, eps, save_stats=False)[0]
 
 
 class EncoderFn(GradAwareFunction):

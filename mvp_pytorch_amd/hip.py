@@ -32,6 +32,7 @@ SYMBOLS = [
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
+    "mvptr_gemm_nt_ln", "mvptr_ln_stats_finalize",
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
     "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
     "mvptr_masked_mean", "mvptr_dgelu_mul", "mvptr_compact_scored",
@@ -104,6 +105,8 @@ def load():
         lib.mvptr_set_knob.argtypes = [c_char_p, c_char_p]
     lib.mvptr_gemm_nt.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, I64, P, POINTER(Dropout), P]
     lib.mvptr_gemm_nt_splitk.argtypes = [P, I64, P, I64, I, I, I, I, P, I64, P]
+    lib.mvptr_gemm_nt_ln.argtypes = [P, I64, P, I64, I, I, I, I, P, P, I64, P, P, P, P, P, I64, P, P]
+    lib.mvptr_ln_stats_finalize.argtypes = [P, I, I, c_float, P, P]
     lib.mvptr_gemm_tn.argtypes = [P, I64, P, I64, I, I, I, P, I64, P, P]
     lib.mvptr_gemm_tn_multi.argtypes = [POINTER(TnProblem), I, P]
     lib.mvptr_gemm_tn_multi_ws.argtypes = [POINTER(TnProblem), I, P, I64, P]
@@ -248,6 +251,37 @@ def dgelu_decode(q):
 def dgelu_encode(g):
     """f32 gelu' values -> the 8-bit stash (test support; the kernels write it themselves)."""
     return torch.clamp(torch.round(g.float() * DGELU_SCALE) + DGELU_ZERO, 0, 255).to(torch.uint8)
+
+
+LN_FOLD_BIAS, LN_FOLD_GELU, LN_RESID_STATS = 0, 1, 2
+
+
+def gemm_nt_ln_eligible(N, K):
+    """shapes mvptr_gemm_nt_ln takes (256 x 256 tiles of the ping-pong kernel)"""
+    return N % 256 == 0 and K % 64 == 0 and K >= 128
+
+
+def gemm_nt_ln(a, b, mode, bias, stats=None, colsum=None, aux=None, gamma=None, beta=None, out=None):
+    """LayerNorm folded into a GEMM (mvptr_gemm_nt_ln).  LN_FOLD_BIAS / LN_FOLD_GELU: a = PRE-LayerNorm rows z [M, K] bf16,
+    b = gamma-scaled weight [N, K] bf16, bias = d, stats [M, 2] = (mean, rstd), colsum = c -> bf16 [M, N].
+    LN_RESID_STATS: out = a b^T + bias + (aux, or LN(aux) from stats / gamma / beta) -> (out bf16 [M, N], row partials [M, N / 64, 2])."""
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.bfloat16)
+    part = torch.empty((M, N // 64, 2), device=a.device, dtype=torch.float32) if mode == LN_RESID_STATS else None
+    _check(load().mvptr_gemm_nt_ln(_p(a), a.stride(0), _p(b), b.stride(0), M, N, K, mode, _p(bias), _p(aux),
+                                   aux.stride(0) if aux is not None else 0, _p(stats), _p(colsum), _p(gamma), _p(beta),
+                                   _p(out), out.stride(0), _p(part), _stream()))
+    return (out, part) if mode == LN_RESID_STATS else out
+
+
+def ln_stats_finalize(part, H, eps):
+    """[M, H / 64, 2] partial sums -> stats [M, 2] = (mean, rstd) (mvptr_ln_stats_finalize)."""
+    M = part.shape[0]
+    stats = torch.empty((M, 2), device=part.device, dtype=torch.float32)
+    _check(load().mvptr_ln_stats_finalize(_p(part), M, H, float(eps), _p(stats), _stream()))
+    return stats
 
 
 def gemm_nt_splitk(a, b, splits, n=None):

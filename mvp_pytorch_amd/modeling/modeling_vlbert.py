@@ -118,6 +118,11 @@ class CaptionBertEncoder(nn.Module):
         # gelu'(u) stash of the FFN: "u8" (default: 8-bit fixed point, |error| <= 0.0025) or "bf16" (rounds 1-3; reference-numerics
         # runs and A/B runs of the 8-bit stash: tools/soak.py --gelu-stash)
         self.gelu_stash_bf16 = str(getattr(config, "gelu_stash", "u8")).lower() == "bf16"
+        # config.fold_layernorm: True = every no-grad eval forward of the stack folds its LayerNorms into the neighbouring GEMMs
+        # (engine.encoder_infer_folded; equal to the unfused path up to bf16 rounding), False = never, None (default) = only inside the
+        # cached retrieval engine (encode_text / encode_image / fuse_pairs with packed=True, which promise no more than that)
+        self.fold_layernorm = getattr(config, "fold_layernorm", None)
+        self._fold_now = False
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_flat_cache", None)      # .to() / .half() may replace Parameter objects
@@ -189,14 +194,24 @@ class CaptionBertEncoder(nn.Module):
                                           l0.attention.self.dropout.p, seq_start=starts, seq_len=lens.contiguous(), rows=rows)
                 meta.stash_bf16 = self.gelu_stash_bf16
                 meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
-                y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
+                if self._folds(meta):
+                    y = engine.encoder_infer_folded(engine.PackRows.apply(x, idx), None, meta, self._flat_params())
+                else:
+                    y = engine.EncoderFn.apply(engine.PackRows.apply(x, idx), None, meta, *self._flat_params())
                 return (engine.UnpackRows.apply(y, idx, B * L).view(B, L, H),)
         meta = engine.EncoderMeta(self._packs.for_device(hidden_states.device), B, L, Hc, heads, I, eps, self.training,
                                   l0.output.dropout.p, l0.attention.self.dropout.p)
         meta.stash_bf16 = self.gelu_stash_bf16
         meta.beside = bool(self.__dict__.get("_beside", False))      # set by BiBertImgModel while its two uni-modal stacks share the GPU
+        if self._folds(meta):
+            return (engine.encoder_infer_folded(x, mask, meta, self._flat_params()).view(B, L, H),)
         y = engine.EncoderFn.apply(x, mask, meta, *self._flat_params())
         return (y.view(B, L, H),)
+
+    def _folds(self, meta):
+        """LayerNorms folded into the GEMMs for this call?  Only without autograd, in eval mode, for shapes mvptr_gemm_nt_ln takes."""
+        want = self.fold_layernorm is True or (self.fold_layernorm is None and self._fold_now)
+        return (want and not self.training and not torch.is_grad_enabled() and engine.fold_eligible(meta, self._flat_params()))
 
 
 def _run_layers(self, hidden_states, attention_mask, first, count):
@@ -690,10 +705,12 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             for e in self.encs:
                 if self.on and e.unpad is not False:
                     e.unpad = True
+                e._fold_now = bool(self.on)
 
         def __exit__(self, *exc):
             for e, u in zip(self.encs, self.saved):
                 e.unpad = u
+                e._fold_now = False
 
     @torch.no_grad()
     def encode_text(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, position_ids_a=None, packed=True):

@@ -30,7 +30,7 @@ def test_library_exports_header_symbols():
 def test_abi_version_and_error_string():
     from mvp_pytorch_amd import hip
     lib = hip.load()
-    assert hip.query(0) == 5   # MVPTR_ABI_VERSION (5: mvptr_gemm_tn_stack + mvptr_encoder_layer_bwd_defer; 4: 8-bit gelu' stash)
+    assert hip.query(0) == 6   # MVPTR_ABI_VERSION (6: mvptr_gemm_nt_ln + mvptr_ln_stats_finalize; 5: mvptr_gemm_tn_stack + mvptr_encoder_layer_bwd_defer; 4: 8-bit gelu' stash)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.mvptr_gemm_nt(None, 8, None, 8, 0, 8, 8, 0, None, None, 0, None, None, 8, None, None, None)
     assert rc == -1

@@ -1510,3 +1510,59 @@ def test_encoder_stack_with_dropout_matches_oracle_with_replayed_masks(dev):
     # and the masks matter: without them the oracle is far away
     y0 = orc.encoder({k: v.detach() for k, v in sd.items()}, "enc", layers, xp.detach(), orc.extended_mask(mask), heads, cfg["layer_norm_eps"])
     assert _rel(y.detach().float().cpu(), y0.view(-1, H)[pad_idx]) > 5 * e_y
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_layernorm_folded_inference_stack_matches_oracle(dev, packed):
+    """NS-1 (north_star "fused LayerNorm + QKV projection"): in a no-grad eval forward with config.fold_layernorm the stack runs
+    engine.encoder_infer_folded — every LayerNorm (mb:348-352, 407-411) folded into the GEMMs around it, one LayerNorm launch per
+    stack — and agrees with the oracle's encoder (BertLayerNorm in f32, mb:242-246) as closely as the unfused product path does."""
+    from mvp_pytorch_amd import engine, modeling
+    layers, heads, H = 3, 12, 768
+    cfg = dict(gu.BASE_CFG, num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(1)
+    conf = modeling.make_config(cfg)
+    enc = modeling.modeling_vlbert.CaptionBertEncoder(conf).to(dev).eval()
+    with torch.no_grad():      # LayerNorm weights / biases away from (1, 0): the fold has to carry them
+        for n, p in enc.named_parameters():
+            if "LayerNorm.weight" in n:
+                p.add_(torch.randn_like(p) * 0.2)
+            elif "LayerNorm.bias" in n:
+                p.add_(torch.randn_like(p) * 0.2)
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(15, 120, (11,), generator=g)
+    B, lmax = lens.numel(), int(lens.max())
+    x = (torch.randn(B, lmax, H, generator=g) * 0.6).to(torch.bfloat16)
+    mask = torch.zeros(B, lmax, dtype=torch.long)
+    for b, n in enumerate(lens.tolist()):
+        mask[b, :n] = 1
+    add = orc.extended_mask(mask).view(B, lmax).to(dev)
+    valid = mask.bool()
+
+    calls = []
+    orig = engine.encoder_infer_folded
+    engine.encoder_infer_folded = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            enc.unpad = packed
+            enc.fold_layernorm = False
+            y_unf = enc(x.to(dev), add)[0].float().cpu()
+            enc.fold_layernorm = True
+            y_fold = enc(x.to(dev), add)[0].float().cpu()
+            assert len(calls) == 1, "the folded path did not run"
+            enc.train()                     # training never folds: the LayerNorm output is an operand of the weight gradients
+            enc(x.to(dev), add)
+            enc.eval()
+        assert len(calls) == 1
+        enc(x.to(dev), add)                 # autograd on: not folded either
+        assert len(calls) == 1
+    finally:
+        engine.encoder_infer_folded = orig
+    sd = {"enc." + k: (v.detach().float().cpu().to(torch.bfloat16).float() if v.dim() == 2 else v.detach().float().cpu()) for k, v in enc.state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        yo = orc.encoder(sd, "enc", layers, x.float(), orc.extended_mask(mask), heads, cfg["layer_norm_eps"])
+    e_fold, e_unf = _rel(y_fold[valid], yo[valid]), _rel(y_unf[valid], yo[valid])
+    print("LayerNorm-folded inference stack (packed=%s): rel L2 vs oracle folded %.2e, unfused %.2e, folded vs unfused %.2e"
+          % (packed, e_fold, e_unf, _rel(y_fold[valid], y_unf[valid])))
+    assert e_fold < 8e-3 and e_fold < 1.5 * e_unf + 1e-3, (e_fold, e_unf)

@@ -1147,3 +1147,78 @@ def test_bce_logits_against_torch(dev, rows, cols):
     # bitwise reproducible (ordered partial sums)
     got2 = engine.BceLogitsFn.apply(xd.detach(), y.to(dev))
     assert got2.item() == got.item()
+
+
+# ----------------------------------------------------------------- LayerNorm folded into the neighbouring GEMMs (NS-1, inference path)
+@pytest.mark.parametrize("M,N,K,gelu", [(1000, 2304, 768, False), (777, 3072, 768, True), (300, 768, 3072, False)])
+def test_gemm_nt_ln_fold_matches_layernorm_then_linear(dev, M, N, K, gelu):
+    """mvptr_gemm_nt_ln FOLD modes: the GEMM runs on the PRE-LayerNorm rows with the gamma-scaled weight and finishes the
+    LayerNorm in its epilogue; reference = BertLayerNorm (mb:242-246) in f32, then nn.Linear (+ erf-GELU, mb:394-397) in f32."""
+    from mvp_pytorch_amd import hip
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(M, K, generator=g) * 0.8 + 0.3 * torch.randn(M, 1, generator=g)).to(torch.bfloat16).to(dev)
+    gamma = (torch.rand(K, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(K, generator=g) * 0.2).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    zf = z.float()
+    mu = zf.mean(1, keepdim=True)
+    var = ((zf - mu) ** 2).mean(1, keepdim=True)
+    x = (zf - mu) / torch.sqrt(var + 1e-12) * gamma + beta
+    ref = x @ W.t() + b
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    stats = torch.cat([mu, 1.0 / torch.sqrt(var + 1e-12)], 1).contiguous()
+    wf = (W * gamma[None, :]).to(torch.bfloat16).contiguous()
+    out = hip.gemm_nt_ln(z, wf, hip.LN_FOLD_GELU if gelu else hip.LN_FOLD_BIAS, (W @ beta + b).contiguous(), stats=stats,
+                         colsum=wf.float().sum(1).contiguous())
+    # the unfused product path for scale: LayerNorm kernel (bf16 out), then the plain GEMM
+    y = hip.layernorm_fwd(z, gamma, beta, 1e-12)[0] if K <= 1024 else x.to(torch.bfloat16)      # the LayerNorm kernel takes rows of <= 1024
+    unf = hip.gemm_nt(y, W.to(torch.bfloat16).contiguous(), hip.EPI_BIAS, bias=b).float()
+    if gelu:
+        unf = torch.nn.functional.gelu(unf)
+    e_fold, e_unf = _rel(out.float(), ref), _rel(unf, ref)
+    print("LN fold M=%d N=%d K=%d gelu=%s: folded rel L2 %.2e, unfused %.2e" % (M, N, K, gelu, e_fold, e_unf))
+    assert e_fold < 6e-3 and e_fold < 1.5 * e_unf + 1e-3, (e_fold, e_unf)
+
+
+@pytest.mark.parametrize("M,K,inline_ln", [(900, 768, False), (1111, 3072, True)])
+def test_gemm_nt_ln_residual_and_row_statistics(dev, M, K, inline_ln):
+    """mvptr_gemm_nt_ln RESID_STATS: z = A W^T + b + r with r the residual rows or LayerNorm(residual rows) computed on the fly;
+    the partial sums it leaves + mvptr_ln_stats_finalize = mean / rstd of the STORED rows (what a LayerNorm kernel reading z would
+    compute, mb:242-246)."""
+    from mvp_pytorch_amd import hip
+    N = 768
+    g = torch.Generator().manual_seed(6)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    r = (torch.randn(M, N, generator=g) * 0.7 + 0.2).to(torch.bfloat16).to(dev)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(N, generator=g) * 0.2).to(dev)
+    rf = r.float()
+    if inline_ln:
+        mu = rf.mean(1, keepdim=True)
+        var = ((rf - mu) ** 2).mean(1, keepdim=True)
+        st_r = torch.cat([mu, 1.0 / torch.sqrt(var + 1e-12)], 1).contiguous()
+        res = (rf - mu) / torch.sqrt(var + 1e-12) * gamma + beta
+        z, part = hip.gemm_nt_ln(a, W, hip.LN_RESID_STATS, b, aux=r, stats=st_r, gamma=gamma, beta=beta)
+    else:
+        res = rf
+        z, part = hip.gemm_nt_ln(a, W, hip.LN_RESID_STATS, b, aux=r)
+    ref = a.float() @ W.float().t() + b + res
+    assert _rel(z.float(), ref) < 4e-3
+    stats = hip.ln_stats_finalize(part, N, 1e-12)
+    zf = z.float()
+    mu = zf.mean(1)
+    rstd = 1.0 / torch.sqrt(((zf - mu[:, None]) ** 2).mean(1) + 1e-12)
+    assert float((stats[:, 0] - mu).abs().max()) < 2e-5 * max(1.0, float(mu.abs().max()))
+    assert float(((stats[:, 1] - rstd) / rstd).abs().max()) < 2e-4
+
+
+def test_gemm_nt_ln_rejects_shapes_outside_the_256_tile_kernel(dev):
+    from mvp_pytorch_amd import hip
+    z = torch.zeros(64, 192, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(320, 192, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        hip.gemm_nt_ln(z, w, hip.LN_FOLD_BIAS, torch.zeros(320, device=dev), stats=torch.zeros(64, 2, device=dev), colsum=torch.zeros(320, device=dev))
