@@ -465,7 +465,8 @@ def _secondary_legs(dev, steps):
             "step_frac": round(f_exec / t_rr / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "gflop_per_pair_executed": round(f_exec / ti.numel() / 1e9, 2),
             "gflop_per_pair_full_length": round(f_full / ti.numel() / 1e9, 2),
             "workload": "BiImageBertForRetrieval BERT-base eval, configs[3]: 1000 images x 5 captions (55 / 80 slots), coarse top-64 images per caption "
-                        "+ top-128 captions per image = 448000 pairs re-ranked from cached uni-modal outputs (row-packed; forward only)"}
+                        "+ top-128 captions per image = 448000 pairs re-ranked from cached uni-modal outputs (row-packed; forward only; "
+                        "LayerNorms folded into the neighbouring GEMMs: mvptr_gemm_nt_ln)"}
         del model, text, image, sim
     except Exception as e:   # a secondary leg never takes the headline down
         out["configs3_retrieval_rerank"] = {"error": "%s: %s" % (type(e).__name__, e)}
