@@ -707,17 +707,24 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
       fa[2 * j - 3] = tr_frag(base, ta[2 * j - 3][0], ta[2 * j - 3][1]);
     }
   };
-  auto mma_row = [&](int nb, const bf16x8(&fa)[4], const bf16x8(&fb)[4], auto bias_tag) {
+  auto mma_row = [&](int nb, const bf16x8(&fa)[4], const bf16x8(&fb)[4]) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
       acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[nb], fb[kb], acc[nb][kb], 0, 0, 0);
-    if constexpr (decltype(bias_tag)::value) {
+  };
+  // column sums of the 16 rows x 128 dY columns in fa: 4 x v_dot2c_f32_bf16 against (1, 1) per fragment.  A real (scalar) branch
+  // around it — the empty asm keeps hipcc from turning it into always-computed dot products + selects
+  auto bias_rows = [&](const bf16x8(&fa)[4], bool duty) {
+    if (duty) {
+      asm volatile("" ::: "memory");
       const bf16x2 ones = {f2bf(1.f), f2bf(1.f)};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
-        bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
-      }
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x2 pr = {fa[nb][2 * j], fa[nb][2 * j + 1]};
+          bsum[nb] = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, bsum[nb], false);
+        }
     }
   };
 
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
         for (int kb = 0; kb < 4; ++kb) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[nb][kb][r], rs, voff[kb], soff, 0);
         __builtin_amdgcn_sched_barrier(0);   // four accumulator reads at a time (hipcc otherwise copies all 256 to VGPRs first and spills)
       }
-    if (p.colsum != nullptr && tk == 0 && wk == 0) {
+    if (p.colsum != nullptr) {      // every wave of every tile carries a share of the column sums (see bias_ctr)
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const float tot = bsum[nb] + __shfl_xor(bsum[nb], 32);
@@ -848,7 +855,14 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
   uint32_t offA[NI], offB[NI];
   uint32_t stepA = 0, stepB = 0;
   int nsteps = 0;
+  // Bias-gradient column sums of the dY operand (colsum != NULL): the 2 * tiles_k waves that hold the same dY columns (the two
+  // k-halves of every tile along k) take the 32-row steps in turn — step s belongs to wave (tk, wk) = s mod (2 tiles_k) — so every
+  // tile of the problem runs the same instruction mix.  Round 5a gave all of it to the (tk = 0, wk = 0) waves: 32 extra VALU
+  // instructions per step made those tiles ~5 % slower than their neighbours, they fell out of the window in which an XCD's L2
+  // still holds the shared dY panel, and the panel was fetched twice (FETCH_SIZE 2.23 x the operands for FFN1-type problems against
+  // 1.38 x without column sums; the step's launches 3 030 -> 2 730 us at M = 37 748: profiles/r05_experiments.txt section 9).
   bool do_bias = false;
+  int bias_mod = 1, bias_ctr = 0;
   auto stage_piece = [&](int buf, int st, int i) {
     const uint32_t la = lds0 + (uint32_t)(buf * STAGE_B + wave * 1024);
     if (i < NI) {
@@ -888,7 +902,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
     }
     stepA = (uint32_t)(TM_ * p.lda * 2);
     stepB = (uint32_t)(TM_ * p.ldb * 2);
-    do_bias = (p.colsum != nullptr) && (tk == 0) && (wk == 0);
+    do_bias = (p.colsum != nullptr);
+    bias_mod = 2 * p.tiles_k;
+    bias_ctr = (2 * tk + wk - s0 % bias_mod + bias_mod) % bias_mod;      // steps until this wave's next turn
     // every wave is done with the previous segment's ring (its fragment reads were consumed by its last MFMAs)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
@@ -919,10 +935,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
       auto step = [&](int st, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const char* cur = lds + buf * STAGE_B;
+        bool duty = false;
+        if constexpr (decltype(bias_tag)::value) {
+          duty = (bias_ctr == 0);
+          bias_ctr = duty ? bias_mod - 1 : bias_ctr - 1;
+        }
+        if constexpr (decltype(bias_tag)::value) bias_rows(fa0, duty);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           read_pair(cur + 4096, j, fa1, fb1);
-          mma_row(j, fa0, fb0, bias_tag);
+          mma_row(j, fa0, fb0);
           __builtin_amdgcn_sched_barrier(0);
         }
         const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;
@@ -939,6 +961,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
           }
         }
         const char* nxt = lds + nbuf * STAGE_B;
+        if constexpr (decltype(bias_tag)::value) {
+          if (!more) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: fa1 was not waited for at a barrier
+          bias_rows(fa1, duty);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (STEADY) {
@@ -946,7 +972,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
             stage_piece(buf, st + STAGES, 2 * j + 1);
           }
           if (more) read_pair(nxt, j, fa0, fb0);
-          mma_row(j, fa1, fb1, bias_tag);
+          mma_row(j, fa1, fb1);
           __builtin_amdgcn_sched_barrier(0);
         }
         buf = nbuf;

@@ -26,13 +26,15 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--H", type=int, default=768)
     ap.add_argument("--I", type=int, default=3072)
+    ap.add_argument("--no-colsum", action="store_true", help="no bias-gradient column sums on FFN1 / Q|K|V (A/B of their cost)")
     args = ap.parse_args()
     H, I, L = args.H, args.I, args.layers
     for M in [int(v) for v in args.ms.split(",")]:
         layers = []
         for _ in range(L):
             d2, a, dU, x1, d1, ctx, dq, x = rnd(M, H), rnd(M, I), rnd(M, I), rnd(M, H), rnd(M, H), rnd(M, H), rnd(M, 3 * H), rnd(M, H)
-            layers.append([(d2, a, (H, I), False), (dU, x1, (I, H), True), (d1, ctx, (H, H), False), (dq, x, (3 * H, H), True)])
+            cs = not args.no_colsum
+            layers.append([(d2, a, (H, I), False), (dU, x1, (I, H), cs), (d1, ctx, (H, H), False), (dq, x, (3 * H, H), cs)])
 
         def grads():
             return [[(torch.zeros(n, k, device=dev), torch.zeros(n, device=dev) if cs else None) for (_, _, (n, k), cs) in lay] for lay in layers]

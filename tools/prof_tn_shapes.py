@@ -27,3 +27,24 @@ for name, N, K in TYPES:
     print("%-40s operands %.1f MB, results %.1f MB, %d tiles = %.2f rounds of 256" % (name, 24 * M * (N + K) * 2 / 1e6, 24 * N * K * 4 / 1e6, tiles, tiles / 256.0), flush=True)
     del probs
     torch.cuda.empty_cache()
+# the step's own mix (6 layers x the four types), without and with the bias-gradient column sums of FFN1 and Q|K|V, then one type with them
+for name, with_cs in (("mix of the four types, no column sums", False), ("mix, column sums on ffn1 / qkv (the step)", True)):
+    probs = []
+    for _ in range(6):
+        for (_, N, K), cs in zip(TYPES, (False, True, False, True)):
+            dy = (torch.randn(M, N, device=dev) * 0.5).to(torch.bfloat16)
+            x = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+            probs.append((dy, x, torch.zeros(N, K, device=dev), torch.zeros(N, device=dev) if (cs and with_cs) else None))
+    hip.gemm_tn_stack(probs)
+    torch.cuda.synchronize()
+    print("%-40s operands %.1f MB" % (name, 6 * M * 12288 * 2 / 1e6), flush=True)
+    del probs
+    torch.cuda.empty_cache()
+probs = []
+for _ in range(24):
+    dy = (torch.randn(M, I, device=dev) * 0.5).to(torch.bfloat16)
+    x = (torch.randn(M, H, device=dev) * 0.5).to(torch.bfloat16)
+    probs.append((dy, x, torch.zeros(I, H, device=dev), torch.zeros(I, device=dev)))
+hip.gemm_tn_stack(probs)
+torch.cuda.synchronize()
+print("%-40s operands %.1f MB" % ("ffn1 dW x 24 WITH column sums", 24 * M * (I + H) * 2 / 1e6), flush=True)
