@@ -902,7 +902,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_sk_kernel(TnSkArgs args) {
     }
     stepA = (uint32_t)(TM_ * p.lda * 2);
     stepB = (uint32_t)(TM_ * p.ldb * 2);
-    do_bias = (p.colsum != nullptr);
+    // every problem runs the duty pattern, also those without column sums (their sums are dropped): the tiles of ALL problems
+    // then keep the same pace, so the workgroups of an XCD still start their next tiles together after a round that mixed
+    // problem types (FETCH_SIZE of the step's mix 1.51 x -> 1.32 x the operands, the same as without any column sums; the
+    // launch alone is 1-5 % slower for it, the step the same: profiles/r05_experiments.txt section 9)
+    do_bias = true;
     bias_mod = 2 * p.tiles_k;
     bias_ctr = (2 * tk + wk - s0 % bias_mod + bias_mod) % bias_mod;      // steps until this wave's next turn
     // every wave is done with the previous segment's ring (its fragment reads were consumed by its last MFMAs)
