@@ -364,7 +364,7 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
     fam_ach = fam_flops / (fam_ms * 1e-3) / 1e12
     tn_entry = dict(kernel="gemm_tn_sk_kernel<4>: every weight gradient of an encoder stack in one balanced launch (dW[N,K] += dY[M,N]^T X[M,K]; "
                            "%d problems per stack = %d layers x (FFN2, FFN1, attention output, Q/K/V); 256x256 tiles, four waves of 128x128, whole tiles per "
-                           "workgroup + equal runs over the left-over tiles; 3 launches per step)" % (4 * mix.layers, mix.layers),
+                           "workgroup + XCD-aligned row ranges of the left-over tiles, column sums dealt round all waves; 3 launches per step)" % (4 * mix.layers, mix.layers),
                     achieved=round(tn_ach, 1), frac=round(tn_ach / MFMA_BF16_PEAK_TFLOPS, 4), avg_launch_us=round(tn_ms * 1e3, 1),
                     avg_launch_us_back_to_back=round(tn_hot_ms * 1e3, 1), flop_per_launch=tn_flops,
                     algorithmic_bytes_per_launch=round(mix.tn_bytes()), traffic=(t_tn or {}).get("bytes_per_launch"))
