@@ -83,7 +83,8 @@ const char* mvptr_last_error(void);
  * lda/ldb/ldc/ld_aux in elements; K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned.
  * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual) or, for EPI_GELU_BWD, u8 [M, ld_aux] (the gelu' stash) or NULL.
  * The gelu' stash (ABI 4): one byte per element, q = rint(200 g) + 26, g = (q - 26) / 200 — gelu_erf' lies in
- * [-0.129, 1.129], 0 and 1 are exact, |error| <= 0.0025; out0 of EPI_BIAS_GELU has row stride ldc BYTES, out1 ldc elements.
+ * [-0.129, 1.129], 0 and 1 are exact; dithered rounding since round 5 (the dither is the low mantissa byte of u): |error| < 0.005 with zero mean,
+ * where round-to-nearest's 0.0025 was a deterministic function of u; out0 of EPI_BIAS_GELU has row stride ldc BYTES, out1 ldc elements.
  * vec_out: f32[N] column sums (EPI_GELU_BWD), accumulated with atomics, or NULL.
  * drop: dropout on (acc + bias) for EPI_BIAS_RESID, element index = m * N + n. */
 int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
@@ -568,7 +569,7 @@ typedef struct {
   const int* seq_start;
   const int* seq_len;
   const int* rows_dev;
-  /* ABI 5: 0 = gelu'(u) stashed as 8-bit fixed point (1 B per element, |error| <= 0.0025: the default), 1 = as bf16 (2 B per
+  /* ABI 5: 0 = gelu'(u) stashed as 8-bit fixed point (1 B per element, dithered rounding, |error| < 0.005 with zero mean: the default), 1 = as bf16 (2 B per
    * element: the stash of rounds 1-3) — must be the same in the forward and the backward call of a layer */
   int stash_bf16;
   /* ABI 5: 1 = GEMMs of another stack run beside this layer on a second stream (the text and visual stacks of the two-stage

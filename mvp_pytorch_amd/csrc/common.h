@@ -198,6 +198,25 @@ __device__ __forceinline__ uint32_t dgelu_pack4(float g0, float g1, float g2, fl
   const uint32_t p23 = __builtin_amdgcn_perm(f3, f2, 0x0c0c0400u);
   return p01 | (p23 << 16);
 }
+// The same with DITHERED rounding (round 5): q = rint(200 g + 26 + d), d uniform in [-0.498, 0.498] taken from the low mantissa byte
+// of the pre-activation u itself (256 levels; those bits are the rounding noise of a 768-term f32 sum and do not know where g sits
+// inside its grid cell).  Round-to-nearest made the error a deterministic function of u — every unit with u < -3.3 had its small
+// negative derivative stored as exactly 0 — and four paired 3 000-step runs ended 0.17 +- 0.08 higher in loss than the bf16 stash
+// (profiles/r05_experiments.txt section 10).  With the dither E[stored] = g (|error| <= 0.005 instead of 0.0025, zero mean);
+// g = 0 and g = 1 still store exactly (|d| < 0.5).  Three more VALU operations per element than dgelu_pack4.
+__device__ __forceinline__ uint32_t dgelu_pack4_dither(float g0, float g1, float g2, float g3, float u0, float u1, float u2, float u3) {
+  const float magic = 8388608.0f + MVPTR_DGELU_ZERO;
+  auto enc = [&](float g, float u) {
+    const float r = (float)(__builtin_bit_cast(uint32_t, u) & 0xffu);                       // v_cvt_f32_ubyte0
+    // >= -26: the derivative's minimum (-0.1289 -> 0.22 on the grid) minus the dither would otherwise fall below 0 and wrap to 255
+    const float t = fmaxf(fmaf(r, 1.0f / 256.0f, fmaf(g, MVPTR_DGELU_SCALE, -0.498046875f)), -MVPTR_DGELU_ZERO);
+    return __builtin_bit_cast(uint32_t, t + magic);
+  };
+  const uint32_t f0 = enc(g0, u0), f1 = enc(g1, u1), f2 = enc(g2, u2), f3 = enc(g3, u3);
+  const uint32_t p01 = __builtin_amdgcn_perm(f1, f0, 0x0c0c0400u);
+  const uint32_t p23 = __builtin_amdgcn_perm(f3, f2, 0x0c0c0400u);
+  return p01 | (p23 << 16);
+}
 // (q - 26) is exact and 200 * (1 / 200.f) rounds to 1: the grid points 0 and 1 decode EXACTLY (one fma would leave 1.9e-9 at 0)
 __device__ __forceinline__ float dgelu_decode1(uint32_t q) { return ((float)q - MVPTR_DGELU_ZERO) * (1.0f / MVPTR_DGELU_SCALE); }
 __device__ __forceinline__ float dgelu_unpack(uint32_t w, int i) { return dgelu_decode1((w >> (8 * i)) & 0xffu); }

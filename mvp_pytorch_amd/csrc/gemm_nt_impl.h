@@ -373,7 +373,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       // GEMM's operand — in the Infinity Cache (same-box A/B: all-slots step 41.71 -> 41.46 ms, packed 28.68 -> 28.60)
       // out0 = the 8-bit gelu' stash (common.h), one byte per element, row stride ldc bytes
       uint8_t* dp = reinterpret_cast<uint8_t*>(p.out0) + (int64_t)m * p.ldc + n;
-      const u32x2 dq = {dgelu_pack4(dg[0], dg[1], dg[2], dg[3]), dgelu_pack4(dg[4], dg[5], dg[6], dg[7])};
+      const u32x2 dq = {dgelu_pack4_dither(dg[0], dg[1], dg[2], dg[3], v[0], v[1], v[2], v[3]),
+                        dgelu_pack4_dither(dg[4], dg[5], dg[6], dg[7], v[4], v[5], v[6], v[7])};
       if (nfull && p.vec_out_ok) {
 #ifdef MVPTR_DIAG_BUILD
         if (p.stash_temporal >= 2) {

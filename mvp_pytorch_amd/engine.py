@@ -537,7 +537,7 @@ class EncoderMeta:
 
 
 # gelu'(u) stash format where no config says otherwise (LinearFn of the head transforms reads it too): False = 8-bit fixed
-# point (|error| <= 0.0025, round 4), True = bf16.  config.gelu_stash = "bf16" | "u8" sets it per model (modeling_utils).
+# point (dithered rounding, |error| < 0.005 with zero mean: round 5), True = bf16.  config.gelu_stash = "bf16" | "u8" sets it per model (modeling_utils).
 GELU_STASH_BF16 = False
 # Default of EncoderMeta.defer_wgrad (A/B switch: bench.py --wgrad-per-layer, tests).
 DEFER_WGRAD = True

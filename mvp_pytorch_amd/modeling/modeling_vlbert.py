@@ -115,7 +115,7 @@ class CaptionBertEncoder(nn.Module):
         # skip padded rows (see forward): "train" (default) = in training mode only, where nothing but
         # the losses is consumed; True = always; False = never (the reference's padded execution)
         self.unpad = getattr(config, "unpad", "train")
-        # gelu'(u) stash of the FFN: "u8" (default: 8-bit fixed point, |error| <= 0.0025) or "bf16" (rounds 1-3; reference-numerics
+        # gelu'(u) stash of the FFN: "u8" (default: 8-bit fixed point, dithered rounding: |error| < 0.005, zero mean) or "bf16" (rounds 1-3; reference-numerics
         # runs and A/B runs of the 8-bit stash: tools/soak.py --gelu-stash)
         self.gelu_stash_bf16 = str(getattr(config, "gelu_stash", "u8")).lower() == "bf16"
         # config.fold_layernorm: True = every no-grad eval forward of the stack folds its LayerNorms into the neighbouring GEMMs

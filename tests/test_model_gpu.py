@@ -1402,7 +1402,7 @@ def test_deferred_stack_weight_gradients_equal_per_layer(dev, layers, rows, drop
 def test_gelu_stash_formats_agree(dev):
     """config.gelu_stash = "bf16" (the stash format of rounds 1-3, selectable) against the default 8-bit fixed
     point on the tiny two-stage training fixture, same weights and inputs, dropout off: identical losses (the forward pass only
-    differs in what it SAVES), gradients equal to what the 8-bit grid allows (|error of gelu'| <= 0.0025 on values of
+    differs in what it SAVES), gradients equal to what the 8-bit grid allows (|error of gelu'| < 0.005, zero mean, on values of
     order 0.1 - 1)."""
     d = gu.load("tiny_bi_pretrain_nophrase")
     cfg, dims = d["config"], d["dims"]

@@ -63,10 +63,14 @@ def test_gemm_nt_epilogues(dev):
     aref = torch.nn.functional.gelu(uref)
     aref.sum().backward()
     assert _rel(act, aref.detach()) < 4e-3
-    # gelu'(u) comes back as 8-bit fixed point (step 1/200): half a step + the bf16 rounding of nothing else
+    # gelu'(u) comes back as 8-bit fixed point (step 1/200) with DITHERED rounding (round 5): |error| < one step, zero mean
     assert dq.dtype == torch.uint8
-    assert (hip.dgelu_decode(dq) - uref.grad).abs().max() < 0.0025 + 1e-4
-    assert _rel(hip.dgelu_decode(dq), uref.grad) < 4e-3
+    err = hip.dgelu_decode(dq) - uref.grad
+    assert err.abs().max() < 0.005 + 1e-4
+    assert abs(float(err.mean())) < 1e-4, float(err.mean())                      # unbiased over the 230 k elements (sigma / sqrt(n) = 6e-6)
+    small = uref.grad.abs() < 0.0025                                             # round-to-nearest stored all of these as exactly 0
+    assert abs(float(err[small].mean())) < 3e-4 and float((hip.dgelu_decode(dq)[small] != 0).float().mean()) > 0.05
+    assert _rel(hip.dgelu_decode(dq), uref.grad) < 6e-3
     # bf16 rounding is the only error: the erfc form is accurate to 1.5e-7
     assert (act.float() - aref.detach()).abs().max() < 2.0 ** -8 * max(1.0, aref.abs().max().item())
     z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux)
@@ -124,7 +128,7 @@ def test_gemm_nt_encoder_shapes_every_epilogue(dev, M, N, K):
         aref = torch.nn.functional.gelu(uref)
         aref.sum().backward()
         assert _rel(act, aref.detach()) < 4e-3
-        assert (hip.dgelu_decode(dq) - uref.grad).abs().max() < 0.0025 + 1e-4
+        assert (hip.dgelu_decode(dq) - uref.grad).abs().max() < 0.005 + 1e-4
         z = hip.gemm_nt(a, b, hip.EPI_BIAS_RESID, bias=bias, aux=aux)
         assert _rel(z, base + bias + aux.float()) < 4e-3
         ad = hip.gemm_nt(a, b, hip.EPI_ADD, aux=aux)
@@ -265,7 +269,7 @@ def test_gemm_tn_slab_write_out_is_exact_and_reproducible(dev, M):
         assert _rel(cs_a, dy.float().sum(0)) < 1e-5 and _rel(cs_c, dy.float().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("M,layers,max_wg", [(700, 2, 0), (6400, 3, 0), (10917, 6, 0), (3001, 9, 0), (5000, 2, 40), (97, 1, 0)])
+@pytest.mark.parametrize("M,layers,max_wg", [(700, 2, 0), (6400, 3, 0), (10917, 6, 0), (3001, 9, 0), (5000, 2, 40), (97, 1, 0), (33, 1, 7), (2, 1, 0)])
 def test_gemm_tn_stack(dev, M, layers, max_wg):
     """One balanced launch for the weight gradients of a whole stack (mvptr_gemm_tn_stack): whole tiles per workgroup in
     the full rounds, equal runs of 32-row steps over the left-over tiles.  Checked against f32 products: odd shapes (partial
@@ -303,7 +307,7 @@ def test_gemm_tn_stack(dev, M, layers, max_wg):
         if cs is not None:
             assert _rel(cs, dy[:Mv].float().sum(0)) < 1e-5
     # problems of one call share M
-    bad = probs[:1] + [(dy5[:50], x5[:50], torch.zeros(520, 1000, device=dev), None)]
+    bad = probs[:1] + [(dy5[:M - 1], x5[:M - 1], torch.zeros(520, 1000, device=dev), None)]
     with pytest.raises(RuntimeError, match="share M"):
         hip.gemm_tn_stack(bad)
 

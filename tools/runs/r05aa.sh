@@ -1,0 +1,6 @@
+# Round 5: dithered 8-bit gelu' stash: op tests, parity values, multi-run soak against bf16, step time
+O=gpurun_out/r05aa; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+python3 -m pytest tests -q -m gpu -s > $O/pytest_gpu.log 2>&1; grep -n "passed\|failed\|^FAILED" $O/pytest_gpu.log | tail -8
+python3 tools/stash_soak.py --runs 4 --steps 3000 > $O/soak.log 2>&1; grep -v amdgpu $O/soak.log | cut -c1-300 | tail -3
+for r in 1 2; do python3 bench.py --steps 30 --warmup 8 --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('packed', d['ms_per_step'], d['value'])"; done
