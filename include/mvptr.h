@@ -82,9 +82,9 @@ const char* mvptr_last_error(void);
  * B = W^T as stored by mvptr_cast_pack).
  * lda/ldb/ldc/ld_aux in elements; K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, A/B 16-byte aligned.
  * bias: f32[N] or NULL.  aux: bf16 [M, ld_aux] (residual) or, for EPI_GELU_BWD, u8 [M, ld_aux] (the gelu' stash) or NULL.
- * The gelu' stash (ABI 4): one byte per element, q = rint(200 g) + 26, g = (q - 26) / 200 — gelu_erf' lies in
- * [-0.129, 1.129], 0 and 1 are exact; dithered rounding since round 5 (the dither is the low mantissa byte of u): |error| < 0.005 with zero mean,
- * where round-to-nearest's 0.0025 was a deterministic function of u; out0 of EPI_BIAS_GELU has row stride ldc BYTES, out1 ldc elements.
+ * The gelu' stash (ABI 4; zero point 27 since ABI 6): one byte per element, q = floor(200 g + 27 + d) with the dither d in [0, 1), g = (q - 27) / 200 — gelu_erf' lies in
+ * [-0.129, 1.129], 0 and 1 are exact; the dither is the low mantissa byte of u: |error| < 0.005 with zero mean, where the
+ * round-to-nearest of ABI 4-5 (|error| <= 0.0025) was a deterministic function of u; out0 of EPI_BIAS_GELU has row stride ldc BYTES, out1 ldc elements.
  * vec_out: f32[N] column sums (EPI_GELU_BWD), accumulated with atomics, or NULL.
  * drop: dropout on (acc + bias) for EPI_BIAS_RESID, element index = m * N + n. */
 int mvptr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,

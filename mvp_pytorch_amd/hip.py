@@ -240,7 +240,7 @@ def gemm_nt(a, b, epilogue=EPI_BIAS, bias=None, aux=None, out=None, out1=None, v
     return (out, out1) if epilogue in (EPI_BIAS_GELU, EPI_BIAS_GELU_BF16) else out
 
 
-DGELU_SCALE, DGELU_ZERO = 200.0, 26.0
+DGELU_SCALE, DGELU_ZERO = 200.0, 27.0
 
 
 def dgelu_decode(q):
