@@ -547,7 +547,7 @@ def test_compact_scored_rows(dev):
     and taller than the label matrix (the packed joint map), without one, and with a shortfall of scored slots."""
     from mvp_pytorch_amd import hip
     g = torch.Generator(device="cpu").manual_seed(31)
-    for B, L, ld, rows in ((256, 75, 125, 512), (7, 20, 20, 7), (1, 5, 9, 3), (300, 70, 70, 300)):
+    for B, L, ld, rows in ((256, 75, 125, 512), (7, 20, 20, 7), (1, 5, 9, 3), (300, 70, 70, 300), (600, 70, 72, 600)):      # the last: > 32 labels per thread (the loop path)
         labels = torch.randint(0, 30522, (B, L), generator=g)
         labels[torch.rand(B, L, generator=g) < 0.85] = -1
         pos = torch.randint(-1, 40000, (rows, ld), generator=g, dtype=torch.int32)
