@@ -42,7 +42,7 @@ typedef enum {
 /* mvptr_query `what` codes */
 enum { MVPTR_Q_ABI_VERSION = 0, MVPTR_Q_ARCH_OK = 1, MVPTR_Q_NUM_CU = 2 };
 
-#define MVPTR_ABI_VERSION 6
+#define MVPTR_ABI_VERSION 7
 
 /* GEMM epilogues (see mvptr_gemm_nt) */
 typedef enum {
@@ -470,10 +470,17 @@ int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, int64_t ld_d
 /* Scored rows of a masked-LM head in one launch: the slots (b, l) of labels[B, L] with label > -1, ascending, as
  * out_labels[k] = the label and out_rows[k] = pos[b * ld_pos + l] (int32 row map of the packed buffer; NULL: the flat slot
  * index).  Exactly n_out entries are written: a shortfall is padded with label -1 / row -1 (ignored by the loss); MORE
- * scored slots than n_out is a caller bug that would silently drop rows from the loss — the kernel prints the two counts and
- * traps (the process aborts; ABI 5).  Replaces the masked_select chains of oscar/modeling/modeling_vlbert.py:1231-1234,1245. */
+ * scored slots than n_out is a caller bug that drops rows from the loss — the kernel stays in bounds and reports it through the
+ * DEVICE ERROR WORD `err` (ABI 7; int64 [4] device memory owned by the caller, zero = no error: err[0] = the first
+ * MVPTR_DEV_ERR_* code raised since the caller last cleared it, err[1..2] = the two counts; NULL: a printf only).  The host reads
+ * the word whenever it next reads anything back from the device and raises there — the reference raises catchably at this
+ * point (oscar/modeling/modeling_vlbert.py:435,542), a trap (ABI 5-6) took the whole process down.
+ * Replaces the masked_select chains of oscar/modeling/modeling_vlbert.py:1231-1234,1245. */
+enum { MVPTR_DEV_ERR_SCORED_ROWS = 1,   /* mvptr_compact_scored: more scored slots than output slots */
+       MVPTR_DEV_ERR_PHRASES = 2,       /* host-side check queued by the model: a sample has more phrases than config.max_phrases */
+       MVPTR_DEV_ERR_FEW_REGIONS = 3 }; /* config.wra_strict: an image with phrases has fewer than 3 regions (topk(3), vl:1547) */
 int mvptr_compact_scored(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L, int n_out,
-                         int64_t* out_labels, int32_t* out_rows, void* stream);
+                         int64_t* out_labels, int32_t* out_rows, int64_t* err, void* stream);
 
 /* Index maps of a row-packed pass, built on the device from additive attention masks (valid slot <=> 0).
  * Output sequence s (0 <= s < n_seq) is the concatenation of nseg (1 or 2) segments; segment k covers the slots
@@ -499,8 +506,10 @@ int mvptr_pack_maps(const mvptr_pack_seg* segs, int nseg, int n_seq, int32_t* po
                     int32_t* seq_start, int32_t* seq_len, int64_t* counts, void* stream);
 
 /* Host-provided counts against the device's: counts_a / counts_b are the `counts` outputs of two mvptr_pack_maps calls (int64 [2]:
- * rows, longest); a value that differs from the host's number traps the kernel (the process aborts with a message): host counts
- * that do not describe the batch would silently truncate or over-read the packed rows. */
+ * rows, longest); a value that differs from the host's number traps the kernel (the process aborts with a message).  This is the
+ * one device-side check that cannot report through an error word and carry on: every buffer, grid and LDS tile of the kernels
+ * queued behind it was sized from the host's numbers, so continuing would index out of bounds.  (Callers that want a catchable
+ * error check on the host with one read-back instead: BiBertImgModel.verify_host_counts.) */
 int mvptr_check_counts(const int64_t* counts_a, const int64_t* counts_b, int64_t rows_a, int64_t lmax_a, int64_t rows_b, int64_t lmax_b,
                        void* stream);
 
@@ -638,21 +647,8 @@ int mvptr_encoder_layer_bwd_defer(const mvptr_layer_desc* d, const mvptr_layer_w
                                   const void* dy, void* dx, const mvptr_layer_grads* g, void* ws,
                                   int64_t ws_bytes, mvptr_tn_problem* wgrads, int* n_wgrads, void* stream);
 
-/* Measurement helper (never on the product path): reads `bytes` (a multiple of 4096) of `src` exactly
- * once, mode 0 through buffer_load ... lds (the GEMM operand path), mode 1 through global_load_dwordx4,
- * so that rocprofv3's FETCH_SIZE can be calibrated against a known byte count (tools/calib_fetch.py). */
-int mvptr_diag_stream_read(const void* src, int64_t bytes, int mode, float* sink, void* stream);
-/* Measurement helper: per-CU store rate by access shape.  `blocks` 512-thread workgroups; every wave
- * instruction writes 1 KiB as rows_per_instr segments of 1024 / rows_per_instr bytes, `stride` bytes apart
- * (8 x 128 B at the output row stride = the GEMM epilogues' shape); tools/store_probe.py. */
-int mvptr_diag_store_probe(void* dst, int64_t dst_bytes, int blocks, int64_t bytes_per_wave, int rows_per_instr,
-                           int64_t stride, void* stream);
-/* Measurement helper: operand-fill rate.  `blocks` 256-thread workgroups each stream their wg_bytes region
- * (all the same region when shared != 0) `reps` times in 32-KiB stages, three in flight — the GEMM
- * kernels' staging pattern alone.  mode 0: buffer_load ... lds, mode 1: buffer_load to registers;
- * the working-set size decides the level served from (L2 / Infinity Cache / HBM); tools/fill_probe.py. */
-int mvptr_diag_fill_probe(const void* src, int64_t src_bytes, int blocks, int64_t wg_bytes, int reps, int shared, int mode,
-                          float* sink, void* stream);
+/* The measurement helpers (mvptr_diag_*: FETCH_SIZE calibration, store / fill probes) are declared in mvptr_diag.h and exist in the
+ * diagnostic build of the library only (libmvptr_hip_diag.so, `make diag`); the product library does not export them. */
 
 #ifdef __cplusplus
 }

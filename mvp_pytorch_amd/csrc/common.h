@@ -157,12 +157,44 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * cdf2 + x * e * 0.39894228040143267794f;
 }
 
-// erf-GELU and its derivative for two values at once, written on 2-vectors so the multiplies and
-// FMAs become v_pk_*_f32 (two elements per issue slot).  The GEMM epilogues are VALU-issue bound
-// (4 cycles per instruction and wave, 16 for v_exp/v_rcp), so the forward pass evaluates BOTH
-// gelu(u) and gelu'(u) from one exp and one rcp and stores the derivative; the backward epilogue
-// is then a plain multiply.
+// erf-GELU and its derivative for two values at once (round 6).  The GELU epilogues of the FFN GEMMs are VALU-issue bound
+// (an exp or rcp holds the issue port for 8 cycles, a plain or packed instruction for 4: MI355X_MICROARCH.md), and the round 1-5
+// form — A&S 7.1.26 erfc = poly(1 / (1 + p|z|)) exp(-z^2): abs, rcp, five Horner steps, copysign, beside the exp the derivative
+// needs anyway — spent 54 issue cycles per element on arithmetic whose results are rounded to bf16 / an 8-bit grid.  Now:
+//   y = clamp(c x, -Cy, Cy), t = y^2 = (x^2 / 2) log2(e)          (c^2 = log2(e) / 2: the exp argument IS the polynomial's variable)
+//   Phi(x) = clamp(1/2 + y Q(t), 0, 1),  Q of degree 8: minimax for Phi - 1/2 on |x| <= 4.3 (|error| <= 1.7e-5 in f32 — a sixtieth of
+//            bf16's half ulp on gelu(x) for x > 0), constrained to pass 1/2 at x = 4.3 so that the clamp (the `clamp` bit of the last
+//            v_pk_fma_f32: no instruction) makes Phi EXACTLY 0 / 1 beyond: gelu(x) = x for x >= 4.3 (true: x (1 - 8.5e-6)) and -0 for
+//            x <= -4.3 (true: >= -3.7e-5)
+//   gelu = x Phi,   gelu' = Phi + y e c2,  e = exp2(-t) = exp(-x^2 / 2) (ONE transcendental per element), c2 = 1 / (sqrt(2 pi) c)
+// 14 packed instructions + 2 v_med3 + 2 v_exp per pair = 40 issue cycles per element; no rcp, no abs / copysign.
 __device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& act, f32x2& dact) {
+  constexpr float kC = 8.493217826e-01f, kCy = 3.652083635e+00f, kC2 = 4.697186351e-01f;
+  const f32x2 s = x * kC;
+  f32x2 y, e;
+  y.x = __builtin_amdgcn_fmed3f(s.x, -kCy, kCy);
+  y.y = __builtin_amdgcn_fmed3f(s.y, -kCy, kCy);
+  const f32x2 t = y * y;
+  e.x = __builtin_amdgcn_exp2f(-t.x);
+  e.y = __builtin_amdgcn_exp2f(-t.y);
+  f32x2 q = t * 8.837788279e-10f + -6.147051579e-08f;
+  q = q * t + 1.886201062e-06f;
+  q = q * t + -3.402546645e-05f;
+  q = q * t + 4.076753394e-04f;
+  q = q * t + -3.486348316e-03f;
+  q = q * t + 2.224005386e-02f;
+  q = q * t + -1.083355397e-01f;
+  q = q * t + 4.696965218e-01f;
+  f32x2 cdf;
+  const f32x2 half = {0.5f, 0.5f};
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(cdf) : "v"(y), "v"(q), "v"(half));
+  act = x * cdf;
+  dact = (y * e) * kC2 + cdf;
+}
+
+#ifdef MVPTR_DIAG_BUILD
+// rounds 1-5 (A/B in the diagnostic build, MVPTR_NT_EXP bit 30): Abramowitz & Stegun 7.1.26, one v_exp_f32 + one v_rcp_f32 per element
+__device__ __forceinline__ void gelu_pair_as(f32x2 x, f32x2& act, f32x2& dact) {
   const f32x2 xx = x * x;
   f32x2 e, t;
   e.x = __builtin_amdgcn_exp2f(xx.x * -0.72134752044448170368f);  // exp(-x^2/2)
@@ -180,6 +212,7 @@ __device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& act, f32x2& dact) {
   act = hx * s + hx;
   dact = (x * e) * 0.39894228040143267794f + (s * 0.5f + 0.5f);
 }
+#endif
 
 // gelu'(u) is stashed for the backward pass as 8-bit fixed point (round 4: a third of the FFN1 forward GEMM's output
 // bytes and of the GELU-backward GEMM's aux bytes were this stash in bf16): q = rint(200 g) + 27, g = (q - 27) / 200.
@@ -203,16 +236,17 @@ __device__ __forceinline__ uint32_t dgelu_pack4(float g0, float g1, float g2, fl
 // inside its grid cell).  Round-to-nearest made the error a deterministic function of u — every unit with u < -3.3 had its small
 // negative derivative stored as exactly 0 — and four paired 3 000-step runs ended 0.17 +- 0.08 higher in loss than the bf16 stash
 // (profiles/r05_experiments.txt section 10).  With the dither E[stored] = g (|error| <= 0.005 instead of 0.0025, zero mean);
-// g = 0 and g = 1 still store exactly (d < 1).  Two more VALU operations per element than dgelu_pack4 (the zero point moved from 26 to 27
+// g = 0 and g = 1 still store exactly (d < 1).  One more VALU operation per element than dgelu_pack4 (the zero point moved from 26 to 27
 // with it: the derivative's minimum, 1.22 on the grid, must stay above 0 without a clamp).
 __device__ __forceinline__ uint32_t dgelu_pack4_dither(float g0, float g1, float g2, float g3, float u0, float u1, float u2, float u3) {
   // 200 g + 27 + d is formed at 2^15, where a float keeps exactly eight fractional bits: the code is then BYTE 1 of the word
   // (floor: with d uniform in [0, 1) the expectation is 200 g + 27; no clamp: 200 g + 27 + d lies in [1.2, 253.8])
-  auto enc = [&](float g, float u) {
-    const float r = (float)(__builtin_bit_cast(uint32_t, u) & 0xffu);                       // v_cvt_f32_ubyte0
-    return __builtin_bit_cast(uint32_t, fmaf(r, 1.0f / 256.0f, fmaf(g, MVPTR_DGELU_SCALE, 32768.0f + MVPTR_DGELU_ZERO)));
-  };
-  const uint32_t f0 = enc(g0, u0), f1 = enc(g1, u1), f2 = enc(g2, u2), f3 = enc(g3, u3);
+  // round 6: the dither byte is ADDED TO THE BITS (one v_add_u32 with a byte-0 source select) — at 2^15 one unit of the word is 2^-8,
+  // so this is the same exact sum as fma(byte, 1 / 256, .) of round 5, bit for bit, without the byte -> float conversion
+  const f32x2 b01 = f32x2{g0, g1} * MVPTR_DGELU_SCALE + (32768.0f + MVPTR_DGELU_ZERO);      // v_pk_fma_f32
+  const f32x2 b23 = f32x2{g2, g3} * MVPTR_DGELU_SCALE + (32768.0f + MVPTR_DGELU_ZERO);
+  auto enc = [&](float b, float u) { return __builtin_bit_cast(uint32_t, b) + (__builtin_bit_cast(uint32_t, u) & 0xffu); };
+  const uint32_t f0 = enc(b01.x, u0), f1 = enc(b01.y, u1), f2 = enc(b23.x, u2), f3 = enc(b23.y, u3);
   const uint32_t p01 = __builtin_amdgcn_perm(f1, f0, 0x0c0c0501u);   // byte 0 = f0.b1, byte 1 = f1.b1
   const uint32_t p23 = __builtin_amdgcn_perm(f3, f2, 0x0c0c0501u);
   return p01 | (p23 << 16);

@@ -1,4 +1,5 @@
-// diag.hip — measurement helpers (never on the product path).
+// diag.hip — measurement helpers (never on the product path): compiled into libmvptr_hip_diag.so only (`make diag`,
+// -DMVPTR_DIAG_BUILD, declared in include/mvptr_diag.h); the product build of this file is empty.
 //
 // mvptr_diag_stream_read: reads `bytes` of a buffer exactly once through one of the two load paths
 // the GEMM kernels use, so that rocprofv3's FETCH_SIZE can be calibrated against a KNOWN byte
@@ -7,6 +8,8 @@
 // 1 KiB per wave instruction, the operand path of gemm_nt / gemm_tn); mode 1: global_load_dwordx4
 // to registers.  A checksum goes to `sink` so the reads stay live.
 #include "common.h"
+#ifdef MVPTR_DIAG_BUILD
+#include "../../include/mvptr_diag.h"
 
 namespace {
 
@@ -152,3 +155,4 @@ extern "C" int mvptr_diag_fill_probe(const void* src, int64_t src_bytes, int blo
   MVPTR_CHECK_LAUNCH("diag_fill_probe");
   return MVPTR_OK;
 }
+#endif  // MVPTR_DIAG_BUILD

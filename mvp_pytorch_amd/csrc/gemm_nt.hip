@@ -453,6 +453,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmNtArgs p) {
   nt_epilogue<EPI, MT, 32>(p, Mv, acc, reinterpret_cast<float*>(lds) + wave * (32 * ST_LD), m0, n0, wm, wn, lane);
 }
 
+// epilogues the ping-pong kernel is instantiated for: the encoder's (bias / GELU / residual / GELU backward / add) and the bf16-stash
+// forms of the GELU pair, so that a gelu_stash = "bf16" A/B run compares stash formats and not kernels
+template <int EPI>
+constexpr bool kNt8Epi = (EPI <= MVPTR_EPI_ADD) || EPI == MVPTR_EPI_BIAS_GELU_BF16 || EPI == MVPTR_EPI_GELU_BWD_BF16;
+template <int EPI>
+constexpr bool kGeluFwd = (EPI == MVPTR_EPI_BIAS_GELU || EPI == MVPTR_EPI_BIAS_GELU_BF16);
+template <int EPI>
+constexpr bool kGeluBwd = (EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_GELU_BWD_BF16);
+
 template <int EPI>
 bool nt8_eligible(const GemmNtArgs& a) {
   if ((a.N & 255) || (a.K & 63) || a.K < 128 || a.splits > 1 || a.k_split_len > 0) return false;
@@ -469,10 +478,10 @@ int launch_nt8_mt(GemmNtArgs a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "gemm_nt: set LDS size: %s", hipGetErrorString(e));
   const int nwg = a.tiles_m * a.tiles_n;
-  constexpr bool kEncoderEpi = (EPI <= MVPTR_EPI_GELU_BWD);
+  constexpr bool kEncoderEpi = (EPI <= MVPTR_EPI_GELU_BWD) || kGeluFwd<EPI> || kGeluBwd<EPI>;
   const bool chunked = kEncoderEpi && a.tiles_n > 4;
-  a.group_m = (EPI == MVPTR_EPI_BIAS_GELU && chunked) ? 6 : GROUP_M;
-  a.group_n = chunked ? ((EPI == MVPTR_EPI_GELU_BWD) ? 3 : 4) : a.tiles_n;
+  a.group_m = (kGeluFwd<EPI> && chunked) ? 6 : GROUP_M;
+  a.group_n = chunked ? (kGeluBwd<EPI> ? 3 : 4) : a.tiles_n;
   if (mvptr_knobs().nt_group[0] > 0) a.group_m = mvptr_knobs().nt_group[0];
   if (mvptr_knobs().nt_group[1] > 0) a.group_n = min(mvptr_knobs().nt_group[1], a.tiles_n);
   if (mvptr_knobs().nt_group[0] > 0 && mvptr_knobs().nt_group[1] <= 0) a.group_n = a.tiles_n;
@@ -568,7 +577,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   const char* env = mvptr_knobs().gemm_cfg;
   if (env[0] != 0) {
     if (env[0] == '8') {                                                  // "8": ping-pong loop (gemm_nt8_kernel) where eligible
-      if constexpr (EPI <= MVPTR_EPI_ADD) {
+      if constexpr (kNt8Epi<EPI>) {
         if (nt8_eligible<EPI>(a)) return launch_nt8<EPI>(a, s);
       }
       return launch_bk<EPI, 64, 2, 2, 4, 8, 0>(a, s);
@@ -608,7 +617,7 @@ int launch(const GemmNtArgs& a, hipStream_t s) {
   // more than 64 tiles), with its own tile-height rule.  Cold table, M = 37 748 / 64 000 (profiles/r05_experiments.txt):
   // loop-only 141 -> 125 us (Q/K/V), 188 -> 155 (K = 3072), whole kernels -4 ... -17 %; it also replaces the 256 x 128
   // two-workgroup configuration of the narrow short-K GEMMs (attention output on the joint stack: 83.9 -> 73.7 us).
-  if constexpr (EPI <= MVPTR_EPI_ADD) {      // the encoder epilogues (the others never meet the shape rule on this model's paths)
+  if constexpr (kNt8Epi<EPI>) {      // the encoder epilogues (the others never meet the shape rule on this model's paths)
     if (!nt8_off && tiles256 > 64 && nt8_eligible<EPI>(a)) return launch_nt8<EPI>(a, s);
   }
   if constexpr (EPI <= MVPTR_EPI_ADD) {
@@ -828,6 +837,7 @@ int mvptr_gemm_nt_rows(const void* A, int64_t lda, const void* B, int64_t ldb, i
   a.stash_temporal = (kn.nt_exp & 512) ? 1 : 0;
   if ((kn.nt_exp >> 19) & 7) a.stash_temporal = 1 + ((kn.nt_exp >> 19) & 7);      // bits 19-21: 1 = sc1, 2 = sc0 sc1, 3 = nt (buffer store)
   a.no_epi = (kn.nt_exp & 1024) ? 1 : 0;
+  a.epi_ablate = (kn.nt_exp >> 26) & 31;
   a.store_mode = (kn.nt_exp >> 13) & 7;
 #if defined(MVPTR_STAMP_BUILD) || defined(MVPTR_TIMELINE_BUILD)
   a.stamps = (unsigned long long*)kn.stamps;

@@ -33,6 +33,8 @@ struct GemmNtArgs {
   int64_t slab_stride; //   and write their f32 partial tile into slab z = out0 + z * slab_stride elements; 0 = whole K, no slabs
   int no_epi;          // diagnostic build (MVPTR_NT_EXP bit 10): skip the epilogue (loop-only timing; outputs are not written)
   int store_mode;      // diagnostic build (MVPTR_NT_EXP bits 13-15, persistent kernel): 1 = stores dropped (zero-size descriptor), 2 = nt, 3 = sc1, 4 = sc0 sc1
+  int epi_ablate;      // diagnostic build (MVPTR_NT_EXP bits 26-30): 1 = aux rows not loaded, 2 = outputs not stored, 4 = no column-sum atomics,
+                       //   8 = GELU arithmetic skipped (identity), 16 = the A&S GELU of rounds 1-5 — where does an epilogue's time go
   int stash_temporal;  // diagnostic build (MVPTR_NT_EXP bit 9): EPI_BIAS_GELU stores gelu'(u) with plain instead of non-temporal stores (A/B)
   unsigned long long* stamps;  // diagnostic build only (MVPTR_GEMM_STAMPS): per-workgroup cycle sums
   // fused vocabulary decoder + cross entropy (mvptr_decoder_ce_fwd / _bwd)
@@ -115,6 +117,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
                                             int wm, int wn, int lane) {
   constexpr int WROWS = MT * 16;
   const int c16 = lane & 15, q4 = lane >> 4;
+#ifdef MVPTR_DIAG_BUILD
+  const int abl = p.epi_ablate;
+#else
+  constexpr int abl = 0;
+#endif
 
   const int ch = lane & 7, rsub = lane >> 3;
   const int n = n0 + wn * 64 + ch * 8;
@@ -138,6 +145,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   auto store_bf8 = [&](void* base, int m, const float v[8]) {
+    if (abl & 2) return;
     __bf16* op = (__bf16*)base + (int64_t)m * p.ldc + n;
     if (nfull && p.vec_out_ok) {
       bf16x8 o;
@@ -167,7 +175,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
         }
     }
   }
-  const bool has_aux = kNeedsAux && p.aux != nullptr;
+  const bool has_aux = kNeedsAux && p.aux != nullptr && !(abl & 1);
 
   // residual / pre-activation rows (aux): the four rows of a 32-row chunk are requested together, ONE CHUNK AHEAD of the
   // chunk being finished — issued in front of that chunk's stores, so they are older in the wave's in-order vmcnt queue
@@ -363,6 +371,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         f32x2 a2, d2;
+#ifdef MVPTR_DIAG_BUILD
+        if (abl & 8) a2 = d2 = f32x2{v[e], v[e + 1]};
+        else if (abl & 16) gelu_pair_as(f32x2{v[e], v[e + 1]}, a2, d2);
+        else
+#endif
         gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
         g[e] = a2.x;
         g[e + 1] = a2.y;
@@ -375,7 +388,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       uint8_t* dp = reinterpret_cast<uint8_t*>(p.out0) + (int64_t)m * p.ldc + n;
       const u32x2 dq = {dgelu_pack4_dither(dg[0], dg[1], dg[2], dg[3], v[0], v[1], v[2], v[3]),
                         dgelu_pack4_dither(dg[4], dg[5], dg[6], dg[7], v[4], v[5], v[6], v[7])};
-      if (nfull && p.vec_out_ok) {
+      if (abl & 2) {
+      } else if (nfull && p.vec_out_ok) {
 #ifdef MVPTR_DIAG_BUILD
         if (p.stash_temporal >= 2) {
           // A/B of the cache policy of these half-line (64 bytes per row and wave) stores: 2 = sc1, 3 = sc0 sc1, 4 = nt through
@@ -456,7 +470,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       store_bf8(p.out0, m, v);
     }
   }
-  if ((EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_GELU_BWD_BF16) && p.vec_out != nullptr) {
+  if ((EPI == MVPTR_EPI_GELU_BWD || EPI == MVPTR_EPI_GELU_BWD_BF16) && p.vec_out != nullptr && !(abl & 4)) {
     // sum the 8 row-lanes (lane>>3) that share a column chunk, then one atomic per column
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -548,30 +548,41 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const float* src, int64_
 }
 
 // row-major cast without a transposed copy (the 2054-d region features, modeling_vlbert.py:498 input: 105 MB f32 ->
-// 53 MB bf16 per 256-pair batch): one thread per 8 consecutive columns — four 8-byte loads (f32 rows of 2054
-// elements are 8-byte aligned), one 16-byte store; columns cols..ld_dst-1 are zero-filled
-__global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, int64_t ld_src, int rows, int cols, __bf16* dst,
-                                                         int64_t ld_dst, int chunks, int vec2) {
-  const int64_t total = (int64_t)rows * chunks;
-  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int r = (int)(e / chunks), c0 = (int)(e - (int64_t)r * chunks) * 8;
-    const float* sp = src + (int64_t)r * ld_src + c0;
-    float v[8];
-    if (vec2 && c0 + 7 < cols) {
+// 53 MB bf16 per 256-pair batch).  Round 6: ONE WAVE PER ROW.  A lane owns the 8-column pieces lane, lane + 64, ... of its row
+// (32 bytes of f32 in, one 16-byte store out: a wave instruction covers 2 KiB of contiguous source) and requests ALL of them
+// before it converts the first — 8 KiB in flight per wave, 16-byte loads (global loads only need dword alignment: rows of 2054
+// floats are 8-byte aligned), no integer division per element.  Rounds 3-5 gave a thread one piece (four 8-byte loads, a 64-bit
+// division to find its row) and streamed 3.4 TB/s; columns cols..ld_dst-1 are zero-filled.
+template <int PIECES>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, int64_t ld_src, int rows, int cols,
+                                                         __bf16* __restrict__ dst, int64_t ld_dst, int chunks) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* sp = src + (int64_t)r * ld_src;
+  __bf16* dp = dst + (int64_t)r * ld_dst;
+  for (int cb = 0; cb < chunks; cb += 64 * PIECES) {
+    f32x4 v[PIECES][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x2 x = *reinterpret_cast<const f32x2*>(sp + 2 * j);
-        v[2 * j] = x[0];
-        v[2 * j + 1] = x[1];
+    for (int j = 0; j < PIECES; ++j) {
+      const int c0 = (cb + j * 64 + lane) * 8;
+      if (c0 + 7 < cols) {
+        v[j][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + c0));
+        v[j][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + c0 + 4));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e >> 2][e & 3] = (c0 + e < cols) ? sp[c0 + e] : 0.f;
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (c0 + j < cols) ? sp[j] : 0.f;
     }
-    bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
-    *reinterpret_cast<bf16x8*>(dst + (int64_t)r * ld_dst + c0) = o;
+    for (int j = 0; j < PIECES; ++j) {
+      const int c = cb + j * 64 + lane;
+      if (c >= chunks) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[j][e >> 2][e & 3]);
+      *reinterpret_cast<bf16x8*>(dp + c * 8) = o;
+    }
   }
 }
 
@@ -952,12 +963,11 @@ extern "C" int mvptr_cast_pack(const float* src, int64_t ld_src, int rows, int c
   if (dst && !dst_t && (ld_dst & 7) == 0 && (((uintptr_t)dst) & 15) == 0 && wcols >= 64) {
     // row-major only: the vectorised row cast (whole 16-byte pieces of every destination row, pad columns included)
     const int chunks = (int)(ld_dst / 8);
-    const int vec2 = ((ld_src & 1) == 0 && (((uintptr_t)src) & 7) == 0) ? 1 : 0;
-    const int64_t total = (int64_t)rows * chunks;
-    int g = (int)((total + 255) / 256);
-    if (g > 32768) g = 32768;
-    hipLaunchKernelGGL(cast_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, (__bf16*)dst, ld_dst,
-                       chunks, vec2);
+    const int g = (rows + 3) / 4;
+    if ((ld_src & 1) == 0 && (((uintptr_t)src) & 7) == 0 && chunks > 128)
+      hipLaunchKernelGGL(cast_rows_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, (__bf16*)dst, ld_dst, chunks);
+    else
+      hipLaunchKernelGGL(cast_rows_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, src, ld_src, rows, cols, (__bf16*)dst, ld_dst, chunks);
     MVPTR_CHECK_LAUNCH("cast_pack");
     return MVPTR_OK;
   }

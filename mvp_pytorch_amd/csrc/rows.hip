@@ -353,7 +353,8 @@ extern "C" int mvptr_tap_rows_bwd(const mvptr_tap* taps, int ntaps, void* dst, i
 // pos.reshape(-1).index_select(idx)` — 7 small launches per head (oscar/modeling/modeling_vlbert.py:1231-1234,1245).
 namespace {
 __global__ __launch_bounds__(1024) void compact_scored_kernel(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L,
-                                                               int n_out, int64_t* out_labels, int32_t* out_rows) {
+                                                               int n_out, int64_t* out_labels, int32_t* out_rows,
+                                                               unsigned long long* err) {
   __shared__ int scan[1024];
   const int tid = threadIdx.x, total = B * L;
   const int per = (total + 1023) / 1024;
@@ -401,11 +402,19 @@ __global__ __launch_bounds__(1024) void compact_scored_kernel(const int64_t* lab
     k = scan[tid] - c;
     found = scan[1023];
   }
-  if (found > n_out) {
-    // fewer output slots than scored rows: the surplus would silently drop out of the loss (a stale or wrong scored-row count
-    // in host_counts).  More slots than rows is harmless (padded with -1 = ignored) and stays legal.
-    if (tid == 0) printf("mvptr_compact_scored: %d scored rows but only %d output slots (host_counts.scored_* does not describe this batch)\n", found, n_out);
-    __builtin_trap();
+  if (found > n_out && tid == 0) {
+    // fewer output slots than scored rows: the surplus drops out of the loss (a stale or wrong scored-row count in host_counts,
+    // ADVICE r04).  More slots than rows is harmless (padded with -1 = ignored) and stays legal.  Nothing below goes out of
+    // bounds, so the kernel does not trap (rounds 4-5 did: the whole process died where the reference raises catchably):
+    // it reports through the caller's error word — the first error wins — and the host raises at its next count read-back.
+    if (err != nullptr) {
+      if (atomicCAS(err, 0ull, (unsigned long long)MVPTR_DEV_ERR_SCORED_ROWS) == 0ull) {
+        err[1] = (unsigned long long)found;
+        err[2] = (unsigned long long)n_out;
+      }
+    } else {
+      printf("mvptr_compact_scored: %d scored rows but only %d output slots (host_counts.scored_* does not describe this batch)\n", found, n_out);
+    }
   }
   if (fast) {
 #pragma unroll
@@ -442,20 +451,23 @@ __global__ __launch_bounds__(1024) void compact_scored_kernel(const int64_t* lab
 }  // namespace
 
 extern "C" int mvptr_compact_scored(const int64_t* labels, const int32_t* pos, int64_t ld_pos, int B, int L, int n_out,
-                                    int64_t* out_labels, int32_t* out_rows, void* stream) {
+                                    int64_t* out_labels, int32_t* out_rows, int64_t* err, void* stream) {
   if (B <= 0 || L <= 0 || n_out < 0 || (int64_t)B * L >= (int64_t)1 << 30 || !labels || (n_out > 0 && (!out_labels || !out_rows)) ||
       (pos && ld_pos < L))
     MVPTR_FAIL(MVPTR_BAD_ARG, "compact_scored: bad argument");
   if (n_out == 0) return MVPTR_OK;
   hipLaunchKernelGGL(compact_scored_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, pos, ld_pos, B, L, n_out, out_labels,
-                     out_rows);
+                     out_rows, reinterpret_cast<unsigned long long*>(err));
   MVPTR_CHECK_LAUNCH("compact_scored");
   return MVPTR_OK;
 }
 
 // Host-provided counts against the device's (sync-free training step: the input-only counts of a batch come from where
-// the batch was built; the pack maps count them again on the device).  A mismatch is a caller bug that would silently
-// truncate or over-read the packed rows: trap.
+// the batch was built; the pack maps count them again on the device).  A mismatch is a broken caller contract, not bad data:
+// every buffer, grid and LDS tile of the step has been sized from the host's numbers, so kernels queued behind this one would
+// index past their buffers.  This is the one check that still TRAPS (round 6 turned the others into the device error word):
+// stopping the queue is the only safe continuation.  model.verify_host_counts = True checks on the host instead (one
+// read-back, catchable ValueError) while a data pipeline is being brought up.
 namespace {
 __global__ void check_counts_kernel(const int64_t* a, const int64_t* b, int64_t ra, int64_t la, int64_t rb, int64_t lb) {
   if (a[0] != ra || a[1] != la || b[0] != rb || b[1] != lb) {

@@ -73,6 +73,8 @@ several rings/trees over the links in parallel).
 """
 import contextlib
 
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -117,6 +119,8 @@ def default_exchange(model):
 
 
 class GradSync:
+    _logged_exchange = False
+
     def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="default", sparse_rows="default",
                  force_collectives=False, demote_after=8, check_mixed_use=False, collective="all_reduce"):
         self.check_mixed_use = check_mixed_use
@@ -173,10 +177,18 @@ class GradSync:
         self._build()
         self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         engine.set_grad_sink(self)
+        self._restore_reserve = None
         if self.world > 1 and backend == "nccl" and engine.WGRAD_RESERVE_CUS == 0:
             # the stack-wide weight-gradient launch (engine.EncoderFn) keeps every CU it gets for 0.6 - 3 ms: leave a few to
-            # the collectives' kernels so that buckets already on the wire keep moving meanwhile
-            engine.WGRAD_RESERVE_CUS = 16
+            # the collectives' kernels so that buckets already on the wire keep moving meanwhile (a sixteenth of the CUs;
+            # close() puts the previous value back: the setting is process-wide)
+            self._restore_reserve = engine.WGRAD_RESERVE_CUS
+            ncu = torch.cuda.get_device_properties(self.params[0].device).multi_processor_count if self.params and self.params[0].is_cuda else 256
+            engine.WGRAD_RESERVE_CUS = max(8, ncu // 16)
+        if self.exchange and not GradSync._logged_exchange:
+            GradSync._logged_exchange = True
+            print("[mvptr] GradSync exchange: wire %s, %d row-sparse table(s), collective %s, world %d" %
+                  (str(self.comm_dtype).replace("torch.", ""), len(self.sparse), self.collective, self.world), file=sys.stderr)
         self.zero_grad()
 
     def close(self):
@@ -191,6 +203,9 @@ class GradSync:
                 engine._SINKS.pop(id(p), None)
         if engine.grad_sink() is self:
             engine._last_sink_ref[0] = None
+        if self._restore_reserve is not None:
+            engine.WGRAD_RESERVE_CUS = self._restore_reserve
+            self._restore_reserve = None
 
     # ------------------------------------------------------------------ bucket layout
     def _build(self):

@@ -571,10 +571,17 @@ class AsyncCounts:
     _pins = {}
 
     def __init__(self, values):
-        t = torch.stack([v.reshape(()) for v in values]).to(torch.int64)
+        self._n = len(values)
+        vals = [v.reshape(()) for v in values]
+        if vals and vals[0].is_cuda:
+            # every count copy carries the device error word along (hip.device_error_word): the host's next look at the device
+            # is also its look at the data-dependent checks queued since the last one
+            vals.append(hip.device_error_word(vals[0].device)[0])
+        t = torch.stack([v.to(torch.int64) for v in vals])
         if not t.is_cuda:
             self._host, self._event = t, None
             return
+        self._device = t.device
         # one small ring of pinned buffers per (device, count): a device is driven by one thread at a time (its
         # nn.DataParallel replica), and those threads are new ones in every forward pass, so the thread is not part of the key
         key = (t.device.index, t.numel())
@@ -593,7 +600,12 @@ class AsyncCounts:
     def get(self):
         if self._event is not None:
             self._event.synchronize()
-        return [int(v) for v in self._host.tolist()]
+        out = [int(v) for v in self._host.tolist()]
+        if len(out) > self._n:
+            if out[self._n]:
+                hip.raise_device_error(out[self._n], self._device)
+            out = out[:self._n]
+        return out
 
 
 class PackRows(torch.autograd.Function):
@@ -742,6 +754,7 @@ class EncoderFn(GradAwareFunction):
         probs = (hip.TnProblem * (4 * n))() if defer else None
         n_probs = 0
         delivered_later = []
+        convert_later = []
         sizes = [3 * H * H, 3 * H, H * H, H, H, H, I * H, I, H * I, H, H, H]
         total = sum(sizes)
         grads = [None] * (16 * n)
@@ -797,7 +810,11 @@ class EncoderFn(GradAwareFunction):
                 for j in range(16):
                     p = ps[j]
                     if p.requires_grad:
-                        grads[16 * li + j] = gl[j] if p.dtype == torch.float32 else gl[j].to(p.dtype)
+                        # deferred mode: the four weight gradients and two column-sum bias gradients of this scratch arena are only
+                        # written by the stack-wide launch below, so a dtype conversion must wait for it
+                        grads[16 * li + j] = gl[j]
+                        if p.dtype != torch.float32:
+                            convert_later.append((16 * li + j, p.dtype))
             d_cur = dx
         if defer and n_probs > 0:
             rd = meta.rows_dev.data_ptr() if (meta.rows and meta.rows_dev is not None) else None
@@ -806,6 +823,8 @@ class EncoderFn(GradAwareFunction):
             hip._check(lib.mvptr_gemm_tn_stack(probs, n_probs, ctypes.c_void_p(rd) if rd else None, max_wg, stream))
         for p in delivered_later:
             sink.delivered(p)
+        for k, dt in convert_later:
+            grads[k] = grads[k].to(dt)
         ctx.stashes = ctx.xs = None
         return (d_cur, None, None) + tuple(grads)
 

@@ -27,8 +27,8 @@ SYMBOLS = [
     "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
-    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features", "mvptr_diag_stream_read",
-    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd", "mvptr_diag_store_probe", "mvptr_diag_fill_probe",
+    "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features",
+    "mvptr_decoder_ce_fwd", "mvptr_decoder_ce_bwd",
     "mvptr_adamw_mirror_multi", "mvptr_sumsq_partials", "mvptr_sumsq_partial", "mvptr_clip_coef",
     "mvptr_sgemm_small", "mvptr_l2norm_fwd", "mvptr_l2norm_bwd", "mvptr_clip_ce_fwd", "mvptr_clip_ce_bwd",
     "mvptr_gather_rows", "mvptr_scatter_add_rows", "mvptr_ce_mean_small", "mvptr_pack_maps", "mvptr_gemm_nt_splitk",
@@ -38,6 +38,8 @@ SYMBOLS = [
     "mvptr_masked_mean", "mvptr_dgelu_mul", "mvptr_compact_scored",
     "mvptr_gemm_tn_stack", "mvptr_encoder_layer_bwd_defer",
 ]
+# include/mvptr_diag.h: exported by the diagnostic build only (MVPTR_LIB=diag)
+DIAG_SYMBOLS = ["mvptr_diag_stream_read", "mvptr_diag_store_probe", "mvptr_diag_fill_probe", "mvptr_set_knob"]
 
 
 class Dropout(Structure):
@@ -141,7 +143,7 @@ def load():
     lib.mvptr_bce_logits.argtypes = [P, P, I, I, P, P, P, I, P]
     lib.mvptr_check_counts.argtypes = [P, P, I64, I64, I64, I64, P]
     lib.mvptr_masked_mean.argtypes = [P, P, I, P, P]
-    lib.mvptr_compact_scored.argtypes = [P, P, I64, I, I, I, P, P, P]
+    lib.mvptr_compact_scored.argtypes = [P, P, I64, I, I, I, P, P, P, P]
     lib.mvptr_dgelu_mul.argtypes = [P, I64, P, I64, I, P, I64, I, I, I, P]
     lib.mvptr_tap_rows_bwd.argtypes = [POINTER(Tap), I, P, I64, I, P, I64, I, I, P, I64, P]
     lib.mvptr_l2norm_fwd.argtypes = [P, P, P, I, I, F, P]
@@ -155,9 +157,10 @@ def load():
     lib.mvptr_wra_fwd.argtypes = [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]
     lib.mvptr_wra_bwd.argtypes = [P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P]
     lib.mvptr_b64_decode_features.argtypes = [P, P, P, P, I, I, I, P, P, I64, P, P]
-    lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
-    lib.mvptr_diag_store_probe.argtypes = [P, I64, I, I64, I, I64, P]
-    lib.mvptr_diag_fill_probe.argtypes = [P, I64, I, I64, I, I, I, P, P]
+    if hasattr(lib, "mvptr_diag_stream_read"):      # diagnostic build only (include/mvptr_diag.h)
+        lib.mvptr_diag_stream_read.argtypes = [P, I64, I, P, P]
+        lib.mvptr_diag_store_probe.argtypes = [P, I64, I, I64, I, I64, P]
+        lib.mvptr_diag_fill_probe.argtypes = [P, I64, I, I64, I, I, I, P, P]
     lib.mvptr_decoder_ce_fwd.argtypes = [P, I64, P, I64, P, P, I, I, I, P, P, P, P, P]
     lib.mvptr_decoder_ce_bwd.argtypes = [P, I64, P, I64, P, P, P, P, I, I, I, P, I64, I, P]
     lib.mvptr_encoder_layer_fwd.argtypes = [POINTER(LayerDesc), POINTER(LayerWeights), P, P, P, P, P, I64, P]
@@ -478,22 +481,29 @@ def decoder_ce_bwd(h, w, bias, labels, lse_row, scale, V, Vp):
     return d
 
 
+def _diag_lib():
+    lib = load()
+    if not hasattr(lib, "mvptr_diag_stream_read"):
+        raise RuntimeError("the measurement helpers live in the diagnostic library only: `make -C mvp_pytorch_amd/csrc diag` and MVPTR_LIB=diag")
+    return lib
+
+
 def diag_store_probe(buf, blocks, bytes_per_wave, rows_per_instr, stride):
-    """Measurement helper: store-rate probe (see mvptr.h)."""
-    _check(load().mvptr_diag_store_probe(_p(buf), buf.numel() * buf.element_size(), blocks, bytes_per_wave, rows_per_instr,
+    """Measurement helper: store-rate probe (see mvptr_diag.h)."""
+    _check(_diag_lib().mvptr_diag_store_probe(_p(buf), buf.numel() * buf.element_size(), blocks, bytes_per_wave, rows_per_instr,
                                          stride, _stream()))
 
 
 def diag_fill_probe(buf, blocks, wg_bytes, reps, shared, mode, sink):
-    """Measurement helper: operand-fill probe (see mvptr.h)."""
-    _check(load().mvptr_diag_fill_probe(_p(buf), buf.numel() * buf.element_size(), blocks, wg_bytes, reps, int(shared), mode,
+    """Measurement helper: operand-fill probe (see mvptr_diag.h)."""
+    _check(_diag_lib().mvptr_diag_fill_probe(_p(buf), buf.numel() * buf.element_size(), blocks, wg_bytes, reps, int(shared), mode,
                                         _p(sink), _stream()))
 
 
 def diag_stream_read(buf, mode, sink):
     """Calibration helper: read every byte of `buf` once (mode 0: LDS-DMA, mode 1: global loads)."""
     nbytes = buf.numel() * buf.element_size()
-    _check(load().mvptr_diag_stream_read(_p(buf), nbytes, mode, _p(sink), _stream()))
+    _check(_diag_lib().mvptr_diag_stream_read(_p(buf), nbytes, mode, _p(sink), _stream()))
 
 
 def b64_decode_features(text, offsets, n_chars, num_boxes, R, D, out_f32=None, out_bf16=None, err=None):
@@ -697,6 +707,67 @@ def scatter_add_rows(src, idx, dst, dst2=None):
     return dst
 
 
+# ---------------------------------------------------------------------------------------------
+# Device error word (ABI 7): data-dependent failures that the reference raises catchably (modeling_vlbert.py:435,542,1547) are
+# detected by kernels / queued device ops long after the host has moved on.  Rounds 4-5 trapped or used torch._assert_async — on
+# ROCm both abort the whole process.  Now such a check writes a code into a small per-device int64 word; the host looks at it
+# whenever it reads ANYTHING back from that device (engine.AsyncCounts carries word[0] along with every count copy;
+# check_device_errors() reads it explicitly) and raises RuntimeError there, one step late at most, with the process intact.
+DEV_ERR_SCORED_ROWS, DEV_ERR_PHRASES, DEV_ERR_FEW_REGIONS = 1, 2, 3
+DEV_ERR_TEXT = {
+    DEV_ERR_SCORED_ROWS: "more scored (label > -1) slots than the host's count: host_counts.scored_* does not describe this batch",
+    DEV_ERR_PHRASES: "a sample has more phrases than config.max_phrases",
+    DEV_ERR_FEW_REGIONS: "word-region alignment needs >= 3 valid regions per image (topk(3), modeling_vlbert.py:1547)",
+}
+_err_words = {}
+
+
+def device_error_word(device):
+    """int64 [4] on `device` (code, detail, detail, unused); zero = no error"""
+    key = torch.device(device).index if torch.device(device).type == "cuda" else -1
+    if key == -1:
+        return None
+    w = _err_words.get(key)
+    if w is None:
+        w = _err_words[key] = torch.zeros(4, dtype=torch.int64, device=device)
+    return w
+
+
+def flag_device_error_if(bad, code):
+    """queue `if bad: word[0] = code` on bad's device (bad: 0-dim bool tensor, e.g. `(x > limit).any()`); ONE small launch, no
+    host sync (torch._assert_async cost the same launch and aborted the process)"""
+    w = device_error_word(bad.device)
+    if w is None:       # CPU tensors: the host can simply look
+        if bool(bad):
+            raise RuntimeError(DEV_ERR_TEXT[code])
+        return
+    w[:1].masked_fill_(bad.reshape(1), code)
+
+
+def raise_device_error(code, device=None):
+    """host side of the error word: called with word[0] as read back; clears the word and raises"""
+    code = int(code)
+    if code == 0:
+        return
+    detail = ""
+    if device is not None:
+        w = device_error_word(device)
+        if w is not None:
+            vals = [int(v) for v in w.tolist()]
+            if code == DEV_ERR_SCORED_ROWS:
+                detail = " (%d scored rows, %d slots)" % (vals[1], vals[2])
+            w.zero_()
+    raise RuntimeError("device-side check failed: " + DEV_ERR_TEXT.get(code, "error code %d" % code) + detail)
+
+
+def check_device_errors(device=None):
+    """read the error word(s) now (synchronises) and raise if a device-side check has failed since the last look"""
+    for key, w in list(_err_words.items()):
+        if device is not None and torch.device(device).index != key:
+            continue
+        raise_device_error(int(w[0].item()), w.device)
+
+
 def compact_scored(labels, pos, n_out):
     """labels int64 [B, L] (contiguous), pos int32 [*, ld] row map (its first B rows / L columns are read; None: flat slot index)
     -> (labels of the slots with label > -1 in ascending slot order int64 [n_out], their rows int32 [n_out]) — mvptr_compact_scored."""
@@ -705,7 +776,8 @@ def compact_scored(labels, pos, n_out):
     assert pos is None or (pos.dtype == torch.int32 and pos.stride(-1) == 1 and pos.shape[0] >= B and pos.shape[1] >= L)
     ol = torch.empty(n_out, dtype=torch.int64, device=labels.device)
     orow = torch.empty(n_out, dtype=torch.int32, device=labels.device)
-    _check(load().mvptr_compact_scored(_p(labels), _p(pos), pos.stride(0) if pos is not None else 0, B, L, int(n_out), _p(ol), _p(orow), _stream()))
+    _check(load().mvptr_compact_scored(_p(labels), _p(pos), pos.stride(0) if pos is not None else 0, B, L, int(n_out), _p(ol), _p(orow),
+                                       _p(device_error_word(labels.device)), _stream()))
     return ol, orow
 
 

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn import CrossEntropyLoss, MSELoss
 
-from .. import engine
+from .. import engine, hip
 from .modeling_bert import (BertConfig, BertEmbeddings, BertLayer, BertLayerNorm, BertLMPredictionHead,
                             BertPooler, BertPreTrainedModel, BertQAPredictionHead, HeadLinear, embed_inputs)
 from .modeling_utils import ImgPreTrainedModel
@@ -594,7 +594,13 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             main.wait_stream(side)
         if host_counts is not None:
             ra, la_max, rb, lb_max = (int(host_counts[k]) for k in ("rows_a", "lmax_a", "rows_b", "lmax_b"))
-            hip.check_counts(cnt_a, cnt_b, (ra, la_max, rb, lb_max))      # device-side: host_counts must describe this batch's masks
+            if getattr(self, "verify_host_counts", False):
+                # bring-up mode of a data pipeline: one read-back, a catchable error instead of the device-side trap
+                got = [int(v) for v in torch.cat([cnt_a, cnt_b]).tolist()]
+                if got != [ra, la_max, rb, lb_max]:
+                    raise ValueError("host_counts (rows_a, lmax_a, rows_b, lmax_b) = %r, the masks give %r" % ([ra, la_max, rb, lb_max], got))
+            else:
+                hip.check_counts(cnt_a, cnt_b, (ra, la_max, rb, lb_max))      # device-side: host_counts must describe this batch's masks
         else:
             ra, la_max, rb, lb_max = counts.get()
         xa_p = engine.tap_rows(xa.view(B * La, H), idx_a[:ra])
@@ -885,7 +891,7 @@ def wra_sample_on_device(seq, phrase_index, img_index, text_len, draws=None, max
     Pw = int(max_phrases) if max_phrases else text_len
     p0, p1, i0, i1 = phrase_index[:, 0], phrase_index[:, 1], img_index[:, 0], img_index[:, 1]
     if max_phrases:
-        torch._assert_async(((p1 - p0) <= Pw).all(), "a sample has more phrases than config.max_phrases")
+        hip.flag_device_error_if(((p1 - p0) > Pw).any(), hip.DEV_ERR_PHRASES)      # raised at the host's next read-back (hip.py)
     ar_p = engine.arange(Pw, dev)
     rows_p = (p0[:, None] + ar_p[None, :]).clamp(max=Lj - 1)                              # [B, Pw]
     valid_p = ar_p[None, :] < (p1 - p0)[:, None]
@@ -1083,15 +1089,14 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
             Pw = int(getattr(self.config, "max_phrases", None) or La)
             Rw = Lj - La
             if getattr(self.config, "max_phrases", None):
-                torch._assert_async(((phrase_index[:, 1] - phrase_index[:, 0]) <= Pw).all(),
-                                    "a sample has more phrases than config.max_phrases")
+                hip.flag_device_error_if(((phrase_index[:, 1] - phrase_index[:, 0]) > Pw).any(), hip.DEV_ERR_PHRASES)
             # topk(3) of the reference (vl:1547) raises — catchably, and only for a sample that HAS phrases (t2i_sim returns 0
-            # for an empty phrase set) — when an image has fewer than 3 regions.  A device-side assert would abort the whole
+            # for an empty phrase set) — when an image has fewer than 3 regions.  A device-side assert (rounds 3-5) aborted the whole
             # process on ROCm for any such image: the kernel clamps the drawn rank to the regions that exist
             # (csrc/wra.hip) unless config.wra_strict asks for the reference's failure, restricted to samples with phrases.
             if getattr(self.config, "wra_strict", False):
                 few = ((img_index[:, 1] - img_index[:, 0]) < 3) & ((phrase_index[:, 1] - phrase_index[:, 0]) > 0)
-                torch._assert_async((~few).all(), "word-region alignment needs >= 3 valid regions per image (topk(3), vl:1547)")
+                hip.flag_device_error_if(few.any(), hip.DEV_ERR_FEW_REGIONS)
             rows_p, rows_r = hip.wra_rows(pos_j, phrase_index, img_index, n, Pw, Rw)
             idxs += [rows_p.view(-1), rows_r.view(-1)]
         taps = engine.MultiTapFn.apply(both, None, *idxs)
@@ -1153,8 +1158,11 @@ class BiBertImgForPreTraining(ImgPreTrainedModel):
         needs on the host (valid rows / longest sequence of both inputs, scored MLM rows), computed where the batch was
         built, so that the row-packed training step does not read them back from the device.  They MUST describe this
         batch: the device checks them against the masks and the labels (mvptr_check_counts: rows / longest sequence;
-        mvptr_compact_scored: no more scored rows than slots) and a mismatch TRAPS — on ROCm the process aborts with both sets
-        of numbers printed; train.model_inputs rejects counts that cannot fit the batch's shapes before anything is queued.
+        mvptr_compact_scored: no more scored rows than slots).  Wrong row / longest-sequence counts TRAP (every buffer behind
+        them is sized from the host's numbers: the process aborts with both sets printed; `model.bert.verify_host_counts = True`
+        checks on the host with one read-back and raises ValueError instead); too many scored rows raise RuntimeError at the
+        host's next count read-back (hip.device_error_word); train.model_inputs rejects counts that cannot fit the batch's shapes
+        before anything is queued.
         Recompute them (synthetic.host_counts) whenever a collated batch is edited, or leave the argument out."""
         if (self.packed_pipeline and self.training and masked_lm_labels_a is not None and masked_lm_labels_b is not None and
                 head_mask is None and phrase_mod == "sample" and (phrase_index is None or (img_index is not None and self.wra_on_device)) and

@@ -1,6 +1,8 @@
 """Pre-training step harness: the counterpart of `forward_backward` + optimizer step in
 oscar/run_pretrain_ml.py:519-562,632-644 (DeepSpeed branch call signature :528-531, without
 DeepSpeed), plus the data-parallel gradient exchange."""
+import inspect
+
 import torch
 
 from .optimization import AdamW, WarmupLinearSchedule
@@ -25,7 +27,7 @@ def model_inputs(batch, max_tag_length):
     hc = batch.get("host_counts")
     if hc is not None and "input_mask_a" in batch:
         # cheap host-side sanity of counts a caller may have carried over from another batch (the device-side checks —
-        # mvptr_check_counts on rows / longest sequence, mvptr_compact_scored on the scored rows — ABORT the process on a mismatch)
+        # mvptr_check_counts on rows / longest sequence — traps on a mismatch; mvptr_compact_scored on the scored rows — raises at the next read-back)
         ma, mb = batch["input_mask_a"], batch["input_mask_b"]
         ok = (0 < int(hc["rows_a"]) <= ma.numel() and 0 < int(hc["rows_b"]) <= mb.numel() and 0 < int(hc["lmax_a"]) <= ma.shape[1]
               and 0 < int(hc["lmax_b"]) <= mb.shape[1] and 0 <= int(hc["scored_a"]) <= ma.numel() and 0 <= int(hc["scored_b"]) <= mb.numel())
@@ -65,6 +67,15 @@ def clip_coefficient(model, grad_sync, max_grad_norm):
     return None
 
 
+def _takes_want_norm(fn):
+    """dp.GradSync (and anything with its call signature) is told whether the clip norm is wanted; a plain callable is not"""
+    try:
+        params = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return "want_norm" in params or any(p.kind == inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_weight=1.0, max_grad_norm=0.0,
                   grad_sync=None, return_losses=False):
     """One optimisation step.  grad_sync: optional callable run between backward and the
@@ -79,9 +90,9 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
     loss = loss_weight * outputs[0]
     loss.backward()
     if grad_sync is not None:
-        try:
+        if _takes_want_norm(grad_sync):     # chosen up front: an exception inside the exchange must not re-run it
             grad_sync(want_norm=max_grad_norm > 0)
-        except TypeError:           # a plain callable
+        else:                               # a plain callable
             grad_sync()
     grad_scale = None
     if max_grad_norm > 0:

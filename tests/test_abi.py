@@ -25,12 +25,18 @@ def test_library_exports_header_symbols():
     for s in syms:
         assert hasattr(lib, s), "missing export: " + s
     assert sorted(hip.SYMBOLS) == syms
+    # the measurement helpers are declared in mvptr_diag.h and live in the diagnostic build only
+    for s in hip.DIAG_SYMBOLS:
+        assert not hasattr(lib, s), "diagnostic export in the product library: " + s
+    dtext = open(os.path.join(ROOT, "include", "mvptr_diag.h")).read()
+    dtext = re.sub(r"/\*.*?\*/", "", dtext, flags=re.S)
+    assert sorted(set(re.findall(r"\b(mvptr_[a-z0-9_]+)\s*\(", dtext))) == sorted(hip.DIAG_SYMBOLS)
 
 
 def test_abi_version_and_error_string():
     from mvp_pytorch_amd import hip
     lib = hip.load()
-    assert hip.query(0) == 6   # MVPTR_ABI_VERSION (6: mvptr_gemm_nt_ln + mvptr_ln_stats_finalize; 5: mvptr_gemm_tn_stack + mvptr_encoder_layer_bwd_defer; 4: 8-bit gelu' stash)
+    assert hip.query(0) == 7   # MVPTR_ABI_VERSION (7: device error word of mvptr_compact_scored, mvptr_diag_* out of the product library; 6: mvptr_gemm_nt_ln + mvptr_ln_stats_finalize; 5: mvptr_gemm_tn_stack + mvptr_encoder_layer_bwd_defer; 4: 8-bit gelu' stash)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.mvptr_gemm_nt(None, 8, None, 8, 0, 8, 8, 0, None, None, 0, None, None, 8, None, None, None)
     assert rc == -1

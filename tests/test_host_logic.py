@@ -690,3 +690,17 @@ def test_stream_policy_by_backend(monkeypatch):
     assert not _streams_allowed(True) and _streams_allowed("always") and not _streams_allowed("single_rank")
     monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 1)
     assert _streams_allowed(True) and _streams_allowed("single_rank")
+
+
+def test_device_error_word_host_side():
+    """hip.flag_device_error_if / engine.AsyncCounts on CPU tensors: the host can look at once, so the check raises in place
+    (the device path — a word carried along with every count copy — is covered by tests/test_ops_gpu.py::test_compact_scored_rows)."""
+    import torch
+    from mvp_pytorch_amd import engine, hip
+    hip.flag_device_error_if(torch.tensor(False), hip.DEV_ERR_PHRASES)
+    with pytest.raises(RuntimeError, match="max_phrases"):
+        hip.flag_device_error_if(torch.tensor(True), hip.DEV_ERR_PHRASES)
+    assert engine.AsyncCounts([torch.tensor(3), torch.tensor(9)]).get() == [3, 9]
+    with pytest.raises(RuntimeError, match="device-side check failed: .*3 valid regions"):
+        hip.raise_device_error(hip.DEV_ERR_FEW_REGIONS)
+    hip.raise_device_error(0)

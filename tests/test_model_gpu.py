@@ -1281,8 +1281,24 @@ def test_sync_free_joint_pass_and_host_counts(dev):
     worst = max((_rel(gb[n], ga[n]), n) for n in ga if ga[n].norm() > 1e-6 and not n.endswith("attention.self.key.bias"))
     print("worst gradient rel L2", worst)
     assert worst[0] < 1e-2, worst
-    # (host_counts that do not describe the batch trip torch._assert_async on the device — on ROCm that aborts the
-    #  process, which is the intended "fail loudly"; not exercised here for that reason)
+    # (host_counts whose row / longest-sequence numbers do not describe the batch trap on the device — every buffer behind them
+    #  is sized from them — and are not exercised here; bert.verify_host_counts checks on the host instead, below)
+    model.bert.verify_host_counts = True
+    hc = batch["host_counts"]
+    bad = dict(hc, rows_a=int(hc["rows_a"]) - 1)
+    with pytest.raises(ValueError, match="host_counts"):
+        model(**dict(kw, host_counts=bad))
+    model.bert.verify_host_counts = False
+    # too few slots for the scored rows: the step runs (the surplus rows drop out of the loss), the device error word is set and
+    # the host raises at its next look — catchably, the process stays alive (ABI 5-6: trap)
+    from mvp_pytorch_amd import hip
+    hip.check_device_errors(dev)
+    short = dict(hc, scored_a=max(int(hc["scored_a"]) - 2, 1))
+    with Replay(dict(draw_randperm=[perm.numpy()]), dev):
+        out = model(**dict(kw, host_counts=short))
+    assert torch.isfinite(out[0]).all()
+    with pytest.raises(RuntimeError, match="more scored"):
+        hip.check_device_errors(dev)
 
 
 @pytest.mark.parametrize("bound,rows,plan", [(20000, 9000, 4500), (9000, 9000, 4500), (3000, 1100, 550),
@@ -1397,6 +1413,43 @@ def test_deferred_stack_weight_gradients_equal_per_layer(dev, layers, rows, drop
         # rounding per summand apart (measured 1.6e-3)
         tol = 5e-3 if n.endswith("intermediate.dense.bias") else 2e-5
         assert _rel(g1[n], g0[n]) < tol, (n, _rel(g1[n], g0[n]))
+
+
+def test_deferred_weight_gradients_reach_non_f32_parameters(dev):
+    """with deferred weight gradients the scratch arena of a layer whose parameters are NOT f32 is only
+    complete after the stack-wide launch; the conversion to the parameter's dtype used to run inside the layer loop and handed
+    autograd zeros for Wqkv / bqkv / Wo / Wi / bi / Wout.  A bf16-parameter stack must get the gradients the per-layer path gives."""
+    from mvp_pytorch_amd import engine, modeling
+    cfg = dict(gu.BASE_CFG, num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    enc = modeling.modeling_vlbert.CaptionBertEncoder(modeling.make_config(cfg)).to(dev).to(torch.bfloat16).train()
+    g = torch.Generator().manual_seed(5)
+    B, L = 40, 64
+    x = (torch.randn(B * L, 768, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.randn(B * L, 768, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    starts = (torch.arange(B, dtype=torch.int32) * L).to(dev)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+
+    def run(defer):
+        prev = engine.DEFER_WGRAD
+        engine.DEFER_WGRAD = defer
+        try:
+            enc.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            enc.forward_rows(xin, starts, lens, B, L).backward(dy)
+            torch.cuda.synchronize()
+            return {n: p.grad.float().clone() for n, p in enc.named_parameters()}
+        finally:
+            engine.DEFER_WGRAD = prev
+
+    g0, g1 = run(False), run(True)
+    assert set(g0) == set(g1) and len(g0) == 32
+    for n in g0:
+        if n.endswith("attention.self.key.bias"):
+            continue
+        assert g0[n].norm() > 0 and g1[n].norm() > 0, n
+        assert all(p.grad.dtype == torch.bfloat16 for p in enc.parameters())
+        assert _rel(g1[n], g0[n]) < 8e-3, (n, _rel(g1[n], g0[n]))
 
 
 def test_gelu_stash_formats_agree(dev):

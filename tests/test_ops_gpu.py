@@ -102,6 +102,40 @@ def test_gemm_nt_epilogues(dev):
     assert _rel(hip.dgelu_mul(dyh, gq), dyh.float() * hip.dgelu_decode(gq)) < 3e-3
 
 
+def test_gelu_epilogue_function_values(dev):
+    """Round 6: the GELU pair of the FFN1 epilogue is a degree-8 minimax polynomial for Phi - 1/2 on |x| <= 4.3 with ONE exp
+    (common.h gelu_pair) instead of A&S 7.1.26 (exp + rcp).  A zero product + a bias that sweeps [-9, 9] puts known pre-activations
+    through the epilogue: gelu(x) and gelu'(x) against float64 erf (modeling_bert.py:142-148) to far below the output's bf16
+    rounding, and the exact tails the `clamp` bit of the last v_pk_fma_f32 provides (Phi = 0 / 1 beyond |x| = 4.3)."""
+    import math
+    from mvp_pytorch_amd import hip
+    N, K, M = 8192, 64, 32
+    x = torch.linspace(-9.0, 9.0, N, dtype=torch.float64)
+    x[N // 2] = 0.0
+    bias = x.float().to(dev)
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros(N, K, dtype=torch.bfloat16, device=dev)
+    d16, act = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU_BF16, bias=bias)
+    xf = bias.double().cpu()
+    cdf = 0.5 * (1.0 + torch.erf(xf / math.sqrt(2.0)))
+    want = xf * cdf
+    dwant = cdf + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2.0 * math.pi)
+    got, dgot = act[0].double().cpu(), d16[0].double().cpu()
+    assert torch.equal(act, act[0:1].expand_as(act)) and torch.equal(d16, d16[0:1].expand_as(d16))
+    # function error (2e-5 |x| at most) + half a bf16 ulp of the result
+    assert ((got - want).abs() <= 2.0 ** -9 * want.abs() + 2.5e-5 * xf.abs() + 1e-9).all(), float((got - want).abs().max())
+    assert ((dgot - dwant).abs() <= 2.0 ** -9 * dwant.abs() + 2e-4).all(), float((dgot - dwant).abs().max())
+    hi, lo = xf >= 4.3001, xf <= -4.3001
+    assert torch.equal(got[hi], xf[hi].float().to(torch.bfloat16).double())       # Phi clamps to exactly 1 ...
+    assert (got[lo] == 0).all()                                                   # ... and exactly 0
+    assert (dgot[hi] - 1.0).abs().max() < 4e-3 and dgot[lo].abs().max() < 2e-4
+    assert float(got[N // 2]) == 0.0 and abs(float(dgot[N // 2]) - 0.5) < 1e-6
+    # the 8-bit stash of the same derivative: one grid step
+    dq, act8 = hip.gemm_nt(a, b, hip.EPI_BIAS_GELU, bias=bias)
+    assert torch.equal(act8, act)
+    assert (hip.dgelu_decode(dq)[0].double().cpu() - dwant).abs().max() < 0.005 + 2e-4
+
+
 @pytest.mark.parametrize("M,N,K", [(16500, 768, 768), (16700, 2304, 768), (17000, 3072, 768), (16641, 768, 3072), (16900, 768, 2304),
                                    (70000, 768, 768), (33000, 3072, 256), (37748, 768, 2304), (10917, 768, 768),
                                    (11143, 3072, 768), (10917, 768, 3072)])
@@ -560,8 +594,20 @@ def test_compact_scored_rows(dev):
         assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), want_r)
         ol, orow = hip.compact_scored(labels.to(dev), None, n)
         assert torch.equal(ol.cpu(), want_l) and torch.equal(orow.cpu(), idx.to(torch.int32))
-        # (fewer output slots than scored rows is a caller bug since ABI 5: the kernel traps — on ROCm the process aborts, so
-        #  that case is not exercised here)
+        # fewer output slots than scored rows is a caller bug: since ABI 7 the kernel cuts the surplus, stays in bounds and
+        # reports through the device error word; the host raises at its next read-back (ABI 5-6 trapped: the process died)
+        if n > 3:
+            ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n - 3)
+            assert torch.equal(ol.cpu(), want_l[:n - 3]) and torch.equal(orow.cpu(), want_r[:n - 3])
+            with pytest.raises(RuntimeError, match=r"more scored .* \(%d scored rows, %d slots\)" % (n, n - 3)):
+                hip.check_device_errors(dev)
+            hip.check_device_errors(dev)          # the word was cleared by the raise
+            from mvp_pytorch_amd import engine
+            hip.compact_scored(labels.to(dev), pos.to(dev), n - 1)
+            cnt = engine.AsyncCounts([torch.tensor(5, device=dev), torch.tensor(7, device=dev)])      # any count copy carries the word
+            with pytest.raises(RuntimeError, match="more scored"):
+                cnt.get()
+            assert engine.AsyncCounts([torch.tensor(5, device=dev), torch.tensor(7, device=dev)]).get() == [5, 7]
         ol, orow = hip.compact_scored(labels.to(dev), pos.to(dev), n + 5)                # shortfall padded with -1 / -1
         assert torch.equal(ol.cpu()[:n], want_l) and (ol.cpu()[n:] == -1).all() and (orow.cpu()[n:] == -1).all()
 

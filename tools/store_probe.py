@@ -6,6 +6,8 @@ import sys
 
 import torch
 
+os.environ.setdefault("MVPTR_LIB", "diag")   # the probes are exported by the diagnostic build only (include/mvptr_diag.h)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvp_pytorch_amd import hip  # noqa: E402
 
