@@ -398,7 +398,7 @@ def _enc_flops(lens, cfg):
     return float((nl * (lens * 2 * (4 * H * H + 2 * H * I) + 4 * lens * lens * H)).sum())
 
 
-def _secondary_legs(dev, steps):
+def _secondary_legs(dev, steps, no_graph=False):
     """Driver-visible secondary workloads (never `value`): BASELINE configs[3] — cached two-stage
     retrieval re-ranking at its COCO-5k shape, 1 000 images x 5 captions, README lengths 50 tok + 5 phrases / 30 tags / 50 regions,
     the reference's candidate counts (run_retrieval.py:694-826: top-64 images per caption + top-128 captions per image =
@@ -483,20 +483,16 @@ def _secondary_legs(dev, steps):
         kw = dict(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
                   input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"], img_feats=b["img_feats"])
 
-        def vqa_step():
-            loss = model(labels=labels, **kw)[0]
-            loss.backward()
-            sync()
-            coef = train.clip_coefficient(model, sync, 1.0)      # run_vqa.py max_grad_norm (line 667), fused into the update
-            if coef is not None:
-                opt.step(grad_scale=coef)
-            else:
-                opt.step()
-            sched.step()
-            sync.zero_grad()
-            return loss
+        # host counts as a collate function would compute them (no read-back in the step), the step captured as one HIP graph
+        from mvp_pytorch_amd.synthetic import finetune_host_counts
+        vb = dict(kw, labels=labels, host_counts=finetune_host_counts(b, 20))
+        vstep = train.GraphedStep(model, opt, sched, max_grad_norm=1.0, grad_sync=sync,      # run_vqa.py max_grad_norm (line 667), fused into the update
+                                  forward=lambda m, bb: m(**bb), enabled=not no_graph)
 
-        for _ in range(3):
+        def vqa_step():
+            return vstep(vb)
+
+        for _ in range(3 + vstep.warm_steps + 1):
             vqa_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -517,6 +513,7 @@ def _secondary_legs(dev, steps):
                                     "final_loss": round(float(loss.item()), 4),
                                     "step_frac": round(f_exec / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                     "gflop_per_question_executed": round(f_exec / dims["B"] / 1e9, 1), "gflop_per_question_full_length": round(f_full / 1e9, 1),
+                                    "hip_graph": {"captures": vstep.captures, "replayed_steps": vstep.replays, "capture_error": vstep.last_error},
                                     "workload": "BiImageBertForVQA BERT-base train step (fwd + bwd + fused global-norm clip 1.0 + AdamW), 64 questions/GPU, "
                                                 "128 tok + 5 phrases / 30 tags / 50 regions, 3129-way BCE head, dropout 0.1"}
         sync.close()
@@ -531,7 +528,7 @@ def _single_stream_line(args):
     model stays resident, nothing is re-exec'd)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--model", "single", "--steps", str(args.steps), "--warmup", "2",
-           "--batch", str(args.batch), "--no-extras"]
+           "--batch", str(args.batch), "--no-extras"] + (["--no-graph"] if args.no_graph else [])
     try:
         o = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
         d = json.loads(o.stdout.decode().strip().splitlines()[-1])
@@ -637,6 +634,11 @@ def main():
                     help="A/B: two grouped weight-gradient launches per encoder layer (rounds 1-4) instead of one balanced launch per stack (round 5)")
     ap.add_argument("--count-readbacks", action="store_true",
                     help="A/B: the round-3 step — row counts read back from the device inside the step (no host_counts, joint pass sized exactly)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="A/B: queue every step's ~460 launches from Python (rounds 1-5) instead of replaying the step as one captured HIP "
+                         "graph per batch signature (train.GraphedStep; N = 1 only: multi-rank steps are driven from Python hooks)")
+    ap.add_argument("--gelu-stash", choices=["u8", "bf16"], default=None,
+                    help="A/B: format of the gelu' stash of the FFN (config.gelu_stash; default: the model's)")
     ap.add_argument("--cpu-baseline-child", choices=["bi", "single"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--budget", type=float, default=10.0, help=argparse.SUPPRESS)
@@ -694,6 +696,8 @@ def main():
         cfg = dict(cfg, parallel_stacks=False)
     if args.count_readbacks:
         cfg = dict(cfg, sync_free_joint=False)
+    if args.gelu_stash:
+        cfg = dict(cfg, gelu_stash=args.gelu_stash)
     if args.wgrad_per_layer:
         from mvp_pytorch_amd import engine as _engine
         _engine.DEFER_WGRAD = False
@@ -728,15 +732,26 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # One optimisation step = train.pretrain_step; at N = 1 its device work is captured once per batch signature as a HIP graph and
+    # replayed (train.GraphedStep: same kernels, same arithmetic, one launch instead of ~460; --no-graph queues them from Python)
+    stepper = train.GraphedStep(model, opt, sched, max_tag_length=dims["G"], max_grad_norm=args.max_grad_norm, grad_sync=sync,
+                                enabled=(world == 1 and not args.no_graph))
+
+    def step(b):
+        return stepper(b)
+
     def timed(b, warmup, steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
         loss = None
+        if stepper.enabled:
+            for _ in range(stepper.warm_steps + 1):      # untimed: the eager steps a new batch signature needs + its capture
+                step(b)
         for _ in range(warmup):
-            train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
+            step(b)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss = train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
+            loss = step(b)
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -756,7 +771,7 @@ def main():
     for _ in range(3):
         torch.cuda.synchronize()
         h0 = time.perf_counter()
-        train.pretrain_step(model, batch, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
+        step(batch)
         host_enqueue_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     host_enqueue_ms = sorted(host_enqueue_ms)[1]
@@ -834,12 +849,12 @@ def main():
             for i in range(n):
                 b = stager.get()
                 b = {k: v for k, v in b.items() if k != "img_feats"}      # the model takes the bf16 operand
-                train.pretrain_step(model, b, opt, sched, max_tag_length=dims["G"], grad_sync=sync, max_grad_norm=args.max_grad_norm)
+                step(b)
                 stager.release()
                 if i + 1 < n:
                     stager.put_collated(host)
 
-        piped_steps(2)
+        piped_steps(2 + (stepper.warm_steps + 1 if stepper.enabled else 0))
         fence()
         t0 = time.perf_counter()
         piped_steps(args.steps)
@@ -884,6 +899,8 @@ def main():
                        # wall time the host needs to queue one step's launches behind an empty queue (median of three steps
                        # after the timed region): the step is GPU-bound while this stays below ms_per_step
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 2),
+                       "hip_graph": {"enabled": bool(stepper.enabled), "captures": stepper.captures, "replayed_steps": stepper.replays,
+                                     "eager_steps": stepper.eager_steps, "capture_error": stepper.last_error},
                        "data_parallel": dp_info},
             "roofline": roof,
         }
@@ -891,7 +908,7 @@ def main():
             out["config"]["single_stream_model"] = _single_stream_line(args)
             del model, opt, sync, batch
             torch.cuda.empty_cache()
-            out["config"]["secondary"] = _secondary_legs(dev, args.steps)
+            out["config"]["secondary"] = _secondary_legs(dev, args.steps, args.no_graph)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(single=single)
         print(json.dumps(out), flush=True)

@@ -553,6 +553,12 @@ int mvptr_b64_decode_features(const void* text, const int64_t* offsets, const in
 
 /* Materialise the dropout keep-mask (1/0 bytes) for n elements — test support. */
 int mvptr_dropout_mask(const mvptr_dropout* drop, int64_t n, uint8_t* keep, void* stream);
+/* Dropout salt (ABI 7).  Dropout seeds are launch ARGUMENTS (mvptr_dropout, mvptr_layer_desc.seed): a captured HIP graph replays
+ * them as captured, i.e. every replay would drop the same elements.  `word` (device uint32, owned by the caller, registered for
+ * the CURRENT device; NULL unregisters) is read by every dropout-applying kernel at its start and mixed into its seeds
+ * (seed_lo ^= w * 0x9E3779B9, seed_hi += w * 0x85EBCA6B): a captured training step increments the word once per replay and gets
+ * fresh masks.  A word of 0 — or none — leaves the documented masks untouched (eager steps).  Host call, no stream. */
+int mvptr_set_dropout_salt(const uint32_t* word);
 
 /* One BERT encoder layer, forward and backward, composed from the kernels above.
  * Replaces CaptionBertLayer.forward modeling_vlbert.py:191-199 (attention :63-103,

@@ -148,6 +148,7 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 
 // ------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
 // ----------------------------------------------------------------------------------- backward
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
+  p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 // are short and latency-bound: -15 % on their launches), 2 for Lp = 128 (the register budget of 3 costs spills there).
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
+  p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.x;

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(GemmNtArgs p) {
           } else if constexpr (EPI == MVPTR_EPI_BIAS_RESID) {
             const uint64_t di = (uint64_t)(m0 + erow + mt * 16) * (uint64_t)p.N + (uint64_t)(n0 + ecol + pr * 32);
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) drop_apply2(p.drop, di + (uint64_t)e, v[e], v[e + 1]);
+            for (int e = 0; e < 8; e += 2) drop_apply2(drop_resolve(p.drop), di + (uint64_t)e, v[e], v[e + 1]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a[e];
             store8(rsO, v);

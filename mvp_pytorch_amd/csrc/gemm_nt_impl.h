@@ -123,6 +123,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
   constexpr int abl = 0;
 #endif
 
+  const DropDev drop = (EPI == MVPTR_EPI_BIAS_RESID) ? drop_resolve(p.drop) : p.drop;
   const int ch = lane & 7, rsub = lane >> 3;
   const int n = n0 + wn * 64 + ch * 8;
   const bool nfull = (n + 7 < p.N);
@@ -428,15 +429,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
         // every element index fits 32 bits (all of this model's outputs): 32-bit index arithmetic, two multiplies per hash
         const uint32_t pr = ((uint32_t)m * (uint32_t)p.N + (uint32_t)n) >> 1;
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) drop_apply2_lo(p.drop, pr + (uint32_t)(e >> 1), v[e], v[e + 1]);
+        for (int e = 0; e < 8; e += 2) drop_apply2_lo(drop, pr + (uint32_t)(e >> 1), v[e], v[e + 1]);
       } else if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
 #pragma unroll
         for (int e = 0; e < 8; e += 2)
-          drop_apply2(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
+          drop_apply2(drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          v[e] = drop_apply(p.drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
+          v[e] = drop_apply(drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += a[e];

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const __bf16* z, const floa
                                                       const float* beta, float eps, __bf16* y,
                                                       float* mean, float* rstd, int M_arg, int H,
                                                       int rpg, int gstride, int roff, DropDev drop, const int* rows_dev) {
+  drop = drop_resolve(drop);
   const int M = rows_clamped(M_arg, rows_dev);
   const int lane = threadIdx.x & 63;
   const int nch = H >> 3;
@@ -101,6 +102,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* dy, const __b
                                                        float* partial,
                                                        int M_arg, int H, int rpg, int gstride, int roff,
                                                        DropDev ydrop, DropDev ddrop, const int* rows_dev) {
+  ydrop = drop_resolve(ydrop);
+  ddrop = drop_resolve(ddrop);
   const int M = rows_clamped(M_arg, rows_dev);
   __shared__ float red[3][3][1024];  // waves 1..3 publish, wave 0 sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const fl
                                                         const float* beta, float eps, __bf16* y,
                                                         float* mean, float* rstd, int M_arg, int rpg,
                                                         int gstride, int roff, DropDev drop, const int* rows_dev) {
+  drop = drop_resolve(drop);
   const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -315,6 +319,8 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 4) void ln_bwd_j_kernel(const __bf1
                                                         const float* gamma, __bf16* dz, __bf16* dd,
                                                         float* partial, int M_arg, int rpg, int gstride,
                                                         int roff, DropDev ydrop, DropDev ddrop, const int* rows_dev) {
+  ydrop = drop_resolve(ydrop);
+  ddrop = drop_resolve(ddrop);
   const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
   __shared__ float red[3][3][H];  // waves 1..3 publish, wave 0 sums
@@ -631,6 +637,7 @@ __global__ void cast_f32_kernel(const __bf16* src, int64_t ld_src, int rows, int
 }
 
 __global__ void dropout_mask_kernel(DropDev d, int64_t n, uint8_t* keep) {
+  d = drop_resolve(d);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     keep[i] = (d.thresh16 == 0 || mvptr_rand16((uint64_t)i, d.seed_lo, d.seed_hi) >= d.thresh16) ? 1 : 0;
 }
@@ -711,6 +718,25 @@ void mvptr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mvptr_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// dropout salt (common.h drop_resolve): one registered device word per device
+namespace {
+constexpr int kMaxDev = 64;
+const uint32_t* g_drop_salt[kMaxDev] = {nullptr};
+}  // namespace
+const uint32_t* mvptr_drop_salt() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  return g_drop_salt[dev];
+}
+extern "C" int mvptr_set_dropout_salt(const uint32_t* word) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) MVPTR_FAIL(MVPTR_HIP_ERROR, "set_dropout_salt: no current device");
+  if (((uintptr_t)word & 3) != 0) MVPTR_FAIL(MVPTR_BAD_ALIGN, "set_dropout_salt: the word must be 4-byte aligned");
+  g_drop_salt[dev] = word;
+  return MVPTR_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernel-configuration knobs (see common.h): constants in the product build, environment + mvptr_set_knob in the

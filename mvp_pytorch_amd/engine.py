@@ -573,6 +573,9 @@ class AsyncCounts:
     def __init__(self, values):
         self._n = len(values)
         vals = [v.reshape(()) for v in values]
+        if vals and vals[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a device -> host count read-back cannot be part of a captured HIP graph (train.GraphedStep needs batches "
+                               "that carry host_counts)")
         if vals and vals[0].is_cuda:
             # every count copy carries the device error word along (hip.device_error_word): the host's next look at the device
             # is also its look at the data-dependent checks queued since the last one

@@ -36,7 +36,7 @@ SYMBOLS = [
     "mvptr_wra_rows", "mvptr_wra_fwd", "mvptr_wra_bwd", "mvptr_gemm_tn_multi_ws", "mvptr_gemm_tn_ws_bytes",
     "mvptr_hard_negative_mine", "mvptr_bce_logits", "mvptr_check_counts", "mvptr_tap_rows_bwd",
     "mvptr_masked_mean", "mvptr_dgelu_mul", "mvptr_compact_scored",
-    "mvptr_gemm_tn_stack", "mvptr_encoder_layer_bwd_defer",
+    "mvptr_gemm_tn_stack", "mvptr_encoder_layer_bwd_defer", "mvptr_set_dropout_salt",
 ]
 # include/mvptr_diag.h: exported by the diagnostic build only (MVPTR_LIB=diag)
 DIAG_SYMBOLS = ["mvptr_diag_stream_read", "mvptr_diag_store_probe", "mvptr_diag_fill_probe", "mvptr_set_knob"]
@@ -131,6 +131,8 @@ def load():
     lib.mvptr_ce_fwd.argtypes = [P, I64, P, P, P, I, I, P]
     lib.mvptr_ce_bwd.argtypes = [P, I64, P, P, P, P, I64, I, I, I, P]
     lib.mvptr_dropout_mask.argtypes = [POINTER(Dropout), I64, P, P]
+    if hasattr(lib, "mvptr_set_dropout_salt"):      # (absent from pre-ABI-7 builds loaded for A/B runs through MVPTR_LIB)
+        lib.mvptr_set_dropout_salt.argtypes = [P]
     lib.mvptr_adamw_multi.argtypes = [P, P, P, I, I, F, F, F, P, P]
     lib.mvptr_adamw_mirror_multi.argtypes = [P, P, I, I, F, F, F, P, P]
     lib.mvptr_sumsq_partials.restype = c_int64
@@ -766,6 +768,22 @@ def check_device_errors(device=None):
         if device is not None and torch.device(device).index != key:
             continue
         raise_device_error(int(w[0].item()), w.device)
+
+
+_salt_words = {}
+
+
+def dropout_salt(device):
+    """The dropout salt word of `device` (int32 [1], zero; registered with the library on first use — mvptr_set_dropout_salt).
+    Kernels mix it into their dropout seeds; a graph-captured step adds 1 per replay (train.GraphedStep), eager steps leave it 0."""
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    w = _salt_words.get(key)
+    if w is None:
+        w = _salt_words[key] = torch.zeros(1, dtype=torch.int32, device=d)
+        with torch.cuda.device(key):
+            _check(load().mvptr_set_dropout_salt(_p(w)))
+    return w
 
 
 def compact_scored(labels, pos, n_out):

@@ -453,13 +453,28 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
                 use_b=False, position_ids_a=None, input_ids_b=None, token_type_ids_b=None,
                 attention_mask_b=None, phrase_layer=None, position_ids_b=None, head_mask=None,
                 img_feats=None, encoder_history_states=None, encode_hn=False, hn_mod="hard", logit=None,
-                pack_hints=None, beside=None):
-        """beside: optional callable(txt, vis, sim_mat) with work that only needs the uni-modal outputs (the visual
+                pack_hints=None, beside=None, host_counts=None):
+        """host_counts (optional, encode_hn=False paths; synthetic.finetune_host_counts): rows / longest sequence of the three
+        row-packed passes computed where the batch was built — no read-back inside the step (checked on the device against the
+        masks, mvptr_check_counts: a mismatch traps, every buffer behind it is sized from these numbers).
+        beside: optional callable(txt, vis, sim_mat) with work that only needs the uni-modal outputs (the visual
         MLM head and the contrastive loss of the pre-training model).  It is queued on the side stream before the
         joint stack, so its small kernels — and, in the backward pass, their gradients — run beside the joint
         stack's GEMMs instead of after them; the caller waits for engine.side_stream before using its results."""
         if head_mask is not None or encoder_history_states:
             raise NotImplementedError("head_mask / encoder_history_states are outside the accelerated path")
+        joint_hint = None
+        packing = input_ids_a.is_cuda and (self.txt_encoder.unpad is True or (self.txt_encoder.unpad == "train" and self.training))
+        if host_counts is not None and not encode_hn and pack_hints is None and packing and attention_mask_a is not None and attention_mask_b is not None:
+            hc = {k: int(v) for k, v in host_counts.items()}
+            pack_hints = ((hc["rows_a"], hc["lmax_a"]), (hc["rows_b"], hc["lmax_b"]))
+            joint_hint = (hc["rows_j"], hc["lmax_j"])
+            cut0 = 1 if use_b else max_tag_length
+            la, lb = attention_mask_a.sum(1), attention_mask_b.sum(1)
+            lj = la + attention_mask_b[:, cut0:].sum(1)
+            cnts = torch.stack([la.sum(), la.max(), lb.sum(), lb.max(), lj.sum(), lj.max()]).to(torch.int64)
+            hip.check_counts(cnts[0:2], cnts[2:4], pack_hints[0] + pack_hints[1])
+            hip.check_counts(cnts[4:6], cnts[4:6], joint_hint + joint_hint)
         txt, vis, mask_a, mask_b = self._uni(input_ids_a, token_type_ids_a, attention_mask_a, position_ids_a,
                                              input_ids_b, token_type_ids_b, attention_mask_b, position_ids_b, img_feats,
                                              pack_hints)
@@ -531,7 +546,7 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             if phrase_layer is not None:
                 (sequence_output,), mid_joint = self.mul_encoder(joint, joint_mask, return_at_layer=phrase_layer)
             else:
-                sequence_output = self.mul_encoder(joint, joint_mask)[0]
+                sequence_output = self.mul_encoder(joint, joint_mask, pack_hint=joint_hint)[0]
         pooled_output = self.pooler(sequence_output)
         outputs = (sequence_output, pooled_output, hard_out, hard_pooled)
         if phrase_layer is not None:          # vl:605-608: a fourth element
@@ -649,7 +664,9 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         pos_j, idx_j, st_j, ln_j, cnt_j = hip.pack_maps(
             [dict(mask=mask_a, sel=sel_txt, len=La, pos=pos_a),
              dict(mask=mask_b, sel=sel_img, col0=cut, len=Lb - cut, pos=pos_b, src_base=ra)], 2 * n, fill_idx=sync_free)
-        cj = engine.AsyncCounts([cnt_j[0], cnt_j[1]])
+        # (inside a HIP-graph capture — train.GraphedStep — nothing can be read back: the pass keeps the plan of the eager warm-up steps)
+        capturing = torch.cuda.is_current_stream_capturing()
+        cj = None if capturing else engine.AsyncCounts([cnt_j[0], cnt_j[1]])
         if beside is not None:
             if two_streams:
                 side.wait_stream(main)
@@ -666,14 +683,18 @@ class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             # for the previous step's count, which has long landed.
             # the latest count that has LANDED is the hint (the host may run more than a step ahead of the device: a copy that
             # is still in flight is simply left for a later step — nothing here waits)
-            pend = _JOINT_PENDING.setdefault(self, [])
-            while pend and pend[0].ready():
-                self._joint_plan = pend.pop(0).get()[0]
-            pend.append(cj)
-            del pend[:-8]
+            if not capturing:
+                pend = _JOINT_PENDING.setdefault(self, [])
+                while pend and pend[0].ready():
+                    self._joint_plan = pend.pop(0).get()[0]
+                pend.append(cj)
+                del pend[:-8]
             xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j)[0]
             both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, La + Lb - cut, rows_dev=cnt_j, rows_plan=self._joint_plan)
         else:
+            if capturing:
+                raise RuntimeError("the joint pass sized from a count read-back (config.sync_free_joint = False, or padded widths over 256) "
+                                   "cannot be captured in a HIP graph")
             rj, lj_max = cj.get()
             xj_p = engine.MultiTapFn.apply(txt_p, vis_p, idx_j[:rj])[0]
             both = self.mul_encoder.forward_rows(xj_p, st_j, ln_j, 2 * n, lj_max)
@@ -1478,11 +1499,14 @@ class BiImageBertForVQA(_FreezeMixin, BertPreTrainedModel):
 
     def forward(self, input_ids_a, token_type_ids_a=None, attention_mask_a=None, labels=None, input_ids_b=None,
                 token_type_ids_b=None, attention_mask_b=None, max_tag_length=20, position_ids_a=None,
-                position_ids_b=None, head_mask=None, img_feats=None, soft_label=False):
+                position_ids_b=None, head_mask=None, img_feats=None, soft_label=False, host_counts=None):
+        """host_counts (optional, not a reference argument): synthetic.finetune_host_counts(batch, max_tag_length) — the step then
+        reads nothing back from the device (and can be captured as a HIP graph, train.GraphedStep)."""
         outputs, _, _ = self.bert(input_ids_a=input_ids_a, position_ids_a=position_ids_a, token_type_ids_a=token_type_ids_a,
                                   attention_mask_a=attention_mask_a, head_mask=head_mask, img_feats=img_feats,
                                   input_ids_b=input_ids_b, position_ids_b=position_ids_b, token_type_ids_b=token_type_ids_b,
-                                  attention_mask_b=attention_mask_b, max_tag_length=max_tag_length, encode_hn=False)
+                                  attention_mask_b=attention_mask_b, max_tag_length=max_tag_length, encode_hn=False,
+                                  host_counts=host_counts)
         logits = self.cls(self.dropout(outputs[0][:, 0]))
         out = (logits,) + outputs[2:]
         if labels is not None:

@@ -54,6 +54,9 @@ class AdamW(Optimizer):
         if not 0.0 <= eps:
             raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+        # HIP-graph capture of a training step (train.GraphedStep): while a list, step() only LAUNCHES the update kernels —
+        # no step counters, no descriptor-table upload — and appends what a replay has to refresh on the host (advance())
+        self._graph_plan = None
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
@@ -80,9 +83,13 @@ class AdamW(Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
+                capturing = self._graph_plan is not None
+                if not capturing:
+                    st["step"] += 1
                 step_no = st["step"] if step_no is None else step_no
                 if st["step"] != step_no:  # parameters of a group that joined later: single-tensor path
+                    if capturing:
+                        raise RuntimeError("AdamW: a parameter whose step counter differs from its group's cannot be captured")
                     self._single(p, st, group, grad_scale)
                     m = engine.mirror_of(p)
                     if m is not None and m["cache"]() is not None:
@@ -105,16 +112,18 @@ class AdamW(Optimizer):
                 mirrored = [i for i, m in enumerate(mir) if m is not None]
                 if plain:
                     pick = lambda xs: [xs[i] for i in plain]   # noqa: E731
-                    self._fused(pick(ps), pick(gs), pick(ms), pick(vs), b1, b2, group["eps"], step_size, decay, grad_scale)
+                    self._fused(pick(ps), pick(gs), pick(ms), pick(vs), b1, b2, group["eps"], step_size, decay, grad_scale, group)
                 if mirrored:
                     pick = lambda xs: [xs[i] for i in mirrored]   # noqa: E731
                     self._fused_mirror(pick(ps), pick(gs), pick(ms), pick(vs), pick(mir), b1, b2, group["eps"], step_size, decay,
-                                       grad_scale)
+                                       grad_scale, group)
                     for m in pick(mir):
                         c = m["cache"]()
                         if c is not None:
                             fresh.add(c)
                 continue
+            if self._graph_plan is not None:
+                raise RuntimeError("AdamW: only the fused HIP update (contiguous f32 parameters on the device) can be captured")
             if grad_scale is not None:
                 gs = torch._foreach_mul(gs, grad_scale.reshape(()))
             torch._foreach_mul_(ms, b1)
@@ -130,7 +139,41 @@ class AdamW(Optimizer):
             c.mark_fresh()      # after the version bumps of _fused_mirror: the next forward pass finds the copies current
         return loss
 
-    def _fused_mirror(self, ps, gs, ms, vs, mirrors, b1, b2, eps, step_size, decay, grad_scale):
+    def _upload(self, st, dt, ptrs, fill, step_size, decay):
+        """Descriptor table of one fused launch -> device: two PINNED host copies used in turn (each guarded by the event of the
+        upload that last read it), pointer columns rewritten only when a pointer changed (`fill`), step_size / decay every step;
+        an asynchronous copy on the launch stream."""
+        i = st["turn"]
+        st["turn"] = i ^ 1
+        if st["events"][i] is not None:
+            st["events"][i].synchronize()   # the upload that last read this host buffer (two steps ago) is done
+        host = st["hosts"][i]
+        tab = host.numpy().view(dt)
+        if st["ptrs"][i] != ptrs:
+            fill(tab)
+            st["ptrs"][i] = ptrs
+        tab["step_size"] = step_size
+        tab["decay"] = decay
+        st["dev"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
+
+    def advance(self, plan):
+        """Host side of one REPLAYED step (train.GraphedStep): what step() does besides launching kernels — step counters, bias
+        correction and weight decay of the current learning rate into the descriptor tables the captured kernels read."""
+        for e in plan:
+            group = e["group"]
+            b1, b2 = group["betas"]
+            for p in e["ps"]:
+                self.state[p]["step"] += 1
+            step_no = self.state[e["ps"][0]]["step"]
+            step_size = group["lr"]
+            if group["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** step_no) / (1.0 - b1 ** step_no)
+            self._upload(e["st"], e["dt"], e["ptrs"], e["fill"], step_size, 1.0 - group["lr"] * group["weight_decay"])
+
+    def _fused_mirror(self, ps, gs, ms, vs, mirrors, b1, b2, eps, step_size, decay, grad_scale, group=None):
         """Parameters that have bf16 working copies (engine.register_mirror): update + copies in one pass over
         64 x 64 tiles (mvptr_adamw_mirror_multi)."""
         from . import hip
@@ -140,20 +183,17 @@ class AdamW(Optimizer):
         st = cache.get(key)
         dt = np.dtype(hip.MIRROR_DT)
         if st is None:
+            if self._graph_plan is not None:
+                raise RuntimeError("AdamW: this parameter set has not been stepped eagerly yet (warm-up steps come first)")
             nbytes = len(ps) * dt.itemsize
             st = dict(hosts=[torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)], events=[None, None],
                       ptrs=[None, None], turn=0, dev=torch.empty(nbytes, dtype=torch.uint8, device=dev), base=None, total=0)
             cache[key] = st
-        i = st["turn"]
-        st["turn"] = i ^ 1
-        if st["events"][i] is not None:
-            st["events"][i].synchronize()
-        host = st["hosts"][i]
-        tab = host.numpy().view(dt)
         dptr = lambda t: 0 if t is None else t.data_ptr()   # noqa: E731
         ptrs = (tuple(g.data_ptr() for g in gs), tuple(m.data_ptr() for m in ms), tuple(v.data_ptr() for v in vs),
                 tuple((dptr(m["dst"]), dptr(m["dst_t"]), dptr(m["dst_f32"])) for m in mirrors))
-        if st["ptrs"][i] != ptrs:
+
+        def fill(tab):
             tiles = []
             for j, (p, m) in enumerate(zip(ps, mirrors)):
                 rows, cols = (p.shape[0], p.shape[1]) if p.dim() == 2 else (1, p.numel())
@@ -163,17 +203,17 @@ class AdamW(Optimizer):
                           dptr(dst_t), dst_t.stride(0) if dst_t is not None else 0, m["col_off_t"], 0, dptr(m["dst_f32"]))
                 wcols = max(cols, ld_dst) if dst is not None else cols
                 tiles.append(((rows + 63) // 64) * ((wcols + 63) // 64))
-            st["ptrs"][i] = ptrs
             if st["base"] is None or st.get("tiles") != tiles:
                 base = np.zeros(len(ps) + 1, dtype=np.int32)
                 base[1:] = np.cumsum(tiles)
                 st["base"], st["total"], st["tiles"] = torch.from_numpy(base).to(dev), int(base[-1]), tiles
-        tab["step_size"] = step_size
-        tab["decay"] = decay
-        st["dev"].copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st["events"][i] = ev
+
+        if self._graph_plan is None:
+            self._upload(st, dt, ptrs, fill, step_size, decay)
+        else:
+            if st["base"] is None or ptrs not in st["ptrs"]:
+                raise RuntimeError("AdamW: the descriptor table of this launch changed since the warm-up steps")
+            self._graph_plan.append(dict(st=st, dt=dt, ptrs=ptrs, fill=fill, ps=list(ps), group=group))
         hip.adamw_mirror_multi(st["dev"], st["base"], len(ps), st["total"], b1, b2, eps, grad_scale)
         self._bump(ps)
 
@@ -190,7 +230,7 @@ class AdamW(Optimizer):
     _TABLE_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
                           ("step_size", "<f4"), ("decay", "<f4")])
 
-    def _fused(self, ps, gs, ms, vs, b1, b2, eps, step_size, decay, grad_scale=None):
+    def _fused(self, ps, gs, ms, vs, b1, b2, eps, step_size, decay, grad_scale=None, group=None):
         """One launch for the whole group through the C ABI (mvptr_adamw_multi)."""
         from . import hip
         dev = ps[0].device
@@ -198,6 +238,8 @@ class AdamW(Optimizer):
         cache = self.__dict__.setdefault("_fused_cache", {})
         ent = cache.get(key)
         if ent is None:
+            if self._graph_plan is not None:
+                raise RuntimeError("AdamW: this parameter set has not been stepped eagerly yet (warm-up steps come first)")
             ct, co = [], []
             for i, p in enumerate(ps):
                 for off in range(0, p.numel(), hip.ADAMW_CHUNK):
@@ -205,12 +247,8 @@ class AdamW(Optimizer):
                     co.append(off)
             ent = (torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev), len(ct))
             cache[key] = ent
-        # descriptor table: two PINNED host copies (used in turn, each guarded by the event of the upload
-        # that last read it) and a device copy, kept per parameter group.  The
-        # pointer columns are rewritten only when a pointer changed (gradient tensors are reallocated
-        # by zero_grad(set_to_none) unless a GradSync pins them into its buckets); step_size / decay
-        # change every step.  The upload is an asynchronous copy from pinned memory on the launch
-        # stream (a pageable source would make it a blocking copy).
+        # descriptor table: see _upload (pointer columns are rewritten only when a pointer changed: gradient tensors are
+        # reallocated by zero_grad(set_to_none) unless a GradSync pins them into its buckets)
         if len(ent) == 3:
             nbytes = len(ps) * self._TABLE_DT.itemsize
             hosts = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -218,27 +256,22 @@ class AdamW(Optimizer):
                               dev=torch.empty(nbytes, dtype=torch.uint8, device=dev)),)
             cache[key] = ent
         st = ent[3]
-        i = st["turn"]
-        st["turn"] = i ^ 1
-        if st["events"][i] is not None:
-            st["events"][i].synchronize()   # the upload that last read this host buffer (two steps ago) is done
-        host, tab_dev = st["hosts"][i], st["dev"]
-        tab = host.numpy().view(self._TABLE_DT)
         ptrs = (tuple(g.data_ptr() for g in gs), tuple(m.data_ptr() for m in ms), tuple(v.data_ptr() for v in vs))
-        if st["ptrs"][i] != ptrs:
+
+        def fill(tab):
             tab["p"] = [p.data_ptr() for p in ps]
             tab["g"] = ptrs[0]
             tab["m"] = ptrs[1]
             tab["v"] = ptrs[2]
             tab["n"] = [p.numel() for p in ps]
-            st["ptrs"][i] = ptrs
-        tab["step_size"] = step_size
-        tab["decay"] = decay
-        tab_dev.copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st["events"][i] = ev
-        hip.adamw_multi(tab_dev, ent[0], ent[1], ent[2], b1, b2, eps, grad_scale)
+
+        if self._graph_plan is None:
+            self._upload(st, self._TABLE_DT, ptrs, fill, step_size, decay)
+        else:
+            if ptrs not in st["ptrs"]:
+                raise RuntimeError("AdamW: the descriptor table of this launch changed since the warm-up steps")
+            self._graph_plan.append(dict(st=st, dt=self._TABLE_DT, ptrs=ptrs, fill=fill, ps=list(ps), group=group))
+        hip.adamw_multi(st["dev"], ent[0], ent[1], ent[2], b1, b2, eps, grad_scale)
         self._bump(ps)
 
     @staticmethod

@@ -103,3 +103,13 @@ def host_counts(batch):
     la, lb = ma.sum(1), mb.sum(1)
     return HostCounts(rows_a=int(la.sum()), lmax_a=int(la.max()), rows_b=int(lb.sum()), lmax_b=int(lb.max()),
                       scored_a=int((batch["lm_label_ids_a"] > -1).sum()), scored_b=int((batch["lm_label_ids_b"] > -1).sum()))
+
+
+def finetune_host_counts(batch, max_tag_length=20):
+    """The same for the fine-tune models (BiImageBertForVQA / ...ForSequenceClassification, `host_counts=`): valid rows / longest
+    sequence of the two uni-modal passes and of the JOINT pass — text slots + the visual slots from `max_tag_length` on
+    (modeling_vlbert.py:466-468; no hard negatives are mined on this path, so the joint count is input-only too)."""
+    ma, mb = batch["input_mask_a"], batch["input_mask_b"]
+    la, lb = ma.sum(1), mb.sum(1)
+    lj = la + mb[:, max_tag_length:].sum(1)
+    return dict(rows_a=int(la.sum()), lmax_a=int(la.max()), rows_b=int(lb.sum()), lmax_b=int(lb.max()), rows_j=int(lj.sum()), lmax_j=int(lj.max()))

@@ -707,6 +707,111 @@ def test_pretrain_step_matches_reference_adamw_probes(dev):
     assert all(p.grad is None for p in model.parameters())   # optimizer.zero_grad(set_to_none) ran
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_graphed_step_matches_eager_steps(dev, dropout):
+    """train.GraphedStep — the device work of a pre-training step captured as ONE HIP graph per batch signature
+    and replayed — against train.pretrain_step on the same model, batch and draws.  Two eager warm-up steps, then captured steps
+    under a warm-up schedule (the learning rate changes every step: it must reach the captured AdamW kernels through their
+    descriptor tables, AdamW.advance).  Gradients are accumulated with f32 atomics, so two EAGER runs already differ in the last
+    bits; the captured run must sit at that noise level (losses to 2e-5 relative over 6 steps, total parameter update to 1e-2
+    relative L2 against 2x the eager / eager figure), every optimizer step counter must read 6, and with dropout on the salt word
+    must have advanced once per replay (fresh masks: the seeds themselves are captured launch arguments)."""
+    from mvp_pytorch_amd import dp, hip, train
+    from mvp_pytorch_amd.optimization import AdamW, WarmupLinearSchedule
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout, max_phrases=3)
+    dims = dict(B=16, T=12, P=3, G=6, R=5)
+    batch = synthetic_batch(dims, cfg, 33, device=dev)
+    assert "host_counts" in batch
+    steps = 6
+
+    def run(graphed):
+        torch.manual_seed(0)
+        from mvp_pytorch_amd import engine
+        engine._seed_counter[0] = 0x5DEECE66D
+        from mvp_pytorch_amd import modeling
+        model = modeling.BiBertImgForPreTraining(modeling.make_config(cfg))      # (not _build: it switches dropout and the device-side WRA draws off)
+        sd = {k: torch.from_numpy(v) for k, v in gu.det_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 17, 1.0).items()}
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        opt = AdamW([{"params": list(model.parameters()), "weight_decay": 0.01}], lr=1e-3, eps=1e-8)
+        sched = WarmupLinearSchedule(opt, warmup_steps=10, t_total=100)
+        sync = dp.GradSync(model)
+        stepper = train.GraphedStep(model, opt, sched, max_tag_length=dims["G"], max_grad_norm=1.0, grad_sync=sync, enabled=graphed)
+        losses = []
+        for _ in range(steps):
+            losses.append(float(stepper(batch)))
+        torch.cuda.synchronize()
+        hip.check_device_errors(dev)
+        upd = {n: (p.detach().float().cpu() - sd[n].float()) for n, p in model.named_parameters()}
+        steps_seen = {int(opt.state[p]["step"]) for p in model.parameters() if p in opt.state and len(opt.state[p])}
+        sync.close()
+        return losses, upd, steps_seen, stepper
+
+    salt0 = int(hip.dropout_salt(dev).item())
+    l_a, u_a, s_a, _ = run(False)
+    l_b, u_b, s_b, _ = run(False)
+    l_g, u_g, s_g, st = run(True)
+    assert st.last_error is None, st.last_error
+    assert st.captures == 1 and st.replays == steps - 2 and st.eager_steps == 2, (st.captures, st.replays, st.eager_steps)
+    assert s_a == s_g == {steps}, (s_a, s_g)
+    assert int(hip.dropout_salt(dev).item()) == salt0 + steps - 2
+    hip.dropout_salt(dev).zero_()
+
+    def upd_rel(x, y):
+        num = sum(float((x[n] - y[n]).pow(2).sum()) for n in x)
+        den = sum(float(y[n].pow(2).sum()) for n in x)
+        return (num / den) ** 0.5
+
+    noise = upd_rel(u_b, u_a)
+    got = upd_rel(u_g, u_a)
+    print("dropout", dropout, "losses eager", l_a, "graphed", l_g, "update rel L2: eager/eager %.3e graphed/eager %.3e" % (noise, got))
+    if dropout == 0.0:
+        assert max(abs(a - g) / abs(a) for a, g in zip(l_a, l_g)) < 2e-5 + 4 * max(abs(a - b) / abs(a) for a, b in zip(l_a, l_b))
+        assert got < max(1e-2, 2 * noise), (got, noise)
+    else:
+        # the first two (eager) steps draw the same masks; the replays draw others than the eager run's (salted seeds): same
+        # distribution, finite, and still descending like the eager run
+        assert max(abs(a - g) / abs(a) for a, g in zip(l_a[:2], l_g[:2])) < 2e-5 + 4 * max(abs(a - b) / abs(a) for a, b in zip(l_a[:2], l_b[:2]))
+        assert all(np.isfinite(l_g)) and abs(l_g[-1] - l_a[-1]) / abs(l_a[-1]) < 0.1
+
+
+def test_finetune_host_counts_and_captured_vqa_step(dev):
+    """The fine-tune path without read-backs: BiImageBertForVQA(host_counts=synthetic.finetune_host_counts(...)) gives the loss and
+    gradients of the step that reads its row counts back (same kernels on the same rows: bit-identical loss), and that step —
+    forward, backward, fused clip, AdamW — runs as a captured HIP graph (train.GraphedStep with a custom forward)."""
+    from mvp_pytorch_amd import dp, train
+    from mvp_pytorch_amd.optimization import AdamW, ConstantLRSchedule
+    from mvp_pytorch_amd.synthetic import finetune_host_counts, synthetic_batch
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, loss_type="bce", num_labels=37)
+    dims = dict(B=10, T=18, P=3, G=20, R=8)
+    b = {k: v.to(dev) for k, v in synthetic_batch(dims, cfg, 41).items() if isinstance(v, torch.Tensor)}
+    kw = dict(input_ids_a=b["input_ids_a"], token_type_ids_a=b["segment_ids_a"], attention_mask_a=b["input_mask_a"],
+              input_ids_b=b["input_ids_b"], token_type_ids_b=b["segment_ids_b"], attention_mask_b=b["input_mask_b"], img_feats=b["img_feats"])
+    labels = torch.rand(dims["B"], 37, generator=torch.Generator().manual_seed(1)).to(dev)
+    hc = finetune_host_counts(b, 20)
+    got = {}
+    for use_hc in (False, True):
+        model, _ = _build("BiImageBertForVQA", cfg, 23, dev, train=True)
+        o = model(labels=labels, host_counts=hc if use_hc else None, **kw)
+        o[0].backward()
+        torch.cuda.synchronize()
+        got[use_hc] = (o[0].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert torch.equal(got[True][0], got[False][0])
+    worst = max((_rel(got[True][1][n], got[False][1][n]), n) for n in got[False][1] if got[False][1][n].norm() > 1e-6)
+    assert worst[0] < 1e-5, worst
+    model, _ = _build("BiImageBertForVQA", cfg, 23, dev, train=True)
+    opt = AdamW([{"params": list(model.parameters()), "weight_decay": 0.01}], lr=1e-3, eps=1e-8)
+    sync = dp.GradSync(model)
+    step = train.GraphedStep(model, opt, ConstantLRSchedule(opt), max_grad_norm=1.0, grad_sync=sync, forward=lambda m, bb: m(**bb))
+    vb = dict(kw, labels=labels, host_counts=hc)
+    losses = [float(step(vb)) for _ in range(5)]
+    torch.cuda.synchronize()
+    assert step.last_error is None and step.captures == 1 and step.replays == 3, (step.last_error, step.captures, step.replays)
+    assert abs(losses[0] - float(got[True][0])) < 1e-6 * abs(losses[0]) and losses[-1] < losses[0]
+    sync.close()
+
+
 def test_branches_parity(dev):
     """qa_ans + phrase_mod='hard' (vl:1264-1283), hn_mod='sample' (vl:535-540), use_b, classifier='mlp',
     soft-label / MSE / BCE / KL losses (vl:1777-1797) against tiny_branches.npz (reference outputs)."""

@@ -53,6 +53,9 @@ def main():
                   ("ffn1 fwd GELU bf16 stash", x, rnd(I, H), hip.EPI_BIAS_GELU_BF16, None),
                   ("ffn2 fwd RESID", xi, rnd(H, I), hip.EPI_BIAS_RESID, x),
                   ("ffn2 dgrad GELU_BWD", x, rnd(I, H), hip.EPI_GELU_BWD, torch.randint(0, 256, (M, I), device=dev, dtype=torch.uint8)),
+                  ("ffn2 dgrad GELU_BWD bf16", x, rnd(I, H), hip.EPI_GELU_BWD_BF16, rnd(M, I)),
+                  ("ffn2 dgrad GELU_BWD no vec", x, rnd(I, H), hip.EPI_GELU_BWD, torch.randint(0, 256, (M, I), device=dev, dtype=torch.uint8)),
+                  ("ffn2 dgrad GELU_BWD16 no vec", x, rnd(I, H), hip.EPI_GELU_BWD_BF16, rnd(M, I)),
                   ("ffn1 dgrad ADD", xi, rnd(H, I), hip.EPI_ADD, x),
                   ("qkv dgrad ADD", x3, rnd(H, 3 * H), hip.EPI_ADD, x)]
         print("M = %d, cold us" % M)
@@ -66,7 +69,7 @@ def main():
             if epi == hip.EPI_BIAS_GELU_BF16:
                 out0 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             out1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if two else None
-            vec = torch.zeros(N, device=dev) if epi == hip.EPI_GELU_BWD else None
+            vec = torch.zeros(N, device=dev) if (epi in (hip.EPI_GELU_BWD, hip.EPI_GELU_BWD_BF16) and "no vec" not in name) else None
             row = "%-26s" % name
             for vname, bits in variants:
                 exp = 1024 if bits < 0 else (bits << 26)
