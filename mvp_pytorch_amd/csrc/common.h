@@ -187,32 +187,64 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 //   gelu = x Phi,   gelu' = Phi + y e c2,  e = exp2(-t) = exp(-x^2 / 2) (ONE transcendental per element), c2 = 1 / (sqrt(2 pi) c)
 // 18 packed instructions + 2 v_med3 + 2 v_exp per pair = 48 issue cycles per element (A&S: 54); measured on the FFN1 GEMM of the
 // joint stack (M = 37 748, cold): 245 -> 242 us — the epilogue is NOT bound by its arithmetic (profiles/r06_experiments.txt).
-__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& act, f32x2& dact) {
+// NP pairs at once, every step written across the pairs: the Horner recurrence is twelve DEPENDENT packed FMAs per pair, and hipcc
+// emitted one pair's chain after the other with an s_nop between the links (a packed result cannot feed the next instruction) —
+// latency-bound, no faster than the A&S form it replaced.  Interleaved, the NP chains fill each other's gaps (same operations on
+// every element: bit-identical to the pair form).
+template <int NP>
+__device__ __forceinline__ void gelu_pairs(const f32x2 (&x)[NP], f32x2 (&act)[NP], f32x2 (&dact)[NP]) {
   constexpr float kC = 8.493217826e-01f, kCy = 4.161676884e+00f, kC2 = 4.697186351e-01f, kS = 1.154764146e-01f;
-  const f32x2 s = x * kC;
-  f32x2 y, e;
-  y.x = __builtin_amdgcn_fmed3f(s.x, -kCy, kCy);
-  y.y = __builtin_amdgcn_fmed3f(s.y, -kCy, kCy);
-  const f32x2 t = y * y;
-  e.x = __builtin_amdgcn_exp2f(-t.x);
-  e.y = __builtin_amdgcn_exp2f(-t.y);
-  const f32x2 u = t * kS + -1.0f;
-  f32x2 q = u * -9.827667382e-04f + 3.157508560e-03f;
-  q = q * u + -4.038130865e-03f;
-  q = q * u + 5.177745130e-03f;
-  q = q * u + -1.078274101e-02f;
-  q = q * u + 1.885492913e-02f;
-  q = q * u + -2.694023401e-02f;
-  q = q * u + 3.640379757e-02f;
-  q = q * u + -4.770958051e-02f;
-  q = q * u + 6.151610240e-02f;
-  q = q * u + -8.433147520e-02f;
-  q = q * u + 1.698188037e-01f;
-  f32x2 cdf;
+  constexpr float kQ[12] = {1.698188037e-01f, -8.433147520e-02f, 6.151610240e-02f, -4.770958051e-02f, 3.640379757e-02f, -2.694023401e-02f,
+                            1.885492913e-02f, -1.078274101e-02f, 5.177745130e-03f, -4.038130865e-03f, 3.157508560e-03f, -9.827667382e-04f};
+  f32x2 y[NP], e[NP], u[NP], q[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const f32x2 s = x[j] * kC;
+    y[j].x = __builtin_amdgcn_fmed3f(s.x, -kCy, kCy);
+    y[j].y = __builtin_amdgcn_fmed3f(s.y, -kCy, kCy);
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const f32x2 t = y[j] * y[j];
+    e[j].x = __builtin_amdgcn_exp2f(-t.x);
+    e[j].y = __builtin_amdgcn_exp2f(-t.y);
+    u[j] = t * kS + -1.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) q[j] = u[j] * kQ[11] + kQ[10];
+#pragma unroll
+  for (int i = 9; i >= 0; --i)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) q[j] = q[j] * u[j] + kQ[i];
   const f32x2 half = {0.5f, 0.5f};
-  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(cdf) : "v"(y), "v"(q), "v"(half));
-  act = x * cdf;
-  dact = (y * e) * kC2 + cdf;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    f32x2 cdf;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(cdf) : "v"(y[j]), "v"(q[j]), "v"(half));
+    act[j] = x[j] * cdf;
+    dact[j] = (y[j] * e[j]) * kC2 + cdf;
+  }
+}
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& act, f32x2& dact) {
+  const f32x2 xs[1] = {x};
+  f32x2 a[1], d[1];
+  gelu_pairs<1>(xs, a, d);
+  act = a[0];
+  dact = d[0];
+}
+// the eight values an epilogue lane finishes per row: gelu(v) -> g, gelu'(v) -> dg
+__device__ __forceinline__ void gelu8(const float (&v)[8], float (&g)[8], float (&dg)[8]) {
+  f32x2 x[4], a[4], d[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
+  gelu_pairs<4>(x, a, d);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    g[2 * j] = a[j].x;
+    g[2 * j + 1] = a[j].y;
+    dg[2 * j] = d[j].x;
+    dg[2 * j + 1] = d[j].y;
+  }
 }
 
 #ifdef MVPTR_DIAG_BUILD

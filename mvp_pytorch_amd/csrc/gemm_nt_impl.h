@@ -334,14 +334,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
     if (EPI == MVPTR_EPI_BIAS || EPI == EPI_FOLD_BIAS) {
       store_bf8(p.out0, m, v);
     } else if (EPI == EPI_FOLD_GELU) {
-      float g[8];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        f32x2 a2, d2;
-        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-        g[e] = a2.x;
-        g[e + 1] = a2.y;
-      }
+      float g[8], dg[8];
+      gelu8(v, g, dg);
       store_bf8(p.out0, m, g);
     } else if (EPI == EPI_RESID_LN) {
       if (p.ln_stats != nullptr) {      // the residual rows are pre-LayerNorm rows: normalise them here
@@ -369,20 +363,21 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       if (ch == 0) *reinterpret_cast<f32x2*>(p.part + ((int64_t)m * p.part_ld + ((n0 >> 6) + wn)) * 2) = f32x2{s1, s2};
     } else if (EPI == MVPTR_EPI_BIAS_GELU) {
       float g[8], dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        f32x2 a2, d2;
 #ifdef MVPTR_DIAG_BUILD
-        if (abl & 8) a2 = d2 = f32x2{v[e], v[e + 1]};
-        else if (abl & 16) gelu_pair_as(f32x2{v[e], v[e + 1]}, a2, d2);
-        else
+      if (abl & 24) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 a2, d2;
+          if (abl & 8) a2 = d2 = f32x2{v[e], v[e + 1]};
+          else gelu_pair_as(f32x2{v[e], v[e + 1]}, a2, d2);
+          g[e] = a2.x;
+          g[e + 1] = a2.y;
+          dg[e] = d2.x;
+          dg[e + 1] = d2.y;
+        }
+      } else
 #endif
-        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-        g[e] = a2.x;
-        g[e + 1] = a2.y;
-        dg[e] = d2.x;
-        dg[e + 1] = d2.y;
-      }
+      gelu8(v, g, dg);
       // gelu'(u) is only read in the backward pass: non-temporal stores keep it from displacing gelu(u) — the next
       // GEMM's operand — in the Infinity Cache (same-box A/B: all-slots step 41.71 -> 41.46 ms, packed 28.68 -> 28.60)
       // out0 = the 8-bit gelu' stash (common.h), one byte per element, row stride ldc bytes
@@ -413,15 +408,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_GELU_BF16) {
       float g[8], dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        f32x2 a2, d2;
-        gelu_pair(f32x2{v[e], v[e + 1]}, a2, d2);
-        g[e] = a2.x;
-        g[e + 1] = a2.y;
-        dg[e] = d2.x;
-        dg[e + 1] = d2.y;
-      }
+      gelu8(v, g, dg);
       store_bf8(p.out0, m, dg);      // the bf16 stash of rounds 1-3
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {

@@ -108,7 +108,7 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
     else:
         optimizer.zero_grad(set_to_none=True)
     if return_losses:
-        return [o.detach() for o in outputs]
+        return [o.detach() if isinstance(o, torch.Tensor) else o for o in outputs]
     return loss.detach()
 
 
@@ -223,7 +223,7 @@ class GraphedStep:
         else:
             self.optimizer.step()
         self.grad_sync.zero_grad()
-        return loss.detach(), [o.detach() for o in outputs]
+        return loss.detach(), [o.detach() if isinstance(o, torch.Tensor) else o for o in outputs]
 
     def _capture(self, sig, batch):
         from . import hip
@@ -271,5 +271,5 @@ class GraphedStep:
         self.scheduler.step()
         self.replays += 1
         if return_losses:
-            return [o.clone() for o in ent["outputs"]]
+            return [o.clone() if isinstance(o, torch.Tensor) else o for o in ent["outputs"]]
         return ent["loss"].clone()

@@ -44,7 +44,9 @@ def main():
     H, I = 768, 3072
     flush = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
     variants = [("full", 0), ("loop only", -1), ("A&S gelu (r1-5)", 16), ("no gelu math", 8), ("no stores", 2), ("no aux loads", 1),
-                ("no colsum", 4), ("no aux, no colsum", 5), ("no stores, no aux", 3), ("no st/aux/colsum/math", 15)]
+                ("no colsum", 4), ("no aux, no colsum", 5), ("no stores, no aux", 3), ("no st/aux/colsum/math", 15),
+                # cache policy of the 8-bit stash stores (MVPTR_NT_EXP bit 9 / bits 19-21; product: non-temporal)
+                ("stash plain", -512), ("stash sc1", -(1 << 19)), ("stash sc0sc1", -(2 << 19)), ("stash nt buf", -(3 << 19))]
     for M in [int(v) for v in args.ms.split(",")]:
         x, xi, x3 = rnd(M, H), rnd(M, I), rnd(M, 3 * H)
         shapes = [("qkv fwd BIAS", x, rnd(3 * H, H), hip.EPI_BIAS, None),
@@ -72,7 +74,7 @@ def main():
             vec = torch.zeros(N, device=dev) if (epi in (hip.EPI_GELU_BWD, hip.EPI_GELU_BWD_BF16) and "no vec" not in name) else None
             row = "%-26s" % name
             for vname, bits in variants:
-                exp = 1024 if bits < 0 else (bits << 26)
+                exp = 1024 if bits == -1 else (-bits if bits < 0 else (bits << 26))
                 hip.set_knob("MVPTR_NT_EXP", str(exp))
                 us = cold_us(lambda: hip.gemm_nt(a, b, epi, bias=bias, aux=aux, out=out0, out1=out1, vec_out=vec), flush)
                 row += "%22.1f" % us
