@@ -152,6 +152,39 @@ __device__ __forceinline__ void drop_apply2(const DropDev& d, uint64_t idx_even,
   v1 = ((h >> 16) >= d.thresh16) ? v1 * d.scale : 0.f;
 }
 
+// Dropout of NP element pairs at once, every hash step written across the pairs.  drop_apply2 / drop_apply2_lo hash ONE pair behind a
+// wave-uniform `thresh16 == 0` test: every pair became its own basic block, and its chain — two quarter-rate integer multiplies
+// and six dependent shifts / adds — ran at its latency (the dropout of a residual epilogue cost as much as the erf-GELU:
+// 17 us of a 77-us attention-output GEMM).  Here the caller tests `thresh16` once and the NP chains fill each other's gaps.
+// pair[j] = index of the even element of pair j, >> 1; LO: every pair index is below 2^32 (the usual case: M * N < 2^33) — the
+// same masks as mvptr_pair_hash / mvptr_pair_hash_lo, bit for bit.
+template <int NP, bool LO>
+__device__ __forceinline__ void drop_pairs(const DropDev& d, const uint64_t (&pair)[NP], float (&v)[2 * NP]) {
+  uint32_t x[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    x[j] = (uint32_t)pair[j] ^ d.seed_lo;
+    if (!LO) x[j] += (uint32_t)(pair[j] >> 32) * 0x9E3779B9u;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 16;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] *= 0x7feb352du;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 15;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] += d.seed_hi;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] *= 0x846ca68bu;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 16;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    v[2 * j] = ((x[j] & 0xffffu) >= d.thresh16) ? v[2 * j] * d.scale : 0.f;
+    v[2 * j + 1] = ((x[j] >> 16) >= d.thresh16) ? v[2 * j + 1] * d.scale : 0.f;
+  }
+}
+
 // erf-GELU (modeling_bert.py:142-148) through erfc(z) = poly(t) * exp(-z^2), t = 1/(1 + p z)
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7): one v_exp_f32 + one v_rcp_f32 instead of the
 // libm erff call; the same exp(-x^2/2) also gives the normal pdf for the derivative.

@@ -412,19 +412,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& p, int Mv, f32x4 (
       store_bf8(p.out0, m, dg);      // the bf16 stash of rounds 1-3
       store_bf8(p.out1, m, g);
     } else if (EPI == MVPTR_EPI_BIAS_RESID) {
-      if ((p.N & 1) == 0 && (uint64_t)p.M * (uint64_t)p.N < ((uint64_t)1 << 32)) {
-        // every element index fits 32 bits (all of this model's outputs): 32-bit index arithmetic, two multiplies per hash
-        const uint32_t pr = ((uint32_t)m * (uint32_t)p.N + (uint32_t)n) >> 1;
+      if (drop.thresh16 != 0) {
+        if ((p.N & 1) == 0) {   // (m * N + n) even: lanes own whole hash pairs; the four pairs of the row piece hashed in lockstep
+          uint64_t pr[4];
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) drop_apply2_lo(drop, pr + (uint32_t)(e >> 1), v[e], v[e + 1]);
-      } else if ((p.N & 1) == 0) {  // (m*N + n) even: lanes own whole hash pairs
+          for (int e = 0; e < 4; ++e) pr[e] = (((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 1) + (uint64_t)e;
+          // every element index fits 32 bits (all of this model's outputs): 32-bit index arithmetic, two multiplies per hash
+          if ((uint64_t)p.M * (uint64_t)p.N < ((uint64_t)1 << 32)) drop_pairs<4, true>(drop, pr, v);
+          else drop_pairs<4, false>(drop, pr, v);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; e += 2)
-          drop_apply2(drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e], v[e + 1]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = drop_apply(drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
+          for (int e = 0; e < 8; ++e)
+            v[e] = drop_apply(drop, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), v[e]);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += a[e];

@@ -242,6 +242,21 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(LnFinal f0, LnFina
 // 4l + 256j of each of the J column groups (8-byte accesses, every lane busy, 512 contiguous
 // bytes per wave instruction) and a wave keeps RPW rows in flight, so the loads of the next row
 // are outstanding while the statistics of the previous one are reduced.
+// dropout of the 4 J elements a lane owns of row r in the H = 256 J kernels (columns 256 j + 4 lane ...: two hash pairs per j), all
+// 2 J pair hashes in lockstep (common.h drop_pairs); the caller has tested thresh16
+template <int J>
+__device__ __forceinline__ void row_dropout(const DropDev& d, int r, int lane, bool lo32, float (&t)[4 * J]) {
+  uint64_t pr[2 * J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const uint64_t idx = (uint64_t)r * (uint64_t)(256 * J) + (uint64_t)(256 * j + 4 * lane);
+    pr[2 * j] = idx >> 1;
+    pr[2 * j + 1] = (idx >> 1) + 1;
+  }
+  if (lo32) drop_pairs<2 * J, true>(d, pr, t);
+  else drop_pairs<2 * J, false>(d, pr, t);
+}
+
 template <int J, int RPW>
 __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const float* gamma,
                                                         const float* beta, float eps, __bf16* y,
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const fl
   drop = drop_resolve(drop);
   const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
+  const bool lo32 = (uint64_t)M_arg * (uint64_t)H < ((uint64_t)1 << 32);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gm[J], bt[J];
 #pragma unroll
@@ -296,15 +312,15 @@ __global__ __launch_bounds__(256) void ln_fwd_j_kernel(const __bf16* z, const fl
         if (rstd) rstd[r] = rs;
       }
       const int64_t orow = remap_row(r, rpg, gstride, roff);
+      float t[4 * J];
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[4 * j + e] = (gamma != nullptr) ? v[j][e] * rs * gm[j][e] + bt[j][e] : v[j][e] + mu;
+      if (drop.thresh16 != 0) row_dropout<J>(drop, r, lane, lo32, t);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        float t[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = (gamma != nullptr) ? v[j][e] * rs * gm[j][e] + bt[j][e] : v[j][e] + mu;
-        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
-        drop_apply2(drop, idx, t[0], t[1]);
-        drop_apply2(drop, idx + 2, t[2], t[3]);
-        const bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+        const bf16x4 o = {f2bf(t[4 * j]), f2bf(t[4 * j + 1]), f2bf(t[4 * j + 2]), f2bf(t[4 * j + 3])};
         *reinterpret_cast<bf16x4*>(y + orow * H + 256 * j + 4 * lane) = o;
       }
     }
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 4) void ln_bwd_j_kernel(const __bf1
   ddrop = drop_resolve(ddrop);
   const int M = rows_clamped(M_arg, rows_dev);
   constexpr int H = 256 * J;
+  const bool lo32 = (uint64_t)M_arg * (uint64_t)H < ((uint64_t)1 << 32);
   __shared__ float red[3][3][H];  // waves 1..3 publish, wave 0 sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool ident = (gamma == nullptr);
@@ -359,40 +376,42 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 4) void ln_bwd_j_kernel(const __bf1
       if (r >= M) break;
       float xh[J][4], g[J][4];
       float s1 = 0.f, s2 = 0.f;
+      float dall[4 * J];
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dall[4 * j + e] = bf2f(R.a[i][j][e]);
+      if (ydrop.thresh16 != 0) row_dropout<J>(ydrop, r, lane, lo32, dall);
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        float d[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = bf2f(R.a[i][j][e]);
-        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
-        drop_apply2(ydrop, idx, d[0], d[1]);
-        drop_apply2(ydrop, idx + 2, d[2], d[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          const float de = dall[4 * j + e];
           xh[j][e] = (bf2f(R.x[i][j][e]) - R.mu[i]) * R.rs[i];
-          g[j][e] = d[e] * gm[j][e];
+          g[j][e] = de * gm[j][e];
           s1 += g[j][e];
           s2 += g[j][e] * xh[j][e];
-          ag[j][e] += d[e] * xh[j][e];
-          ab[j][e] += d[e];
+          ag[j][e] += de * xh[j][e];
+          ab[j][e] += de;
         }
       }
       const float c1 = ident ? 0.f : wave_sum(s1) * (1.0f / (float)H);
       const float c2 = ident ? 0.f : wave_sum(s2) * (1.0f / (float)H);
+      float t[4 * J];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        float t[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = R.rs[i] * (g[j][e] - c1 - xh[j][e] * c2);
-        const bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+        for (int e = 0; e < 4; ++e) t[4 * j + e] = R.rs[i] * (g[j][e] - c1 - xh[j][e] * c2);
+        const bf16x4 o = {f2bf(t[4 * j]), f2bf(t[4 * j + 1]), f2bf(t[4 * j + 2]), f2bf(t[4 * j + 3])};
         *reinterpret_cast<bf16x4*>(dz + (int64_t)r * H + 256 * j + 4 * lane) = o;
-        const uint64_t idx = (uint64_t)r * (uint64_t)H + (uint64_t)(256 * j + 4 * lane);
-        drop_apply2(ddrop, idx, t[0], t[1]);
-        drop_apply2(ddrop, idx + 2, t[2], t[3]);
+      }
+      if (ddrop.thresh16 != 0) row_dropout<J>(ddrop, r, lane, lo32, t);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) abias[j][e] += t[e];
+      for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) abias[j][e] += t[4 * j + e];
         if (dd != nullptr) {
-          const bf16x4 od = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+          const bf16x4 od = {f2bf(t[4 * j]), f2bf(t[4 * j + 1]), f2bf(t[4 * j + 2]), f2bf(t[4 * j + 3])};
           *reinterpret_cast<bf16x4*>(dd + (int64_t)r * H + 256 * j + 4 * lane) = od;
         }
       }
