@@ -147,6 +147,86 @@ __device__ __forceinline__ void store_block32(const char* blk, __bf16* dst, int6
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
 // ------------------------------------------------------------------------------------ forward
+// Dropout of the 16 probabilities a lane holds of a 32 x 32 block (registers r, r + 1 = adjacent keys: 8 hash pairs at
+// rowbase + (r & 3) + 8 (r >> 2)), all eight pair hashes in lockstep (common.h pair_hashes: rounds 1-5 hashed one pair after the
+// other, three integer multiplies each — the 64-bit form, although every pair index of this model is below 2^32 — and spent more
+// issue slots on the masks than on the exponentials).  lo32: wave-uniform, B heads L Lp < 2^33.
+template <bool LO32, int G = 4>
+__device__ __forceinline__ void drop_block16(const DropDev& d, uint64_t rowbase, f32x16& v) {
+  // groups of G pairs (G = 4: eight chains in flight cost registers the kernels do not have)
+#pragma unroll
+  for (int g = 0; g < 8 / G; ++g) {
+    uint32_t h[G];
+    if constexpr (LO32) {
+      uint32_t pr[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int r = 2 * (G * g + j);
+        pr[j] = ((uint32_t)rowbase + (uint32_t)((r & 3) + 8 * (r >> 2))) >> 1;
+      }
+      pair_hashes_lo<G>(pr, d.seed_lo, d.seed_hi, h);
+    } else {
+      uint64_t pr[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int r = 2 * (G * g + j);
+        pr[j] = (rowbase + (uint64_t)((r & 3) + 8 * (r >> 2))) >> 1;
+      }
+      pair_hashes<G, false>(pr, d.seed_lo, d.seed_hi, h);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int r = 2 * (G * g + j);
+      v[r] = ((h[j] & 0xffffu) >= d.thresh16) ? v[r] * d.scale : 0.f;
+      v[r + 1] = ((h[j] >> 16) >= d.thresh16) ? v[r + 1] * d.scale : 0.f;
+    }
+  }
+}
+// Keep bits of the 16 (query register) x (this lane's key) probabilities of a block in the key-on-lane passes: the pair (key & ~1,
+// key | 1) of query q shares one hash; this lane hashes the queries whose register parity equals its key parity and swaps with
+// lane ^ 1 (DPP) — eight hashes per lane and block, G at a time in lockstep (the three-workgroups-per-CU kernel has 168 registers:
+// one at a time there, as rounds 3-5 did — with four in flight its spills cost more than the chains saved: 169 -> 198 us)
+template <bool LO32, int G = 4>
+__device__ __forceinline__ uint32_t keep_bits16(const DropDev& d, int bh, int LT, int LpT, int qb, int hh, int key) {
+  const int par = key & 1;
+  uint32_t keepbits = 0;
+#pragma unroll
+  for (int g = 0; g < 8 / G; ++g) {
+    uint32_t h[G];
+    if constexpr (LO32) {
+      uint32_t pr[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int rm = 2 * (G * g + j) + par;      // the query register this lane hashes
+        const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
+        pr[j] = (((uint32_t)bh * (uint32_t)LT + (uint32_t)qm) * (uint32_t)LpT + (uint32_t)(key & ~1)) >> 1;
+      }
+      pair_hashes_lo<G>(pr, d.seed_lo, d.seed_hi, h);
+    } else {
+      uint64_t pr[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int rm = 2 * (G * g + j) + par;
+        const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
+        pr[j] = (((uint64_t)bh * LT + qm) * (uint64_t)LpT + (uint64_t)(key & ~1)) >> 1;
+      }
+      pair_hashes<G, false>(pr, d.seed_lo, d.seed_hi, h);
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int rm = 2 * (G * g + j) + par;
+      const uint32_t hm = h[j];
+      const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+      const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
+      const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
+      keepbits |= (um >= d.thresh16 ? 1u : 0u) << rm;
+      keepbits |= (uo >= d.thresh16 ? 1u : 0u) << (rm ^ 1);
+    }
+  }
+  return keepbits;
+}
+
+template <bool LO32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -155,6 +235,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const int b = bh / p.heads, hd = bh - b * p.heads;
   // LT / LpT: table strides (lse, dropout index, LDS tile placement); L / Lp: this sequence
   const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  constexpr bool lo32 = LO32;      // every dropout element index fits 32 bits (chosen by the launch: B heads L Lp < 2^32)
   const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
   if (L <= 0) return;
   const int64_t row0 = (p.seq_start != nullptr) ? (int64_t)p.seq_start[b] : (int64_t)b * LT;
@@ -223,16 +304,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       load_rows16(maskv, kb, hh, mk);
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = __expf(st[r] * 0.125f + mk[r] - lse);
-      if (p.drop.thresh16 != 0) {
-        const uint64_t rowbase = ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {  // registers r, r+1 hold adjacent keys (even, odd)
-          float a0 = st[r], a1 = st[r + 1];
-          drop_apply2(p.drop, rowbase + (r & 3) + 8 * (r >> 2), a0, a1);
-          st[r] = a0;
-          st[r + 1] = a1;
-        }
-      }
+      if (p.drop.thresh16 != 0) drop_block16<lo32>(p.drop, ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh, st);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pb = pack8(st, s);
@@ -248,6 +320,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ----------------------------------------------------------------------------------- backward
+template <bool LO32>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -255,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
   const int bh = blockIdx.x;
   const int b = bh / p.heads, hd = bh - b * p.heads;
   const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  constexpr bool lo32 = LO32;      // every dropout element index fits 32 bits (chosen by the launch: B heads L Lp < 2^32)
   const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
   if (L <= 0) return;
 #ifdef MVPTR_TIMELINE_BUILD
@@ -329,20 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       // hashes the queries whose register parity equals its key parity and swaps with lane ^ 1
       uint32_t keepbits = 0xffffu;
       if (p.drop.thresh16 != 0) {
-        keepbits = 0;
-        const int par = key & 1;
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 2) {
-          const int rm = r0 + par;  // the query register this lane hashes
-          const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
-          const uint64_t idx = ((uint64_t)bh * LT + qm) * (uint64_t)LpT + (key & ~1);
-          const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
-          const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-          const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
-          const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
-          keepbits |= (um >= p.drop.thresh16 ? 1u : 0u) << rm;
-          keepbits |= (uo >= p.drop.thresh16 ? 1u : 0u) << (rm ^ 1);
-        }
+        keepbits = keep_bits16<lo32>(p.drop, bh, LT, LpT, qb, hh, key);
       }
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
@@ -403,16 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
       }
       float mk16[16];
       load_rows16(maskv, kb, hh, mk16);
-      if (p.drop.thresh16 != 0) {
-        const uint64_t rowbase = ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          float a0 = dp[r], a1 = dp[r + 1];
-          drop_apply2(p.drop, rowbase + (r & 3) + 8 * (r >> 2), a0, a1);
-          dp[r] = a0;
-          dp[r + 1] = a1;
-        }
-      }
+      if (p.drop.thresh16 != 0) drop_block16<lo32>(p.drop, ((uint64_t)bh * LT + q) * (uint64_t)LpT + 32 * kb + 4 * hh, dp);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = __expf(s[r] * 0.125f + mk16[r] - ls);
@@ -469,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 // Needs all of a sequence's blocks resident at once: Lp <= 128 (four waves, one key block each).
 // OCC workgroups per CU: 3 where the LDS footprint allows it (Lp <= 96: the text and visual stacks, whose workgroups
 // are short and latency-bound: -15 % on their launches), 2 for Lp = 128 (the register budget of 3 costs spills there).
-template <int OCC>
+template <int OCC, bool LO32>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -477,6 +529,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   const int bh = blockIdx.x;
   const int b = bh / p.heads, hd = bh - b * p.heads;
   const int LT = p.L, LpT = p.Lp, H = p.heads * 64;
+  constexpr bool lo32 = LO32;      // every dropout element index fits 32 bits (chosen by the launch: B heads L Lp < 2^32)
   const int L = (p.seq_len != nullptr) ? p.seq_len[b] : LT;
   if (L <= 0) return;
 #ifdef MVPTR_TIMELINE_BUILD
@@ -550,19 +603,25 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
         // dropout keep bits: see attn_bwd_kernel pass A
         uint32_t keepbits = 0xffffu;
         if (p.drop.thresh16 != 0) {
-          keepbits = 0;
-          const int par = key & 1;
+          if constexpr (OCC >= 3) {
+            // three workgroups per CU leave 168 registers: the hashes one after the other, as rounds 3-5 had them (with the chains
+            // in lockstep — or merely in one basic block — hipcc overlaps them and spills 26 registers: 169 -> 198 us at L = 96)
+            keepbits = 0;
+            const int par = key & 1;
 #pragma unroll
-          for (int r0 = 0; r0 < 16; r0 += 2) {
-            const int rm = r0 + par;
-            const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
-            const uint64_t idx = ((uint64_t)bh * LT + qm) * (uint64_t)LpT + (key & ~1);
-            const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
-            const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-            const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
-            const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
-            keepbits |= (um >= p.drop.thresh16 ? 1u : 0u) << rm;
-            keepbits |= (uo >= p.drop.thresh16 ? 1u : 0u) << (rm ^ 1);
+            for (int r0 = 0; r0 < 16; r0 += 2) {
+              const int rm = r0 + par;
+              const int qm = 32 * qb + (rm & 3) + 8 * (rm >> 2) + 4 * hh;
+              const uint64_t idx = ((uint64_t)bh * LT + qm) * (uint64_t)LpT + (key & ~1);
+              const uint32_t hm = mvptr_pair_hash(idx >> 1, p.drop.seed_lo, p.drop.seed_hi);
+              const uint32_t ho = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+              const uint32_t um = par ? (hm >> 16) : (hm & 0xffffu);
+              const uint32_t uo = par ? (ho >> 16) : (ho & 0xffffu);
+              keepbits |= (um >= p.drop.thresh16 ? 1u : 0u) << rm;
+              keepbits |= (uo >= p.drop.thresh16 ? 1u : 0u) << (rm ^ 1);
+            }
+          } else {
+            keepbits = keep_bits16<lo32>(p.drop, bh, LT, LpT, qb, hh, key);
           }
         }
 #pragma unroll
@@ -707,9 +766,12 @@ extern "C" int mvptr_attention_fwd_packed(const void* qkv, const float* mask_add
   a.seq_len = seq_len;
   a.drop = make_dropdev(drop);
   const size_t lds = (size_t)a.Lp * 128 * 3 + (size_t)a.Lp * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool lo32 = (uint64_t)B * (uint64_t)heads * (uint64_t)a.L * (uint64_t)a.Lp < ((uint64_t)1 << 32);   // dropout element indices in 32 bits
+  hipError_t e = hipFuncSetAttribute(lo32 ? (const void*)attn_fwd_kernel<true> : (const void*)attn_fwd_kernel<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_fwd: set LDS size: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  if (lo32) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
   MVPTR_CHECK_LAUNCH("attention_fwd");
   return MVPTR_OK;
 }
@@ -754,16 +816,18 @@ extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add
   // sequences of <= 128 rows (every stack of the pre-training step): the one-pass kernel; longer ones: two passes
   const bool fused = a.Lp <= 128 && !two_pass_forced();
   const bool occ3 = fused && a.Lp <= 96;
-  const void* fn = !fused ? (const void*)attn_bwd_kernel
-                          : (occ3 ? (const void*)attn_bwd_fused_kernel<3> : (const void*)attn_bwd_fused_kernel<2>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_bwd: set LDS size: %s", hipGetErrorString(e));
-  if (!fused)
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
-  else if (occ3)
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<3>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+  const bool lo32 = (uint64_t)B * (uint64_t)heads * (uint64_t)a.L * (uint64_t)a.Lp < ((uint64_t)1 << 32);   // dropout element indices in 32 bits
+  auto launch = [&](auto kernel) -> int {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) MVPTR_FAIL(MVPTR_HIP_ERROR, "attention_bwd: set LDS size: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, a);
+    return MVPTR_OK;
+  };
+  int lrc;
+  if (!fused) lrc = lo32 ? launch(attn_bwd_kernel<true>) : launch(attn_bwd_kernel<false>);
+  else if (occ3) lrc = lo32 ? launch(attn_bwd_fused_kernel<3, true>) : launch(attn_bwd_fused_kernel<3, false>);
+  else lrc = lo32 ? launch(attn_bwd_fused_kernel<2, true>) : launch(attn_bwd_fused_kernel<2, false>);
+  if (lrc != MVPTR_OK) return lrc;
   MVPTR_CHECK_LAUNCH("attention_bwd");
   return MVPTR_OK;
 }

@@ -159,11 +159,10 @@ __device__ __forceinline__ void drop_apply2(const DropDev& d, uint64_t idx_even,
 // pair[j] = index of the even element of pair j, >> 1; LO: every pair index is below 2^32 (the usual case: M * N < 2^33) — the
 // same masks as mvptr_pair_hash / mvptr_pair_hash_lo, bit for bit.
 template <int NP, bool LO>
-__device__ __forceinline__ void drop_pairs(const DropDev& d, const uint64_t (&pair)[NP], float (&v)[2 * NP]) {
-  uint32_t x[NP];
+__device__ __forceinline__ void pair_hashes(const uint64_t (&pair)[NP], uint32_t seed_lo, uint32_t seed_hi, uint32_t (&x)[NP]) {
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    x[j] = (uint32_t)pair[j] ^ d.seed_lo;
+    x[j] = (uint32_t)pair[j] ^ seed_lo;
     if (!LO) x[j] += (uint32_t)(pair[j] >> 32) * 0x9E3779B9u;
   }
 #pragma unroll
@@ -173,11 +172,34 @@ __device__ __forceinline__ void drop_pairs(const DropDev& d, const uint64_t (&pa
 #pragma unroll
   for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 15;
 #pragma unroll
-  for (int j = 0; j < NP; ++j) x[j] += d.seed_hi;
+  for (int j = 0; j < NP; ++j) x[j] += seed_hi;
 #pragma unroll
   for (int j = 0; j < NP; ++j) x[j] *= 0x846ca68bu;
 #pragma unroll
   for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 16;
+}
+// the same for pair indices held in 32 bits (no 64-bit index arithmetic in the caller either)
+template <int NP>
+__device__ __forceinline__ void pair_hashes_lo(const uint32_t (&pair)[NP], uint32_t seed_lo, uint32_t seed_hi, uint32_t (&x)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] = pair[j] ^ seed_lo;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 16;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] *= 0x7feb352du;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 15;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] += seed_hi;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] *= 0x846ca68bu;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[j] ^= x[j] >> 16;
+}
+template <int NP, bool LO>
+__device__ __forceinline__ void drop_pairs(const DropDev& d, const uint64_t (&pair)[NP], float (&v)[2 * NP]) {
+  uint32_t x[NP];
+  pair_hashes<NP, LO>(pair, d.seed_lo, d.seed_hi, x);
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     v[2 * j] = ((x[j] & 0xffffu) >= d.thresh16) ? v[2 * j] * d.scale : 0.f;
