@@ -295,7 +295,9 @@ class BertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
         self.apply(self.init_weights)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None,
-                head_mask=None, img_feats=None, encoder_history_states=None):
+                head_mask=None, img_feats=None, encoder_history_states=None, pack_hint=None):
+        """pack_hint (optional, not a reference argument): (valid rows, longest sequence) of the batch from where it was built —
+        the row-packed stack then reads nothing back (checked on the device, mvptr_check_counts)."""
         if head_mask is not None or encoder_history_states:
             raise NotImplementedError("head_mask / encoder_history_states are outside the accelerated path")
         if attention_mask is None:
@@ -305,7 +307,13 @@ class BertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             token_type_ids = torch.zeros_like(input_ids)
         mask = additive_mask(attention_mask)
         x = embed_inputs(self.embeddings, input_ids, token_type_ids, position_ids, img_feats, self)
-        sequence_output = self.encoder(x, mask)[0]
+        if pack_hint is not None and x.is_cuda and (self.encoder.unpad is True or (self.encoder.unpad == "train" and self.training)):
+            ln = attention_mask.sum(1)
+            cnt = torch.stack([ln.sum(), ln.max()]).to(torch.int64)
+            hip.check_counts(cnt, cnt, tuple(int(v) for v in pack_hint) * 2)
+        else:
+            pack_hint = None
+        sequence_output = self.encoder(x, mask, pack_hint=pack_hint)[0]
         return (sequence_output, self.pooler(sequence_output))
 
 
@@ -1008,9 +1016,13 @@ class BertImgForPreTraining(ImgPreTrainedModel):
         self._tie_or_clone_weights(self.cls.predictions.decoder, self.bert.embeddings.word_embeddings)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, masked_lm_labels=None,
-                next_sentence_label=None, position_ids=None, head_mask=None, img_feats=None):
+                next_sentence_label=None, position_ids=None, head_mask=None, img_feats=None, host_counts=None):
+        """host_counts (optional, not a reference argument): dict(rows, lmax, scored) computed where the batch was built
+        (synthetic.synthetic_batch(single_stream=True)) — the loss-only training step then reads nothing back from the device."""
+        hint = (int(host_counts["rows"]), int(host_counts["lmax"])) if host_counts is not None else None
         sequence_output, pooled_output = self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
-                                                   attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats)
+                                                   attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
+                                                   pack_hint=hint)
         T = self.max_text_seq_length
         text = sequence_output[:, :T, :] if T is not None else sequence_output
         seq_relationship_score = self.cls.seq_relationship(pooled_output)
@@ -1021,7 +1033,13 @@ class BertImgForPreTraining(ImgPreTrainedModel):
             # training loops that read outputs[0] only (run_oscarplus_pretrain-style): the head runs on
             # the scored rows alone and the logits never reach HBM; prediction_scores comes back empty
             flat = labels.reshape(-1)
-            idx = torch.nonzero(flat >= 0).squeeze(1)
+            if host_counts is not None and flat.is_cuda:
+                # the scored-row count came with the batch: no read-back; a wrong count shows in the device error word
+                n_sc = int(host_counts["scored"])
+                hip.flag_device_error_if((flat >= 0).sum() != n_sc, hip.DEV_ERR_SCORED_ROWS)
+                idx = torch.nonzero_static(flat >= 0, size=n_sc, fill_value=0).squeeze(1)
+            else:
+                idx = torch.nonzero(flat >= 0).squeeze(1)
             rows = text.reshape(-1, text.shape[-1]).index_select(0, idx)
             masked_lm_loss, scores = self.cls.predictions.loss_and_scores(rows, flat.index_select(0, idx), want_scores=False)
             prediction_scores = scores

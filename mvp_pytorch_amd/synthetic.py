@@ -79,6 +79,9 @@ def synthetic_batch(dims, cfg, seed, single_stream=False, fixed_length=False, de
                      phrase_index=phrase_index, image_index=image_index)
     if not single_stream:
         batch["host_counts"] = host_counts(batch)     # input-only row counts, taken while the batch is still on the host
+    else:
+        ln = batch["input_mask"].sum(1)
+        batch["host_counts"] = HostCounts(rows=int(ln.sum()), lmax=int(ln.max()), scored=int((batch["lm_label_ids"][:, :T] > -1).sum()))
     if device is not None:
         batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     return batch

@@ -38,8 +38,11 @@ def model_inputs(batch, max_tag_length):
         fb = batch["img_feats_bf16"]
         feats = fb.view(batch["input_ids_b" if "input_ids_b" in batch else "input_ids"].shape[0], -1, fb.shape[-1])
     if "input_ids" in batch:
-        return dict(input_ids=batch["input_ids"], token_type_ids=batch["segment_ids"], attention_mask=batch["input_mask"],
-                    masked_lm_labels=batch["lm_label_ids"], next_sentence_label=batch["is_next"], img_feats=feats)
+        kw = dict(input_ids=batch["input_ids"], token_type_ids=batch["segment_ids"], attention_mask=batch["input_mask"],
+                  masked_lm_labels=batch["lm_label_ids"], next_sentence_label=batch["is_next"], img_feats=feats)
+        if hc is not None:
+            kw["host_counts"] = hc      # rows / lmax / scored of the single-stream batch: no read-back inside the step
+        return kw
     return dict(input_ids_a=batch["input_ids_a"], token_type_ids_a=batch["segment_ids_a"],
                 attention_mask_a=batch["input_mask_a"], masked_lm_labels_a=batch["lm_label_ids_a"],
                 input_ids_b=batch["input_ids_b"], img_feats=feats,
