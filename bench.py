@@ -740,7 +740,7 @@ def main():
     def step(b):
         return stepper(b)
 
-    def timed(b, warmup, steps):
+    def timed(b, warmup, steps, step=step):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
         loss = None
         if stepper.enabled:
@@ -811,14 +811,31 @@ def main():
                 try:
                     sync.close()
                     sync = dp.GradSync(model, **kw)
+                    stepper.grad_sync = sync
                     leg_ms, _ = timed(batch, 3, args.steps)
                     dp_info[key] = {"ms_per_step": round(leg_ms, 2), "value": round(world * args.batch / (leg_ms * 1e-3), 1), "steps": args.steps,
                                     "options": what, "stalled_steps": sync.stalled_steps}
                 except Exception as e:      # a leg that fails on its first multi-GPU run must not cost the headline its line
                     dp_info[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            # ZeRO-1 over the buckets: reduce-scatter, AdamW on the rank's shard of a flat parameter arena (moments for
+            # 1 / world of the parameters), all-gather of the updated parameters; its own optimizer (the moments restart: timing only)
+            try:
+                sync.close()
+                sync = dp.GradSync(model, comm_dtype=wire, shard_optimizer=True)
+                opt_s, sched_s = train.build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, t_total=100000, grad_sync=sync)
+                stepper_s = train.GraphedStep(model, opt_s, sched_s, max_tag_length=dims["G"], max_grad_norm=args.max_grad_norm, grad_sync=sync, enabled=False)
+                leg_ms, _ = timed(batch, 3, args.steps, step=lambda b: stepper_s(b))
+                dp_info["dp_sharded_optimizer"] = {"ms_per_step": round(leg_ms, 2), "value": round(world * args.batch / (leg_ms * 1e-3), 1), "steps": args.steps,
+                                                   "optimizer_state_elements_per_rank": opt_s.moment_elements(),
+                                                   "options": "ZeRO-1: reduce-scatter of the gradients, AdamW on 1 / world of every bucket, all-gather of the "
+                                                              "updated f32 parameters; dense exchange of the word table"}
+                del opt_s, sched_s, stepper_s
+            except Exception as e:
+                dp_info["dp_sharded_optimizer"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             try:
                 sync.close()
                 sync = dp.GradSync(model, sparse_rows=sparse, comm_dtype=wire, collective=coll)
+                stepper.grad_sync = sync
             except Exception as e:
                 dp_info["restore_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 

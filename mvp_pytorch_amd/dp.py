@@ -122,13 +122,20 @@ class GradSync:
     _logged_exchange = False
 
     def __init__(self, model, bucket_mb=64, process_group=None, overlap=True, comm_dtype="default", sparse_rows="default",
-                 force_collectives=False, demote_after=8, check_mixed_use=False, collective="all_reduce"):
+                 force_collectives=False, demote_after=8, check_mixed_use=False, collective="all_reduce", shard_optimizer=False):
         self.check_mixed_use = check_mixed_use
+        # ZeRO-1 over the buckets (round 6): every rank keeps the reduce-scattered 1 / world of each bucket's gradient, runs the clip
+        # partial sums and AdamW on that shard only (optimization.ShardedAdamW: moments for 1 / world of the parameters) and the
+        # UPDATED PARAMETERS are all-gathered instead of the reduced gradients.  Needs a static layout (every parameter "hot" from the
+        # first step, no re-layout) and a flat parameter arena congruent with the gradient arena (p.data becomes a view into it).
+        self.shard_optimizer = bool(shard_optimizer)
         dflt = default_exchange(model)
         if isinstance(comm_dtype, str) and comm_dtype == "default":
             comm_dtype = dflt["comm_dtype"]
         if isinstance(sparse_rows, str) and sparse_rows == "default":
-            sparse_rows = dflt["sparse_rows"]
+            sparse_rows = [] if self.shard_optimizer else dflt["sparse_rows"]
+        if self.shard_optimizer and sparse_rows:
+            raise ValueError("GradSync(shard_optimizer=True) exchanges every parameter densely (sparse_rows must be empty)")
         if collective not in ("all_reduce", "rs_ag"):
             raise ValueError("GradSync: collective must be 'all_reduce' or 'rs_ag'")
         self.collective = collective
@@ -157,6 +164,7 @@ class GradSync:
         self._ctl = _control_group(process_group) if self.exchange else None      # host-side exchange of the used-parameter bitmap
         self.comm_dtype = torch.float32 if comm_dtype in (None, "auto") else comm_dtype
         self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
+        self._parena = None       # shard_optimizer: flat f32 parameters laid out like the gradient arena
         self._idle = {}           # hot parameter -> consecutive steps without a gradient on any rank
         self.demote_after = demote_after
         self.stalled_steps = 0    # steps whose hook launches stopped short of the hot buckets
@@ -174,7 +182,17 @@ class GradSync:
                 if u and all((p in self.index) and (p not in claimed) and (p not in self.sparse) for p in u):
                     self._model_units.append(u)
                     claimed.update(u)
+        if self.shard_optimizer:
+            if any(p.dtype != torch.float32 for p in self.params):
+                raise ValueError("GradSync(shard_optimizer=True) needs f32 parameters")
+            self.exchange = True                       # the shard logic runs at every world size (a world of 1 owns everything)
+            if self._ctl is None and dist.is_initialized() and not (self.world > 1 or force_collectives):
+                self._ctl = _control_group(process_group)      # (a one-rank group without force_collectives skipped it above)
+            self._hot = set(self.params)               # layout of step 0; fixed for good at the end of that step's backward (below)
+            self._layout_final = False
         self._build()
+        if self.shard_optimizer:
+            self._flatten_parameters()
         self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         engine.set_grad_sink(self)
         self._restore_reserve = None
@@ -247,9 +265,11 @@ class GradSync:
         # one allocation for all buckets, each starting on a multiple of NORM_CHUNK elements (64 KiB): zero_grad() is one
         # fill, and the chunks of the gradient-norm pass never straddle two buckets (per-bucket partial sums, clip_coef)
         total = 0
+        quantum = NORM_CHUNK * (self.world if self.shard_optimizer else 1)    # a rank's shard of a bucket = whole norm chunks
         for b in self.buckets:
             b["base"] = total
-            total += (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK * NORM_CHUNK
+            b["padded"] = (b["n"] + quantum - 1) // quantum * quantum
+            total += b["padded"]
         dev = self.params[0].device if self.params else torch.device("cpu")
         self._arena = torch.zeros(total, device=dev, dtype=torch.float32)
         for idx, b in enumerate(self.buckets):
@@ -261,6 +281,63 @@ class GradSync:
     def _close(self, items, n, is_hot):
         self.buckets.append(dict(flat=None, n=n, items=items, hot=is_hot, pending=0, work=None, wire=None, streams=set(),
                                  rows_of=None, union=None))
+
+    # ------------------------------------------------------------------ sharded optimizer (ZeRO-1)
+    def _flatten_parameters(self):
+        """p.data of every parameter becomes a view into a flat arena laid out exactly like the gradient arena: the rank's
+        shard of a bucket is then one contiguous range of parameters, gradients and moments, and the updated parameters are
+        all-gathered in place."""
+        self._parena = torch.zeros_like(self._arena)
+        with torch.no_grad():
+            for b in self.buckets:
+                for p, off, n in b["items"]:
+                    view = self._parena[b["base"] + off:b["base"] + off + n].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+        self.rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def _relayout(self, hot):
+        """the one re-layout of the sharded mode (end of step 0's backward): new buckets for the hot set `hot`, this step's
+        gradients and the parameters carried over"""
+        saved = {}
+        for b in self.buckets:
+            for p, off, n in b["items"]:
+                saved[p] = b["flat"][off:off + n].clone()
+        streams = set()
+        for b in self.buckets:
+            streams |= b["streams"]
+        self._hot = set(hot)
+        self._build()
+        self._flatten_parameters()
+        for b in self.buckets:
+            b["work"] = b["wire"] = b["union"] = None
+            b["streams"] = set(streams)
+            for p, off, n in b["items"]:
+                b["flat"][off:off + n].copy_(saved[p])
+                view = b["flat"][off:off + n].view_as(p)
+                if p.grad is not None:
+                    p.grad = view
+            b["pending"] = 0
+        self._next = 0
+        self._norm_buf = None
+
+    def shard_range(self, b):
+        """[lo, hi) of this rank's shard inside bucket b's padded span"""
+        s = b["padded"] // self.world
+        return self.rank * s, (self.rank + 1) * s
+
+    def gather_parameters(self):
+        """All-gather the updated shards of the parameter arena, bucket by bucket, in place."""
+        for b in self.buckets:
+            span = self._parena[b["base"]:b["base"] + b["padded"]]
+            lo, hi = self.shard_range(b)
+            if not dist.is_initialized():
+                continue
+            if self._avg:      # RCCL
+                dist.all_gather_into_tensor(span, span[lo:hi], group=self.group)
+            else:
+                s = hi - lo
+                dist.all_gather([span[k * s:(k + 1) * s] for k in range(self.world)], span[lo:hi].clone(), group=self.group)
 
     def flats(self):
         """The flat f32 gradient buffers (global-norm clipping reads these instead of ~400 tensors): the whole arena
@@ -288,6 +365,20 @@ class GradSync:
             sc[first_chunk:first_chunk + n_chunks] = (x.view(n_chunks, NORM_CHUNK) ** 2).sum(1)
 
     def _sumsq_bucket(self, b):
+        if self.shard_optimizer:
+            # partial sums of THIS rank's reduced shard into the shard's own slots; the other ranks' slots stay zero until the
+            # slot vector is summed over the ranks (clip_coef): the same chunk sums in the same slots as the replicated pass
+            g = b["gshard"]
+            lo, _ = self.shard_range(b)
+            first, n_chunks = (b["base"] + lo) // NORM_CHUNK, g.numel() // NORM_CHUNK
+            sc = self._norm_scratch()
+            if g.is_cuda:
+                from . import hip
+                hip._check(hip.load().mvptr_sumsq_partial(hip._p(g), g.numel(), hip.c_void_p(sc.data_ptr() + 4 * first), hip._stream()))
+            else:
+                sc[first:first + n_chunks] = (g.view(n_chunks, NORM_CHUNK) ** 2).sum(1)
+            self._norm_done.add(id(b))
+            return
         self._sumsq_span(b["base"] // NORM_CHUNK, (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK)
         self._norm_done.add(id(b))
 
@@ -299,7 +390,14 @@ class GradSync:
         slots, added in slot order: the result does not depend on which path produced a slot."""
         sc = self._norm_scratch()
         n = self._arena.numel() // NORM_CHUNK
-        if len(self._norm_done) < len(self.buckets):
+        if self.shard_optimizer:
+            for b in self.buckets:
+                if id(b) not in self._norm_done:
+                    self._sumsq_bucket(b)
+            if self.world > 1 and not self._norm_summed:
+                dist.all_reduce(sc[:n], op=dist.ReduceOp.SUM, group=self.group)      # every slot is non-zero on exactly one rank: exact
+            self._norm_summed = True
+        elif len(self._norm_done) < len(self.buckets):
             if not self._norm_done:
                 self._sumsq_span(0, n)
             else:
@@ -342,6 +440,9 @@ class GradSync:
         self._rows = {}
         self._next = 0            # buckets [0, _next) have been launched this step
         self._norm_done = set()   # buckets whose partial sums of squares are in their slots (finish(want_norm=True))
+        self._norm_summed = False
+        if self.shard_optimizer and getattr(self, "_norm_buf", None) is not None:
+            self._norm_buf.zero_()  # the other ranks' slots must read zero before the slot vector is summed
 
     def note_rows(self, param, ids):
         """Tell the exchange which rows of a row-sparse parameter this rank's step looks up (every id
@@ -477,7 +578,7 @@ class GradSync:
             return                # the same parameter used twice in one graph fires once; be tolerant
         self._ready.add(p)
         b["pending"] -= 1
-        if self.overlap and b["hot"]:
+        if self.overlap and b["hot"] and (not self.shard_optimizer or self._layout_final):
             while self._next < self.n_hot and self.buckets[self._next]["pending"] == 0:
                 self._launch(self._next)
 
@@ -498,6 +599,22 @@ class GradSync:
             if union is not None:
                 b["union"] = union
                 src = b["flat"].view_as(b["rows_of"]).index_select(0, union)
+        if self.shard_optimizer:
+            # reduce-scatter only: this rank keeps 1 / world of the bucket's (chunk-padded) span; no gradient all-gather follows —
+            # the optimizer runs on the shard and the updated parameters are gathered instead (optimization.ShardedAdamW)
+            span = self._arena[b["base"]:b["base"] + b["padded"]]
+            wire = span if self.comm_dtype == torch.float32 else span.to(self.comm_dtype)
+            b["wire"] = wire
+            if not dist.is_initialized():          # no process group: the rank owns the whole span
+                b["shard"], b["work"] = wire, None
+            elif self._avg:                         # RCCL (also a one-rank group: the real collectives run)
+                b["shard"] = torch.empty(wire.numel() // self.world, device=wire.device, dtype=wire.dtype)
+                b["work"] = dist.reduce_scatter_tensor(b["shard"], wire, op=op, group=self.group, async_op=True)
+            else:                     # gloo has no reduce_scatter_tensor: all-reduce, keep the own slice (tests on CPU)
+                b["shard"] = None
+                b["work"] = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+            self._next = idx + 1
+            return
         if self.collective == "rs_ag" and src is b["flat"]:
             # reduce-scatter + all-gather over the bucket's chunk-padded span (the padding is zero and stays zero): every
             # rank owns 1 / world of it between the two collectives
@@ -527,6 +644,19 @@ class GradSync:
                 if p not in self._touched:
                     p.grad = None
             return
+        used = None
+        if self.shard_optimizer and not self._layout_final:
+            # Step 0 of the sharded mode: nothing has gone out yet (the hooks hold back while the layout may still move).  The
+            # parameters that produced a gradient on SOME rank become the hot buckets, the never-used ones (qa_head without
+            # answers, ...) go behind them — the one re-layout of this mode: gradients and parameters move inside the rank, no
+            # optimizer state exists yet.  From here on the layout — and with it every shard — is fixed.
+            used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32)
+            if dist.is_initialized():
+                dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self._ctl)
+            self._layout_final = True
+            hot = {p for p, u in zip(self.params, used.tolist()) if u}
+            if hot != self._hot:
+                self._relayout(hot)
         if self._hot is not None and self._next < self.n_hot:
             self.stalled_steps += 1       # some hot bucket never became ready from the hooks: no overlap behind it
         for idx in range(self._next, len(self.buckets)):
@@ -536,8 +666,30 @@ class GradSync:
         # apply identical updates even when a shard skipped a head
         # (host to host over the control group: the device and its queue of collectives are not involved, nothing here waits
         # for the backward pass)
-        used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32)
-        dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self._ctl)
+        if used is None:
+            used = torch.tensor([1 if p in self._touched else 0 for p in self.params], dtype=torch.int32)
+            if dist.is_initialized():      # (_ctl None = the default group, itself gloo)
+                dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self._ctl)
+        if self.shard_optimizer:
+            for b in self.buckets:
+                if b["work"] is not None:
+                    b["work"].wait()
+                lo, hi = self.shard_range(b)
+                sh = b["shard"] if b["shard"] is not None else b["wire"][lo:hi]
+                if sh.is_cuda and sh is not b["wire"]:
+                    sh.record_stream(torch.cuda.current_stream(sh.device))
+                g = sh if sh.dtype == torch.float32 else sh.to(torch.float32)     # (an f32 slice of the arena itself is fine: it is read before zero_grad())
+                if self.world > 1 and not self._avg:
+                    g.mul_(1.0 / self.world)
+                b["gshard"] = g           # the rank's reduced, averaged gradient shard (f32) until zero_grad()
+                b["wire"] = b["shard"] = None
+                if want_norm:
+                    self._sumsq_bucket(b)
+            used = used.tolist()
+            for p, u in zip(self.params, used):
+                if not u:
+                    p.grad = None
+            return
         for b in self.buckets:
             b["work"].wait()
             if b["union"] is not None:

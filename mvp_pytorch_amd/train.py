@@ -8,13 +8,18 @@ import torch
 from .optimization import AdamW, WarmupLinearSchedule
 
 
-def build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, warmup_steps=0, t_total=100000):
-    """run_pretrain_ml.py:379-393 — no decay on biases and LayerNorm weights."""
+def build_optimizer(model, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.01, warmup_steps=0, t_total=100000, grad_sync=None):
+    """run_pretrain_ml.py:379-393 — no decay on biases and LayerNorm weights.  grad_sync: a dp.GradSync(shard_optimizer=True)
+    selects the ZeRO-1 optimizer over its buckets (optimization.ShardedAdamW)."""
     no_decay = ["bias", "LayerNorm.weight"]
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
               {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
-    opt = AdamW(groups, lr=lr, eps=adam_epsilon)
+    if grad_sync is not None and getattr(grad_sync, "shard_optimizer", False):
+        from .optimization import ShardedAdamW
+        opt = ShardedAdamW(groups, grad_sync, lr=lr, eps=adam_epsilon)
+    else:
+        opt = AdamW(groups, lr=lr, eps=adam_epsilon)
     sched = WarmupLinearSchedule(opt, warmup_steps=warmup_steps, t_total=t_total)
     return opt, sched
 

@@ -150,6 +150,11 @@ def _one_rank_worker(mode, port, q):
     elif mode == "rccl_opts":
         sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.bfloat16,
                            sparse_rows=[model.bert.embeddings.word_embeddings.weight])
+    elif mode == "rccl_sharded":    # ZeRO-1: reduce-scatter, AdamW on the rank's shard of the flat parameter arena, all-gather of the parameters
+        sync = dp.GradSync(model, bucket_mb=0.25, force_collectives=True, comm_dtype=torch.float32, shard_optimizer=True)
+        opt, sched = train.build_optimizer(model, lr=1e-3, t_total=10, grad_sync=sync)
+        from mvp_pytorch_amd.optimization import ShardedAdamW
+        assert isinstance(opt, ShardedAdamW) and opt.moment_elements() == 2 * sync._arena.numel()
     dims = dict(B=4, T=12, P=3, G=6, R=5)
     names = ("bert.txt_encoder.layer.0.attention.self.query.weight", "bert.mul_encoder.layer.1.output.dense.bias",
              "bert.embeddings.word_embeddings.weight", "cls.predictions.decoder.weight", "bert.pooler.dense.weight",
@@ -212,7 +217,7 @@ def test_rccl_world1_and_gradient_arena_match_plain_step(dev):
     parameter updates as a step without any GradSync; the gradient arena alone (no process group) likewise."""
     import numpy as np
     ref = _one_rank("plain")
-    for mode in ("arena", "rccl", "rccl_rsag", "rccl_opts"):
+    for mode in ("arena", "rccl", "rccl_rsag", "rccl_opts", "rccl_sharded"):
         got = _one_rank(mode)
         print("one-rank", mode, got[1], got[4])
         assert np.allclose(got[1], ref[1], rtol=2e-4), (mode, got[1], ref[1])
