@@ -112,6 +112,10 @@ def test_bench_launcher_two_ranks_on_one_gpu(dev):
     assert dpi["dp_conservative"]["ms_per_step"] > 0 and dpi["dp_conservative"]["steps"] == 2 and dpi["dp_conservative"]["stalled_steps"] == 0
     assert "dp_rs_ag" not in dpi or "error" in dpi["dp_rs_ag"] or dpi["dp_rs_ag"]["ms_per_step"] > 0     # RCCL only
     assert isinstance(dpi["exposed_comm_ms"], float) and dpi["ms_per_step_without_exchange"] > 0
+    # the ZeRO-1 leg (round 6): two ranks, each with the Adam moments of half of the chunk-padded arena
+    zs = dpi["dp_sharded_optimizer"]
+    assert "error" not in zs, zs
+    assert zs["ms_per_step"] > 0 and zs["steps"] == 2 and zs["optimizer_state_elements_per_rank"] > 0
     assert line["config"]["max_grad_norm"] == 10.0
 
 
