@@ -332,11 +332,11 @@ def _time_launches(launches, reps, cold):
 
 
 def _pmc_traffic(kernel, packed=True):
-    """HBM bytes per launch from the committed PMC passes (profiles/r02_dominant_traffic.json, made
-    by tools/runs/r02_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
+    """HBM bytes per launch from the committed PMC passes (profiles/r06_dominant_traffic.json, made
+    by tools/runs/r06_profile.sh: tools/prof_dominant.py under rocprofv3 --pmc FETCH_SIZE / --pmc
     WRITE_SIZE, FETCH_SIZE calibrated on a known 1-GiB stream by tools/calib_fetch.py), or None."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = os.path.join(here, "r05_dominant_traffic.json")      # made from this round's kernels only (older files describe other kernels)
+    path = os.path.join(here, "r06_dominant_traffic.json")      # made from this round's kernels only (older files describe other kernels)
     try:
         with open(path) as f:
             return json.load(f)["row_packed_batch" if packed else "all_slots_valid"][kernel]
@@ -380,7 +380,7 @@ def kernel_roofline(dev, dims, cfg, batch=None, single=False):
                        "resident operands): avg_launch_us_back_to_back",
                 avg_launch_us_back_to_back=round(fam_hot_ms * 1e3, 1), flop_per_launch=fam_flops, algorithmic_bytes_per_launch=round(fam_bytes),
                 traffic=(t_fam or {}).get("bytes_per_launch"), second_kernel=tn_entry,
-                traffic_source="profiles/r05_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
+                traffic_source="profiles/r06_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of "
                                "tools/prof_dominant.py; FETCH_SIZE divided by the factor measured on a known 1-GiB LDS-DMA stream, "
                                "tools/calib_fetch.py)",
                 ffn1_forward=dict(kernel="gemm_nt8_kernel<EPI_BIAS_GELU> (FFN1 forward, N=3072, K=768, writes gelu in bf16 and gelu' as 8-bit fixed point; a member of the family)",
