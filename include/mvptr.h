@@ -196,6 +196,11 @@ int mvptr_attention_bwd(const void* qkv, const float* mask_add, const void* ctx,
                         const void* dctx, const float* lse, void* dqkv, int B, int L, int heads,
                         const mvptr_dropout* drop, void* stream);
 
+/* The attention probabilities themselves, f32 [B, heads, L, L]: softmax(Q K^T / 8 + mask) of the same bf16 Q | K rows, no
+ * dropout.  Replaces the `attention_probs` a layer returns under config.output_attentions (modeling_vlbert.py:85,100-101;
+ * collected by CaptionBertEncoder.forward :167-168): an inspection output — the step's kernels never write an L x L tensor. */
+int mvptr_attention_probs(const void* qkv, const float* mask_add, float* probs, int B, int L, int heads, void* stream);
+
 /* Row-packed ("unpadded") form of the two calls above: the reference runs every padded slot of
  * every sequence through the encoder (modeling_vlbert.py:430-460 only masks them as keys); here the
  * valid rows of all sequences are packed back to back and sequence b occupies rows

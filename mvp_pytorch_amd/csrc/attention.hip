@@ -722,6 +722,61 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
 #endif
 }
 
+// ------------------------------------------------------- the probabilities as a tensor (output_attentions)
+// modeling_vlbert.py:100 hands attention_probs back when config.output_attentions is set: an inspection path, not part of
+// a step (the step's kernels above never write anything of size L x L).  One wave per (batch, head, query): a lane owns the
+// keys lane, lane + 64, ...; scores in f32 from the bf16 Q / K rows, softmax over the row, f32 out [B, heads, L, L].
+__global__ __launch_bounds__(256) void attn_probs_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ mask,
+                                                          float* __restrict__ probs, int B, int L, int heads) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b * heads + h) * L + q
+  if (row >= (int64_t)B * heads * L) return;
+  const int q = (int)(row % L);
+  const int bh = (int)(row / L);
+  const int h = bh % heads, b = bh / heads;
+  const int64_t ldq = 3 * (int64_t)heads * 64;
+  const __bf16* qp = qkv + ((int64_t)b * L + q) * ldq + h * 64;
+  float qv[64];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(qp + 8 * c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[8 * c + e] = bf2f(x[e]);
+  }
+  float s[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = lane + 64 * j;
+    s[j] = -INFINITY;
+    if (key < L) {
+      const __bf16* kp = qkv + ((int64_t)b * L + key) * ldq + heads * 64 + h * 64;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(kp + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qv[8 * c + e] * bf2f(x[e]);
+      }
+      s[j] = d * 0.125f + mask[(int64_t)b * L + key];
+    }
+    mx = fmaxf(mx, s[j]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[j] = (lane + 64 * j < L) ? __expf(s[j] - mx) : 0.f;
+    sum += s[j];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lane + 64 * j < L) probs[row * L + lane + 64 * j] = s[j] * inv;
+}
+
 // diagnostic build only: MVPTR_ATTN_TWO_PASS=1 keeps the two-pass kernel for every length (A/B measurements)
 bool two_pass_forced() {
 #ifdef MVPTR_DIAG_BUILD
@@ -781,6 +836,18 @@ extern "C" int mvptr_attention_fwd(const void* qkv, const float* mask_add, void*
                                    void* stream) {
   if (!mask_add) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_fwd: NULL mask/ctx");
   return mvptr_attention_fwd_packed(qkv, mask_add, ctx, lse, nullptr, nullptr, B, L, heads, drop, stream);
+}
+
+extern "C" int mvptr_attention_probs(const void* qkv, const float* mask_add, float* probs, int B, int L, int heads, void* stream) {
+  int rc = check_common("attention_probs", qkv, B, L, heads);
+  if (rc) return rc;
+  if (!mask_add || !probs) MVPTR_FAIL(MVPTR_BAD_ARG, "attention_probs: NULL argument");
+  const int64_t rows = (int64_t)B * heads * L;
+  if ((rows + 3) / 4 > 0x7fffffff) MVPTR_FAIL(MVPTR_BAD_SHAPE, "attention_probs: too many rows");
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)qkv,
+                     mask_add, probs, B, L, heads);
+  MVPTR_CHECK_LAUNCH("attention_probs");
+  return MVPTR_OK;
 }
 
 extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add, const void* ctx,

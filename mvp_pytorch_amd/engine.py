@@ -541,6 +541,8 @@ class EncoderMeta:
 GELU_STASH_BF16 = False
 # Default of EncoderMeta.defer_wgrad (A/B switch: bench.py --wgrad-per-layer, tests).
 DEFER_WGRAD = True
+# Upper bound on the bytes the deferred mode may keep alive per stack (None: only an allocation failure ends it).
+DEFER_WGRAD_MAX_BYTES = None
 # CUs the stack-wide weight-gradient launch leaves free (0: it takes every CU).  Its workgroups keep their CU for the whole
 # launch (0.6 - 3 ms): dp.GradSync sets this in multi-rank RCCL jobs so that the collectives' kernels find a CU meanwhile.
 WGRAD_RESERVE_CUS = 0
@@ -753,7 +755,21 @@ class EncoderFn(GradAwareFunction):
         # problems (4 per layer) go out as one balanced launch after the last layer (mvptr_gemm_tn_stack)
         defer = bool(getattr(meta, "defer_wgrad", False)) and n >= 1
         ws_step = (ws_bytes + 255) // 256 * 256
-        ws = torch.empty(ws_step * n if defer else ws_bytes, device=dev, dtype=torch.uint8)
+        # one workspace per layer stays alive until the stack launch (~18 KB per row per layer: 4 GB for six layers at
+        # M = 37 748).  A stack that does not get that memory takes the per-layer path, as before round 5.
+        ws = None
+        if defer and DEFER_WGRAD_MAX_BYTES is not None and ws_step * n > DEFER_WGRAD_MAX_BYTES:
+            defer = False
+        if defer:
+            try:
+                ws = torch.empty(ws_step * n, device=dev, dtype=torch.uint8)
+            except torch.OutOfMemoryError:
+                if torch.cuda.is_current_stream_capturing():
+                    raise
+                defer = False
+        if ws is None:
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        EncoderFn.last_backward_deferred = defer
         probs = (hip.TnProblem * (4 * n))() if defer else None
         n_probs = 0
         delivered_later = []

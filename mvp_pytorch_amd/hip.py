@@ -24,7 +24,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_GELU_BWD, EPI_ADD, EPI_F32, EPI_BIA
 # every symbol include/mvptr.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "mvptr_query", "mvptr_last_error", "mvptr_gemm_nt", "mvptr_gemm_tn", "mvptr_gemm_tn_multi", "mvptr_colsum",
-    "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
+    "mvptr_attention_fwd", "mvptr_attention_bwd", "mvptr_attention_fwd_packed", "mvptr_attention_bwd_packed", "mvptr_attention_probs", "mvptr_layernorm_fwd", "mvptr_layernorm_bwd",
     "mvptr_layernorm_bwd_ws_bytes", "mvptr_embed_fwd", "mvptr_embed_bwd", "mvptr_cast_pack", "mvptr_cast_multi", "mvptr_cast_f32", "mvptr_ce_fwd",
     "mvptr_ce_bwd", "mvptr_adamw_multi", "mvptr_dropout_mask", "mvptr_layer_saved_bytes", "mvptr_layer_workspace_bytes",
     "mvptr_encoder_layer_fwd", "mvptr_encoder_layer_bwd", "mvptr_b64_decode_features",
@@ -118,6 +118,7 @@ def load():
     lib.mvptr_cast_multi.argtypes = [P, P, I, I, P]
     lib.mvptr_attention_fwd.argtypes = [P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
+    lib.mvptr_attention_probs.argtypes = [P, P, P, I, I, I, P]
     lib.mvptr_attention_fwd_packed.argtypes = [P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_attention_bwd_packed.argtypes = [P, P, P, P, P, P, P, P, I, I, I, POINTER(Dropout), P]
     lib.mvptr_layernorm_fwd.argtypes = [P, P, P, F, P, P, P, I, I, I, I, I, POINTER(Dropout), P]
@@ -360,6 +361,13 @@ def attention_bwd(qkv, mask_add, ctx, dctx, lse, B, L, heads, drop=None):
     dqkv = torch.empty_like(qkv)
     _check(load().mvptr_attention_bwd(_p(qkv), _p(mask_add), _p(ctx), _p(dctx), _p(lse), _p(dqkv), B, L, heads, _dp(drop), _stream()))
     return dqkv
+
+
+def attention_probs(qkv, mask_add, B, L, heads):
+    """softmax(Q K^T / 8 + mask) as a tensor, f32 [B, heads, L, L] (config.output_attentions; no dropout)."""
+    probs = torch.empty((B, heads, L, L), device=qkv.device, dtype=torch.float32)
+    _check(load().mvptr_attention_probs(_p(qkv), _p(mask_add), _p(probs), B, L, heads, _stream()))
+    return probs
 
 
 def attention_fwd_packed(qkv, seq_start, seq_len, B, Lmax, heads, mask_add=None, drop=None, need_lse=True):

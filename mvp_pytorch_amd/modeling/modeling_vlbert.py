@@ -104,8 +104,8 @@ class CaptionBertEncoder(nn.Module):
 
     def __init__(self, config):
         super().__init__()
-        if config.output_attentions or config.output_hidden_states:
-            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused encoder")
+        # vl:131-132.  Both are inspection outputs: a stack that has to hand them back runs layer by layer on padded tensors
+        # (_forward_inspect); the step's fused path never materialises them.
         self.output_attentions = config.output_attentions
         self.output_hidden_states = config.output_hidden_states
         self.num_layers = config.num_hidden_layers
@@ -155,10 +155,12 @@ class CaptionBertEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None,
                 return_at_layer=None, pack_hint=None):
-        if isinstance(attention_mask, list) or encoder_history_states is not None:
-            raise NotImplementedError("phase masks / history states are outside the accelerated path")
+        if encoder_history_states is not None:
+            raise NotImplementedError("history states are outside the accelerated path")
         if head_mask is not None and any(h is not None for h in head_mask):
             raise NotImplementedError("head_mask must stay None")
+        if isinstance(attention_mask, (list, tuple)) or self.output_hidden_states or self.output_attentions:
+            return self._forward_inspect(hidden_states, attention_mask, return_at_layer)
         if return_at_layer is not None:
             # vl:162-163,176-177: also hand back the hidden states after layer `return_at_layer` -> ((final,), mid).
             # Two segments of the stack on padded tensors (the mid output is read position by position).
@@ -230,6 +232,68 @@ def _run_layers(self, hidden_states, attention_mask, first, count):
 
 
 CaptionBertEncoder._run_layers = _run_layers
+
+
+def _forward_inspect(self, hidden_states, attention_mask, return_at_layer=None):
+    """vl:134-178 with the outputs the fused call does not produce: `all_hidden_states` (config.output_hidden_states: the input
+    of every layer + the last output), `all_attentions` (config.output_attentions: softmax(QK^T/8 + mask) per layer, f32
+    [B, heads, L, L], detached), and a LIST of masks (one per phase of ceil(n / len) layers; the first phase's output is handed
+    back as `stage_output`).  Same tuple order as the reference: (hidden, [all_hidden], [all_attentions], [stage_output]), and
+    (outputs, mid_output) with return_at_layer.  Padded execution, runs of layers that need nothing collected stay one launch
+    sequence (_run_layers)."""
+    n = len(self.layer)
+    phased = isinstance(attention_mask, (list, tuple))
+    masks = list(attention_mask) if phased else [attention_mask]
+    per = -(-n // len(masks))
+    heads = self._dims[1]
+    if self.output_attentions and self.training and self.layer[0].attention.self.dropout.p > 0:
+        raise NotImplementedError("output_attentions with active attention dropout: the kernels keep no L x L mask to hand back "
+                                  "(use eval mode or attention_probs_dropout_prob = 0)")
+    every = self.output_hidden_states or self.output_attentions
+    cuts = set(range(1, n)) if every else set()
+    if phased:
+        cuts.update(range(per, n, per))
+    if return_at_layer is not None and 0 <= int(return_at_layer) < n - 1:
+        cuts.add(int(return_at_layer) + 1)
+    bounds = [0] + sorted(cuts) + [n]
+    all_h, all_a = (), ()
+    stage = mid = None
+    h = hidden_states.to(torch.bfloat16)
+    for first, last in zip(bounds[:-1], bounds[1:]):
+        m = masks[first // per].contiguous()
+        if self.output_hidden_states:
+            all_h += (h,)
+        if self.output_attentions:
+            all_a += (self._attention_probs(h, m, first, heads),)
+        h = self._run_layers(h, m, first, last - first)
+        if phased and last == per:
+            stage = h
+        if return_at_layer is not None and last - 1 == int(return_at_layer):
+            mid = h
+    outputs = (h,)
+    if self.output_hidden_states:
+        outputs += (all_h + (h,),)
+    if self.output_attentions:
+        outputs += (all_a,)
+    if stage is not None:
+        outputs += (stage,)
+    return (outputs, mid) if return_at_layer is not None else outputs
+
+
+def _attention_probs(self, hidden_states, mask_add, li, heads):
+    """Layer li's attention probabilities for its input `hidden_states`: Q | K projection of the same bf16 rows (mvptr_gemm_nt,
+    bias epilogue) + mvptr_attention_probs."""
+    B, L, H = hidden_states.shape
+    a = self.layer[li].attention.self
+    with torch.no_grad():
+        w = torch.cat([a.query.weight, a.key.weight, a.value.weight]).to(torch.bfloat16)
+        b = torch.cat([a.query.bias, a.key.bias, a.value.bias]).float()
+        qkv = hip.gemm_nt(hidden_states.detach().contiguous().view(B * L, H), w, hip.EPI_BIAS, bias=b)
+        return hip.attention_probs(qkv, mask_add, B, L, heads)
+
+
+CaptionBertEncoder._forward_inspect = _forward_inspect
+CaptionBertEncoder._attention_probs = _attention_probs
 
 
 def _forward_rows(self, x_rows, seq_start, seq_len, n_seq, lmax, rows_dev=None, rows_plan=0):
@@ -305,16 +369,19 @@ class BertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
             attention_mask = torch.ones((input_ids.shape[0], n), dtype=torch.long, device=input_ids.device)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
-        mask = additive_mask(attention_mask)
+        phased = isinstance(attention_mask, (list, tuple))      # vl:265-276: one mask per phase of the stack
+        mask = [additive_mask(m) for m in attention_mask] if phased else additive_mask(attention_mask)
         x = embed_inputs(self.embeddings, input_ids, token_type_ids, position_ids, img_feats, self)
-        if pack_hint is not None and x.is_cuda and (self.encoder.unpad is True or (self.encoder.unpad == "train" and self.training)):
+        if pack_hint is not None and not phased and x.is_cuda and (self.encoder.unpad is True or (self.encoder.unpad == "train" and self.training)):
             ln = attention_mask.sum(1)
             cnt = torch.stack([ln.sum(), ln.max()]).to(torch.int64)
             hip.check_counts(cnt, cnt, tuple(int(v) for v in pack_hint) * 2)
         else:
             pack_hint = None
-        sequence_output = self.encoder(x, mask, pack_hint=pack_hint)[0]
-        return (sequence_output, self.pooler(sequence_output))
+        encoder_outputs = self.encoder(x, mask, pack_hint=pack_hint)
+        sequence_output = encoder_outputs[0]
+        # vl:346-347: hidden states / attentions / stage output follow when the configuration asks for them
+        return (sequence_output, self.pooler(sequence_output)) + tuple(encoder_outputs[1:])
 
 
 class BiBertImgModel(_ImgBackboneMixin, BertPreTrainedModel):
@@ -1020,14 +1087,15 @@ class BertImgForPreTraining(ImgPreTrainedModel):
         """host_counts (optional, not a reference argument): dict(rows, lmax, scored) computed where the batch was built
         (synthetic.synthetic_batch(single_stream=True)) — the loss-only training step then reads nothing back from the device."""
         hint = (int(host_counts["rows"]), int(host_counts["lmax"])) if host_counts is not None else None
-        sequence_output, pooled_output = self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
-                                                   attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
-                                                   pack_hint=hint)
+        outputs = self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
+                            attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats, pack_hint=hint)
+        sequence_output, pooled_output = outputs[:2]
+        extras = tuple(outputs[2:])       # vl:1116: hidden states / attentions when the configuration asks for them
         T = self.max_text_seq_length
         text = sequence_output[:, :T, :] if T is not None else sequence_output
         seq_relationship_score = self.cls.seq_relationship(pooled_output)
         if masked_lm_labels is None or next_sentence_label is None:
-            return (self.cls.predictions(text), seq_relationship_score)
+            return (self.cls.predictions(text), seq_relationship_score) + extras
         labels = masked_lm_labels[:, :T].contiguous() if T is not None else masked_lm_labels
         if not self.return_prediction_scores:
             # training loops that read outputs[0] only (run_oscarplus_pretrain-style): the head runs on
@@ -1049,7 +1117,7 @@ class BertImgForPreTraining(ImgPreTrainedModel):
         loss_fct = CrossEntropyLoss(ignore_index=-1)
         next_sentence_loss = loss_fct(seq_relationship_score.view(-1, self.num_seq_relations), next_sentence_label.view(-1))
         total_loss = masked_lm_loss + next_sentence_loss
-        return (total_loss, prediction_scores, seq_relationship_score, masked_lm_loss)
+        return (total_loss, prediction_scores, seq_relationship_score) + extras + (masked_lm_loss,)
 
 
 class BiBertImgForPreTraining(ImgPreTrainedModel):

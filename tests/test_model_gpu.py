@@ -1319,6 +1319,108 @@ def test_return_at_layer_and_phrase_layer(dev, k):
         assert torch.equal(mid_joint, out4[0][0])
 
 
+def test_encoder_hidden_states_attentions_and_phase_masks(dev):
+    """vl:131-178: the outputs only an inspecting caller asks for — config.output_hidden_states (input of every layer + the last
+    output), config.output_attentions (softmax(QK^T/8 + mask) per layer) and a LIST of masks (one per phase of the stack, the
+    first phase's output handed back as `stage_output`) — against the oracle's layer loop; tuple order as the reference's;
+    the plain call's values; BertImgModel / BertImgForPreTraining pass the extras on (vl:347, vl:1116)."""
+    from mvp_pytorch_amd import modeling
+    from oracle import mvptr_oracle as orc
+    cfg = dict(gu.TINY_CFG, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(5)
+    plain_model = modeling.BertImgModel(modeling.make_config(cfg)).to(dev).eval()
+    both = modeling.BertImgModel(modeling.make_config(dict(cfg, output_hidden_states=True, output_attentions=True))).to(dev).eval()
+    both.load_state_dict(plain_model.state_dict())
+    sd = {n: p.detach().float().cpu() for n, p in plain_model.state_dict().items()}
+    enc, enc_p = both.encoder, plain_model.encoder
+    n, heads, eps = len(enc.layer), cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    g = torch.Generator().manual_seed(9)
+    B, L, H = 4, 21, cfg["hidden_size"]
+    x = (torch.randn(B, L, H, generator=g) * 0.5).to(torch.bfloat16)
+    lens = torch.tensor([21, 9, 14, 3])
+    mask01 = (torch.arange(L)[None, :] < lens[:, None]).long()
+    add = (1.0 - mask01.float()) * -10000.0
+    valid = mask01.bool()
+
+    def ref_probs(prefix, h):
+        d = H // heads
+        q = orc.linear(sd, prefix + ".query", h).view(B, L, heads, d).permute(0, 2, 1, 3)
+        k = orc.linear(sd, prefix + ".key", h).view(B, L, heads, d).permute(0, 2, 1, 3)
+        return torch.softmax(q @ k.transpose(-1, -2) / d ** 0.5 + add[:, None, None, :], dim=-1)
+
+    with torch.no_grad():
+        out = enc(x.to(dev), add.to(dev))
+        plain = enc_p(x.to(dev), add.to(dev))[0]
+    assert len(out) == 3 and len(out[1]) == n + 1 and len(out[2]) == n
+    assert torch.equal(out[0], out[1][-1]) and torch.equal(out[1][0].cpu(), x)
+    assert _rel(out[0].float().cpu()[valid], plain.float().cpu()[valid]) < 4e-3
+    h = x.float()
+    for i in range(n):
+        # each layer against the oracle's layer on the SAME (bf16) input, so errors do not accumulate across the comparison
+        h_in = out[1][i].float().cpu()
+        pr = ref_probs("encoder.layer.%d.attention.self" % i, h_in)
+        got = out[2][i].cpu()
+        assert got.shape == (B, heads, L, L) and got.dtype == torch.float32
+        assert float((got - pr).abs().max()) < 2e-2 and float((got.sum(-1) - 1).abs().max()) < 1e-5
+        assert float((got * (1 - mask01)[:, None, None, :].float()).max()) == 0.0       # padded keys weigh exp(-10000) = 0
+        ref_out = orc.encoder_layer(sd, "encoder.layer.%d" % i, h_in, add[:, None, None, :], heads, eps)
+        assert _rel(out[1][i + 1].float().cpu()[valid], ref_out[valid]) < 2e-2, i
+        h = orc.encoder_layer(sd, "encoder.layer.%d" % i, h, add[:, None, None, :], heads, eps)
+    assert _rel(out[0].float().cpu()[valid], h[valid]) < 3e-2
+    # only one of the two flags: tuple positions as vl:170-175
+    enc.output_attentions = False
+    with torch.no_grad():
+        o = enc(x.to(dev), add.to(dev))
+    assert len(o) == 2 and len(o[1]) == n + 1 and torch.equal(o[0], out[0])
+    enc.output_attentions, enc.output_hidden_states = True, False
+    with torch.no_grad():
+        o = enc(x.to(dev), add.to(dev))
+    assert len(o) == 2 and len(o[1]) == n and torch.equal(o[1][0], out[2][0])
+    enc.output_hidden_states = True
+    # phase masks: first ceil(n / 2) layers see every key, the rest the padded mask; + return_at_layer
+    open_add = torch.zeros_like(add)
+    per = -(-n // 2)
+    with torch.no_grad():
+        (final, stage), mid = enc_p(x.to(dev), [open_add.to(dev), add.to(dev)], return_at_layer=0)
+    h = x.float()
+    for i in range(n):
+        h = orc.encoder_layer(sd, "encoder.layer.%d" % i, h, (open_add if i < per else add)[:, None, None, :], heads, eps)
+        if i == 0:
+            assert _rel(mid.float().cpu(), h) < 2e-2
+        if i == per - 1:
+            assert _rel(stage.float().cpu(), h) < 3e-2
+    assert _rel(final.float().cpu()[valid], h[valid]) < 3e-2
+    # gradients reach the first layer through the collected states
+    both.train()
+    xd = x.to(dev).requires_grad_(True)
+    o = enc(xd, add.to(dev))
+    sum(t.float()[valid.to(dev)].sum() for t in o[1][1:]).backward()
+    w0 = enc.layer[0].attention.self.query.weight.grad
+    assert xd.grad is not None and w0 is not None and float(w0.abs().sum()) > 0
+    both.eval()
+    # the models hand the extras on
+    from mvp_pytorch_amd.synthetic import synthetic_batch
+    b = synthetic_batch(dict(gu.TINY_DIMS, B=3), cfg, 4, single_stream=True, device=dev)
+    kw = dict(input_ids=b["input_ids"], token_type_ids=b["segment_ids"], attention_mask=b["input_mask"], img_feats=b["img_feats"])
+    with torch.no_grad():
+        o = both(**kw)
+        o_plain = plain_model(**kw)
+    Lt = b["input_mask"].shape[1]
+    assert len(o) == 4 and len(o_plain) == 2 and len(o[2]) == n + 1 and o[3][0].shape == (3, heads, Lt, Lt)
+    v = b["input_mask"].bool()
+    assert _rel(o[0].float()[v], o_plain[0].float()[v]) < 4e-3
+    pre = modeling.BertImgForPreTraining(modeling.make_config(dict(cfg, output_hidden_states=True, max_text_seq_length=gu.TINY_DIMS["T"]))).to(dev).eval()
+    with torch.no_grad():
+        o = pre(masked_lm_labels=b["lm_label_ids"], next_sentence_label=b["is_next"], **kw)
+        o2 = pre(**kw)
+    assert len(o) == 5 and len(o[3]) == n + 1 and o[4].dim() == 0 and len(o2) == 3 and len(o2[2]) == n + 1
+    # what stays outside: dropout on the probabilities leaves no L x L mask to hand back
+    both.train()
+    enc.layer[0].attention.self.dropout.p = 0.1
+    with pytest.raises(NotImplementedError):
+        enc(x.to(dev), add.to(dev))
+
+
 @pytest.mark.parametrize("name", ["tiny_bi_pretrain_nophrase", "cfg1_bi_pretrain_nophrase"])
 def test_packed_training_path_matches_reference(dev, name):
     """the path bench.py times — model.train(), row-packed pipeline (_forward_packed + forward_packed +
@@ -1579,6 +1681,59 @@ def test_deferred_stack_weight_gradients_equal_per_layer(dev, layers, rows, drop
         # rounding per summand apart (measured 1.6e-3)
         tol = 5e-3 if n.endswith("intermediate.dense.bias") else 2e-5
         assert _rel(g1[n], g0[n]) < tol, (n, _rel(g1[n], g0[n]))
+
+
+def test_deferred_weight_gradients_fall_back_when_memory_is_short(dev):
+    """the deferred mode keeps one backward workspace per layer alive; a stack that may not (byte cap,
+    engine.DEFER_WGRAD_MAX_BYTES) or cannot (allocation failure) have that takes the per-layer launches and gets their gradients."""
+    from mvp_pytorch_amd import engine, modeling
+    cfg = dict(gu.BASE_CFG, num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    enc = modeling.modeling_vlbert.CaptionBertEncoder(modeling.make_config(cfg)).to(dev).train()
+    g = torch.Generator().manual_seed(6)
+    B, L = 24, 64
+    x = (torch.randn(B * L, 768, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dy = (torch.randn(B * L, 768, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    starts = (torch.arange(B, dtype=torch.int32) * L).to(dev)
+    lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+
+    def run(defer, cap=None, fail_alloc=False):
+        prev = (engine.DEFER_WGRAD, engine.DEFER_WGRAD_MAX_BYTES)
+        engine.DEFER_WGRAD, engine.DEFER_WGRAD_MAX_BYTES = defer, cap
+        real_empty = torch.empty
+        state = {"failed": 0}
+
+        def empty(*a, **k):      # the first large byte buffer (the per-layer workspaces) does not fit
+            if fail_alloc and not state["failed"] and k.get("dtype") == torch.uint8 and a and isinstance(a[0], int) and a[0] > (1 << 20):
+                state["failed"] = 1
+                raise torch.OutOfMemoryError("simulated")
+            return real_empty(*a, **k)
+        try:
+            enc.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            y = enc.forward_rows(xin, starts, lens, B, L)
+            torch.empty = empty
+            try:
+                y.backward(dy)
+            finally:
+                torch.empty = real_empty
+            torch.cuda.synchronize()
+            assert (not fail_alloc) or state["failed"] == 1
+            return engine.EncoderFn.last_backward_deferred, xin.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}
+        finally:
+            engine.DEFER_WGRAD, engine.DEFER_WGRAD_MAX_BYTES = prev
+
+    was0, dx0, g0 = run(False)
+    was1, dx1, g1 = run(True)
+    was2, dx2, g2 = run(True, cap=1 << 20)
+    was3, dx3, g3 = run(True, fail_alloc=True)
+    assert (was0, was1, was2, was3) == (False, True, False, False)
+    for dx, gg in ((dx2, g2), (dx3, g3)):
+        assert torch.equal(dx, dx0)
+        for n in g0:
+            # the same launches as DEFER_WGRAD = False (their split-K partial sums arrive in any order: f32 summation order apart)
+            assert g0[n].norm() == 0 or _rel(gg[n], g0[n]) < 2e-5, n
+    assert torch.equal(dx1, dx0)
 
 
 def test_deferred_weight_gradients_reach_non_f32_parameters(dev):

@@ -370,6 +370,29 @@ def _attn_ref(qkv, mask, B, L, heads, keep=None, scale=1.0):
     return ctx, torch.logsumexp(s, -1)
 
 
+@pytest.mark.parametrize("L", [5, 64, 70, 125, 256])
+def test_attention_probs_tensor(dev, L):
+    """mvptr_attention_probs (config.output_attentions, vl:85,100): softmax(QK^T/8 + mask) of the bf16 rows in f32, and
+    consistent with the fused kernel: probs @ V is its context output."""
+    g = torch.Generator().manual_seed(L)
+    B, heads = 3, 12
+    H = heads * 64
+    qkv = (torch.randn(B * L, 3 * H, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    lens = torch.tensor([L, max(1, L // 2), max(1, L - 3)])
+    mask = ((torch.arange(L)[None, :] >= lens[:, None]).float() * -10000.0).to(dev)
+    from mvp_pytorch_amd import hip
+    probs = hip.attention_probs(qkv, mask, B, L, heads)
+    q, k, v = (t.float().view(B, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.split(H, dim=1))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125 + mask[:, None, None, :], dim=-1)
+    assert probs.shape == (B, heads, L, L)
+    assert float((probs - ref).abs().max()) < 1e-5
+    ctx, _ = hip.attention_fwd(qkv, mask, B, L, heads)
+    mine = (probs @ v).permute(0, 2, 1, 3).reshape(B * L, H)
+    assert float((mine - ctx.float()).abs().max()) < 2e-2
+    with pytest.raises(RuntimeError):
+        hip.attention_probs(qkv, None, B, L, heads)
+
+
 @pytest.mark.parametrize("B,L,heads", [(2, 32, 2), (3, 45, 2), (2, 125, 12), (2, 70, 12), (1, 193, 4), (2, 256, 2), (2, 5, 1)])
 def test_attention_fwd_bwd(dev, B, L, heads):
     from mvp_pytorch_amd import hip
