@@ -62,8 +62,10 @@ Design
     behind that bucket's collective (while the later buckets are still on the wire), and after the last
     one only the one-workgroup coefficient kernel and AdamW remain (`clip_coef`).  Same slots, same
     values, same summation order as the pass over the whole arena: bit-identical norm;
-  * `collective="rs_ag"` (opt-in, RCCL only): every dense bucket goes out as reduce-scatter +
-    all-gather over its chunk-padded span (SURVEY 8e) instead of one all-reduce; bench.py times both;
+  * `collective="rs_ag"` (opt-in): every dense bucket goes out as reduce-scatter + all-gather over its chunk-padded span
+     instead of one all-reduce; bench.py times both.  Any world size (spans are padded to NORM_CHUNK x world
+    elements when the world is not a power of two); on gloo, which has no reduce_scatter_tensor, the same span goes out as
+    one all-reduce (CPU tests of the layout);
 `force_collectives=True` runs the whole exchange (hooks, bucket launches, wire conversion, row union,
 used-parameter bitmap) on a process group of ONE rank: the RCCL code path on a single GPU
 (tests/test_dp_gpu.py).
@@ -157,10 +159,9 @@ class GradSync:
         self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
-        if collective == "rs_ag" and self.world > 1 and backend != "nccl":
-            raise ValueError("GradSync(collective='rs_ag') needs the RCCL backend (gloo has no reduce_scatter_tensor)")
-        if collective == "rs_ag" and (self.world & (self.world - 1)):
-            raise ValueError("GradSync(collective='rs_ag'): the chunk-padded bucket spans divide evenly over power-of-two world sizes only")
+        # rs_ag on gloo (no reduce_scatter_tensor there) is EMULATED by an all-reduce of the same padded span: CPU tests of the layout
+        # only.  World sizes that are not a power of two pad every bucket to NORM_CHUNK x world elements (below), so the span
+        # always divides evenly.
         self._ctl = _control_group(process_group) if self.exchange else None      # host-side exchange of the used-parameter bitmap
         self.comm_dtype = torch.float32 if comm_dtype in (None, "auto") else comm_dtype
         self._hot = None          # params some rank has produced a gradient for; None = unknown (step 0)
@@ -265,7 +266,10 @@ class GradSync:
         # one allocation for all buckets, each starting on a multiple of NORM_CHUNK elements (64 KiB): zero_grad() is one
         # fill, and the chunks of the gradient-norm pass never straddle two buckets (per-bucket partial sums, clip_coef)
         total = 0
-        quantum = NORM_CHUNK * (self.world if self.shard_optimizer else 1)    # a rank's shard of a bucket = whole norm chunks
+        # a rank's shard of a bucket = whole norm chunks (sharded optimizer); rs_ag needs spans that divide by the world size
+        # (NORM_CHUNK = 2^14 already does for power-of-two worlds)
+        odd_world = self.collective == "rs_ag" and (self.world & (self.world - 1)) != 0
+        quantum = NORM_CHUNK * (self.world if (self.shard_optimizer or odd_world) else 1)
         for b in self.buckets:
             b["base"] = total
             b["padded"] = (b["n"] + quantum - 1) // quantum * quantum
@@ -618,11 +622,16 @@ class GradSync:
         if self.collective == "rs_ag" and src is b["flat"]:
             # reduce-scatter + all-gather over the bucket's chunk-padded span (the padding is zero and stays zero): every
             # rank owns 1 / world of it between the two collectives
-            span = self._arena[b["base"]:b["base"] + (b["n"] + NORM_CHUNK - 1) // NORM_CHUNK * NORM_CHUNK]
+            span = self._arena[b["base"]:b["base"] + b["padded"]]
+            assert span.numel() % self.world == 0
             wire = span if self.comm_dtype == torch.float32 else span.to(self.comm_dtype)
+            b["wire"] = wire
+            if not self._avg:        # gloo: the same span as ONE all-reduce (emulation, see __init__)
+                b["work"] = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+                self._next = idx + 1
+                return
             shard = torch.empty(wire.numel() // self.world, device=wire.device, dtype=wire.dtype)
             dist.reduce_scatter_tensor(shard, wire, op=op, group=self.group, async_op=True)
-            b["wire"] = wire
             b["shard"] = shard      # kept alive until the all-gather has run
             b["work"] = dist.all_gather_into_tensor(wire, shard, group=self.group, async_op=True)   # same communicator: ordered behind the reduce-scatter
             self._next = idx + 1

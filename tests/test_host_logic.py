@@ -298,6 +298,55 @@ def test_grad_sync_two_ranks_gloo(comm_dtype):
     assert v0 == v1 == [3.0, 4.0, 6.0]
 
 
+def _dp_rs_ag_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from mvp_pytorch_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 300), torch.nn.Tanh(), torch.nn.Linear(300, 70), torch.nn.Linear(70, 2))
+    sync = dp.GradSync(m, bucket_mb=0.01, comm_dtype=torch.float32, sparse_rows=[], collective="rs_ag")
+    assert len(sync.buckets) > 2 and all(b["padded"] % world == 0 and b["padded"] % dp.NORM_CHUNK == 0 for b in sync.buckets)
+    out = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(6, 8, generator=g)
+        (m(x) ** 2).sum().backward()
+        sync(want_norm=True)
+        norm, _ = sync.clip_coef(1.0)
+        want = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+        assert abs(float(norm) - float(want)) <= 1e-5 * max(1.0, float(want))
+        ref = torch.autograd.grad((m(x) ** 2).sum(), list(m.parameters()))
+        out.append(([p.grad.detach().clone().numpy() for p in m.parameters()], [r.numpy() for r in ref]))
+        sync.zero_grad()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_rs_ag_layout_on_three_ranks_gloo():
+    """collective='rs_ag' at a world size that is not a power of two (it used to refuse them): every bucket's span is
+    padded to NORM_CHUNK x world elements, so the reduce-scatter shards divide evenly; on gloo the span goes out as one all-reduce
+    (no reduce_scatter_tensor there), which checks the layout, the averaging and the per-bucket norm partial sums on 3 ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = gu.free_port()
+    procs = [ctx.Process(target=_dp_rs_ag_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(3)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(3):
+        for i in range(len(res[0][1][step][0])):
+            want = sum(res[r][1][step][1][i] for r in range(3)) / 3
+            for r in range(3):
+                assert np.allclose(res[r][1][step][0][i], want, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+                assert np.array_equal(res[r][1][step][0][i], res[0][1][step][0][i])
+
+
 def _dp_sparse_worker(rank, world, port, q, comm_dtype):
     import torch.distributed as dist
     from mvp_pytorch_amd import dp
