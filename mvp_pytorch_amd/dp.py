@@ -50,8 +50,10 @@ Design
     ranks fall back to the dense all-reduce of that bucket for the step.  PRECONDITION: every gradient
     row of the table comes from the noted lookups — a table that is tied to another module's weight
     (BertImgForPreTraining ties the MLM decoder to it, modeling_vlbert.py:1095-1100) gets a dense
-    gradient and is rejected here.  The union needs two small blocking all-gathers and host reads
-    inside the launch, which is why it is not the default;
+    gradient and is rejected here.  Formed from DEVICE ids the union needs two small blocking all-gathers and host reads
+    inside the launch; a batch that brings its looked-up rows on the HOST (synthetic.word_rows, batch["word_rows"]) has the
+    union formed ahead of the backward pass over the gloo control group (exchange_rows_early, round 6): nothing is gathered
+    or read back inside the launch then;
   * one backward per zero_grad(), or gradient accumulation inside `with sync.no_sync():` for all but
     the last backward — a second backward outside no_sync() would add into buckets that are already
     being reduced and raises.
@@ -156,6 +158,7 @@ class GradSync:
                 raise ValueError("GradSync: a row-sparse parameter is shared by %d modules (tied weights): its gradient is "
                                  "dense, exchange it densely" % owners)
         self._rows = {}           # row-sparse parameter -> list of id tensors noted for this step
+        self._early_union = {}    # row-sparse parameter -> union formed ahead of the backward pass (exchange_rows_early), False = dense
         self.cap = max(1, int(bucket_mb * (1 << 20) // 4))
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self._avg = backend == "nccl"   # RCCL averages in the collective; gloo sums, we scale
@@ -442,6 +445,7 @@ class GradSync:
         self._uses, self._done = {}, {}   # direct delivery: uses noted in forward passes / deliveries so far
         self._hook_skip = {}              # parameter whose next post-accumulate hook repeats a completed direct delivery -> None (or, check_mixed_use, a clone of its .grad then)
         self._rows = {}
+        self._early_union = {}
         self._next = 0            # buckets [0, _next) have been launched this step
         self._norm_done = set()   # buckets whose partial sums of squares are in their slots (finish(want_norm=True))
         self._norm_summed = False
@@ -458,10 +462,51 @@ class GradSync:
         ids = ids if isinstance(ids, (list, tuple)) else [ids]
         self._rows.setdefault(param, []).extend(t.reshape(-1) for t in ids if t is not None)
 
+    def exchange_rows_early(self, param, host_ids):
+        """The row union of this step formed AHEAD of the backward pass, host to host (round 6).  `host_ids`: CPU int64 tensor(s) with
+        the ids this rank's shard looks up in `param` — input data, known where the batch is built (synthetic.host_counts puts the
+        unique ids into batch["word_rows"], synthetic.word_rows).  The ranks exchange them over the gloo control group while the device is
+        still busy with earlier work, every rank forms the same sorted union, and the union goes to the device as one pinned,
+        asynchronous copy: the launch of the sparse bucket then finds it ready — no all-gather on the data communicator, no device
+        read-back and no host wait inside the launch (_row_union's late form has two of each).  COLLECTIVE: every rank calls it in
+        the same steps (same program, same batch layout); a step without it takes the late form."""
+        if not self.exchange or param not in self.sparse:
+            return
+        ids = host_ids if isinstance(host_ids, (list, tuple)) else [host_ids]
+        ids = [t.reshape(-1) for t in ids if t is not None]
+        if any(t.is_cuda for t in ids):
+            raise ValueError("GradSync.exchange_rows_early takes HOST ids (the device ids go to note_rows)")
+        mine = torch.unique(torch.cat(ids).to(torch.int64)) if ids else torch.empty(0, dtype=torch.int64)
+        rows = param.shape[0]
+        if mine.numel() and (int(mine.min()) < 0 or int(mine.max()) >= rows):
+            raise RuntimeError("GradSync.exchange_rows_early: row id outside the table")
+        if dist.is_initialized() and self.world > 1:
+            cnt = torch.tensor([mine.numel()], dtype=torch.int64)
+            cnts = [torch.empty_like(cnt) for _ in range(self.world)]
+            dist.all_gather(cnts, cnt, group=self._ctl)
+            cnts = [int(c) for c in cnts]
+            pad = torch.full((max(1, max(cnts)),), -1, dtype=torch.int64)
+            pad[:mine.numel()] = mine
+            parts = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad, group=self._ctl)
+            union = torch.unique(torch.cat([q[:c] for q, c in zip(parts, cnts)]))
+        else:
+            union = mine
+        if union.numel() == 0 or union.numel() * 2 > rows:
+            self._early_union[param] = False            # nothing to gain: dense exchange (same decision on every rank)
+            return
+        dev = param.device
+        if dev.type == "cuda":
+            union = union.pin_memory().to(dev, non_blocking=True)
+        self._early_union[param] = union
+
     def _row_union(self, b):
         """All ranks' unique row ids of this step -> the sorted union (identical on every rank), or
         None when some rank has no ids noted (dense fallback, decided from the gathered data alone)."""
         p = b["rows_of"]
+        early = self._early_union.pop(p, None)
+        if early is not None:
+            return None if early is False else early
         dev = b["flat"].device
         noted = self._rows.get(p)
         mine = torch.unique(torch.cat(noted).to(dev)) if noted else None

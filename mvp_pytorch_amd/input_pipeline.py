@@ -188,10 +188,11 @@ class PretrainBatchStager:
         s.decoded, s.staged, s.have_bf16 = False, True, s.bf16_d is not None
         # the input-only counts of the step, taken from the host tensors while they are at hand (the model then needs no
         # read-back for them, synthetic.host_counts)
-        s.host_counts = None
+        s.host_counts = s.word_rows = None
         if all(k in batch for k in ("input_mask_a", "input_mask_b", "lm_label_ids_a", "lm_label_ids_b")):
-            from .synthetic import host_counts
+            from .synthetic import host_counts, word_rows
             s.host_counts = host_counts(batch)
+            s.word_rows = word_rows(batch)
 
     # ------------------------------------------------------------------ device side
     def get(self, check=False):
@@ -220,6 +221,7 @@ class PretrainBatchStager:
             batch["img_feats_bf16"] = s.bf16_d
         if getattr(s, "host_counts", None) is not None and not s.decoded:
             batch["host_counts"] = s.host_counts
+            batch["word_rows"] = s.word_rows
         s.in_use = True
         self._pending = s
         return batch

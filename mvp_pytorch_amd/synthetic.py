@@ -79,6 +79,7 @@ def synthetic_batch(dims, cfg, seed, single_stream=False, fixed_length=False, de
                      phrase_index=phrase_index, image_index=image_index)
     if not single_stream:
         batch["host_counts"] = host_counts(batch)     # input-only row counts, taken while the batch is still on the host
+        batch["word_rows"] = word_rows(batch)         # rows of the word table this batch looks up (data-parallel exchange)
     else:
         ln = batch["input_mask"].sum(1)
         batch["host_counts"] = HostCounts(rows=int(ln.sum()), lmax=int(ln.max()), scored=int((batch["lm_label_ids"][:, :T] > -1).sum()))
@@ -95,6 +96,28 @@ class HostCounts(dict):
         return self
 
     cuda = cpu = pin_memory = to
+
+
+class HostRows:
+    """Host-side int64 ids that stay on the host inside a batch dict (`.to()` returns the object itself; train.GraphedStep leaves
+    it out of a batch's signature): the rows of the word table a batch looks up, for dp.GradSync.exchange_rows_early."""
+    host_only = True
+
+    def __init__(self, ids):
+        self.ids = ids
+
+    def to(self, *a, **k):
+        return self
+
+    cuda = cpu = pin_memory = to
+
+
+def word_rows(batch):
+    """Unique word-table rows of a batch (text, phrase and tag ids; computed where the batch is built, on the host): the word
+    table's gradient is zero outside them, so a data-parallel job exchanges only the ranks' union of these rows — and, knowing
+    them before the step, forms that union host to host ahead of the backward pass (dp.GradSync.exchange_rows_early)."""
+    ids = [batch[k].reshape(-1) for k in ("input_ids_a", "input_ids_b", "input_ids") if k in batch]
+    return HostRows(torch.unique(torch.cat(ids).cpu()))
 
 
 def host_counts(batch):

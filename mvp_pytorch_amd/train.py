@@ -94,7 +94,13 @@ def pretrain_step(model, batch, optimizer, scheduler, max_tag_length=20, loss_we
         # (before backward: a hot bucket goes out from the hook of its last gradient)
         emb = getattr(getattr(getattr(model, "bert", None), "embeddings", None), "word_embeddings", None)
         if emb is not None and emb.weight in grad_sync.sparse:
-            grad_sync.note_rows(emb.weight, [batch.get("input_ids_a"), batch.get("input_ids_b"), batch.get("input_ids")])
+            hr = batch.get("word_rows")
+            if hr is not None and hasattr(grad_sync, "exchange_rows_early"):
+                # the batch came with its looked-up rows (synthetic.word_rows / a collate function): the ranks' union is formed now,
+                # host to host, and waits on the device when the table's bucket goes out (no collective or read-back in the launch)
+                grad_sync.exchange_rows_early(emb.weight, hr.ids)
+            else:
+                grad_sync.note_rows(emb.weight, [batch.get("input_ids_a"), batch.get("input_ids_b"), batch.get("input_ids")])
     outputs = forward(model, batch) if forward is not None else model(**model_inputs(batch, max_tag_length))
     loss = loss_weight * outputs[0]
     loss.backward()
@@ -170,6 +176,8 @@ class GraphedStep:
                 items.append((k, tuple(v.shape), str(v.dtype)))
             elif isinstance(v, dict):
                 items.append((k, tuple(sorted((kk, int(vv)) for kk, vv in v.items()))))
+            elif getattr(v, "host_only", False):
+                continue                # host-side companions of a batch (synthetic.HostRows): not an input of the device work
             elif v is not None:
                 return None
         return tuple(items) + (("training", bool(self.model.training)),)

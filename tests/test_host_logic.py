@@ -347,7 +347,7 @@ def test_rs_ag_layout_on_three_ranks_gloo():
                 assert np.array_equal(res[r][1][step][0][i], res[0][1][step][0][i])
 
 
-def _dp_sparse_worker(rank, world, port, q, comm_dtype):
+def _dp_sparse_worker(rank, world, port, q, comm_dtype, early=False):
     import torch.distributed as dist
     from mvp_pytorch_amd import dp
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -366,11 +366,17 @@ def _dp_sparse_worker(rank, world, port, q, comm_dtype):
         ids_b = torch.randint(0, 60, (6, 3), generator=g)
         # the ids are known before the step: note them BEFORE backward (a hot bucket is launched from
         # the gradient hook as soon as the table's gradient has landed)
-        if step == 1 and rank == 1:
+        if early and step != 1:
+            # round 6: the union formed host to host BEFORE the step (exchange_rows_early); the launch must not gather anything
+            sync.exchange_rows_early(emb.weight, [torch.arange(400)] if step == 2 else [ids_a, ids_b, None])
+            gathers = []
+            real_all_gather = dist.all_gather
+            dist.all_gather = lambda *a, **k: gathers.append(1) or real_all_gather(*a, **k)
+        elif step == 1 and rank == 1:
             pass                          # a rank that notes nothing: every rank falls back to the dense exchange
         elif step == 2:
             sync.note_rows(emb.weight, [torch.arange(400)])   # union > half the table: dense is chosen
-        else:
+        elif not (early and step == 1):
             sync.note_rows(emb.weight, ids_a)
             sync.note_rows(emb.weight, [ids_b, None])
         used_union = None
@@ -388,6 +394,9 @@ def _dp_sparse_worker(rank, world, port, q, comm_dtype):
         loss.backward()
         sync()
         sync._row_union = orig
+        if early and step != 1:
+            dist.all_gather = real_all_gather
+            assert not gathers and not sync._early_union      # nothing gathered inside the launch; the union was consumed
         out.append((local.numpy(), emb.weight.grad.detach().clone().numpy(), head.weight.grad.detach().clone().numpy(),
                     None if used_union is None else used_union.numpy()))
         sync.zero_grad()
@@ -395,17 +404,19 @@ def _dp_sparse_worker(rank, world, port, q, comm_dtype):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
-def test_grad_sync_row_sparse_gloo(comm_dtype):
+@pytest.mark.parametrize("comm_dtype,early", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True)])
+def test_grad_sync_row_sparse_gloo(comm_dtype, early):
     """Row-sparse exchange of an embedding-table gradient (world_size 2, gloo): only the union of the
     looked-up rows travels, the result equals the dense average; a rank without noted ids and a union
-    larger than half the table both fall back to the dense all-reduce on every rank."""
+    larger than half the table both fall back to the dense all-reduce on every rank.  early: the union is formed ahead of the
+    backward pass from HOST ids (exchange_rows_early, round 6) — same unions, same gradients, no all-gather inside the launch;
+    a step without it (step 1: nothing noted either) takes the late form's dense fallback."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = gu.free_port()
     tol = 1e-6 if comm_dtype == torch.float32 else 2e-2
-    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q, comm_dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q, comm_dtype, early)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])

@@ -123,7 +123,7 @@ def grad_summary(model):
 
 
 def np_batch(batch):
-    return {"in:" + k: (v.numpy() if torch.is_tensor(v) else np.array(v)) for k, v in batch.items() if k != "host_counts"}
+    return {"in:" + k: (v.numpy() if torch.is_tensor(v) else np.array(v)) for k, v in batch.items() if k != "host_counts" and not getattr(v, "host_only", False)}
 
 
 def argmax_margin(sim):
