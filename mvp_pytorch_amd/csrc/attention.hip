@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs p) {
 // Needs all of a sequence's blocks resident at once: Lp <= 128 (four waves, one key block each).
 // OCC workgroups per CU: 3 where the LDS footprint allows it (Lp <= 96: the text and visual stacks, whose workgroups
 // are short and latency-bound: -15 % on their launches), 2 for Lp = 128 (the register budget of 3 costs spills there).
-template <int OCC, bool LO32>
+template <int OCC, bool LO32, int NBMAX = 4>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   p.drop = drop_resolve(p.drop);      // device-side salt of graph-replayed steps (common.h)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -586,13 +586,13 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
   const bool owner = wave < nb;
   const int key = 32 * wave + l31;
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-  bf16x8 ds_keep[4][2];
+  bf16x8 ds_keep[NBMAX][2];      // NBMAX: 32-row blocks a sequence of this launch can have (3 for Lp <= 96: 12 -> 7 spilled registers at three workgroups per CU)
   if (owner) {
     // ---------------- phase 1: key block `wave`; key on lane, queries in registers
     const int kb = wave;
     const float mk = maskv[key];
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
+    for (int qb = 0; qb < NBMAX; ++qb) {
       if (qb < nb) {
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_fused_kernel(AttnArgs p) {
     // dS[key][query] over the V (queries 0..63) and dO (queries 64..127) tiles: row = key, 128-B rows, same chunk swizzle;
     // register e of pack8(., st) is query 32 qb + 16 st + 8 (e >> 2) + 4 hh + (e & 3)
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) {
+    for (int qb = 0; qb < NBMAX; ++qb) {
       if (qb < nb) {
         char* ts = (qb >> 1) ? tD : tV;
 #pragma unroll
@@ -892,7 +892,7 @@ extern "C" int mvptr_attention_bwd_packed(const void* qkv, const float* mask_add
   };
   int lrc;
   if (!fused) lrc = lo32 ? launch(attn_bwd_kernel<true>) : launch(attn_bwd_kernel<false>);
-  else if (occ3) lrc = lo32 ? launch(attn_bwd_fused_kernel<3, true>) : launch(attn_bwd_fused_kernel<3, false>);
+  else if (occ3) lrc = lo32 ? launch(attn_bwd_fused_kernel<3, true, 3>) : launch(attn_bwd_fused_kernel<3, false, 3>);
   else lrc = lo32 ? launch(attn_bwd_fused_kernel<2, true>) : launch(attn_bwd_fused_kernel<2, false>);
   if (lrc != MVPTR_OK) return lrc;
   MVPTR_CHECK_LAUNCH("attention_bwd");
